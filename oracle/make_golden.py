@@ -1,0 +1,325 @@
+"""TEST INFRASTRUCTURE ONLY — generates tests/golden/*.npz by running the REAL reference (imported from
+/root/reference through oracle/ref_loader.py) on the deterministic weights of oracle/weights.py, and
+checks the in-repo restatement (oracle/showo_oracle.py) against the reference while doing so.
+
+Run in the build container only:  python oracle/make_golden.py [--full]
+The fixtures it writes are committed; the GPU box never needs /root/reference.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader as R  # noqa: E402
+import showo_oracle as O  # noqa: E402
+import weights as Wt  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+def gen_config(d):
+    return ns(model=ns(showo=ns(num_vq_tokens=d.num_vq_tokens, num_new_special_tokens=d.num_new_special_tokens,
+                                llm_vocab_size=d.llm_vocab)),
+              dataset=ns(preprocessing=ns(max_seq_length=d.max_text_len)))
+
+
+def ref_showo_from_state(d, sd_np):
+    heads = d.heads
+    m = R.build_reference_showo(
+        phi_overrides=dict(hidden_size=d.hidden, intermediate_size=d.ffn, num_hidden_layers=d.layers,
+                           num_attention_heads=heads, num_key_value_heads=heads, vocab_size=d.vocab,
+                           max_position_embeddings=d.max_pos),
+        vocab_size=d.vocab, llm_vocab_size=d.llm_vocab, codebook_size=d.codebook,
+        num_vq_tokens=d.num_vq_tokens, w_clip_vit=d.w_clip_vit)
+    missing = m.load_state_dict(O.to_torch(sd_np), strict=True)
+    return m.eval()
+
+
+def t2i_ids(d, text_lens, rs, bos=None, image_tokens=None):
+    """[pad]*(T-k) + [t2i, bos, w.., eos] + [soi] + image + [eoi]  (prompting_utils.py:92-123)."""
+    T = d.max_text_len + 1
+    bos = d.llm_vocab - 10 if bos is None else bos
+    rows = []
+    for i, k in enumerate(text_lens):
+        words = rs.randint(0, d.llm_vocab - 20, size=k - 3).tolist()
+        text = [d.t2i_id, bos] + words + [bos]
+        img = [d.mask_token_id] * d.num_vq_tokens if image_tokens is None else image_tokens[i]
+        rows.append([d.pad_id] * (T - k) + text + [d.soi_id] + list(img) + [d.eoi_id])
+    return torch.tensor(rows, dtype=torch.long)
+
+
+def mmu_ids(d, n, text_len, rs):
+    """[mmu][soi] img [eoi][sot] text... (prompting_utils.py:162-212 layout, no padding needed here)."""
+    bos = d.llm_vocab - 10
+    rows = []
+    for _ in range(n):
+        img = (rs.randint(0, d.codebook, size=d.num_vq_tokens) + d.image_offset).tolist()
+        txt = rs.randint(0, d.llm_vocab - 20, size=text_len).tolist()
+        rows.append([d.mmu_id, d.soi_id] + img + [d.eoi_id, bos] + txt)
+    return torch.tensor(rows, dtype=torch.long)
+
+
+def report(name, a, b):
+    err = (a.double() - b.double()).abs().max().item()
+    scale = b.double().abs().max().item()
+    print(f"  oracle-vs-reference {name}: max|d|={err:.3e} (scale {scale:.3e})")
+    return err
+
+
+def make_tiny_showo():
+    print("[tiny showo]")
+    d = Wt.ShowoDims(**Wt.TINY)
+    sd_np = Wt.make_showo_state(d, seed=11)
+    ref = ref_showo_from_state(d, sd_np)
+    P = R.load_reference().prompting
+    sd = O.to_torch(sd_np)
+    rs = np.random.RandomState(3)
+    out = {}
+    # ---- (1) forward, t2i masks with different pad counts (CFG-style batch), reference mask builder
+    ids = t2i_ids(d, [5, 8, 3, 9], rs)
+    mask = P.create_attention_mask_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id,
+                                                rm_pad_in_image=True)
+    with torch.no_grad():
+        lg = ref(ids, attention_mask=mask)
+    assert torch.equal(O.mask_t2i(ids, d.pad_id, d.soi_id, d.eoi_id), mask.float())
+    e = report("t2i logits", O.showo_logits(sd, d, ids, attention_mask=mask), lg)
+    assert e < 2e-4
+    out.update(t2i_ids=ids.numpy(), t2i_mask=mask.numpy().astype(np.float32), t2i_logits=lg.numpy())
+    # ---- (2) mmu mask
+    ids_m = mmu_ids(d, 2, 8, rs)
+    mask_m = P.create_attention_mask_for_mmu(ids_m, eoi_id=d.eoi_id)
+    with torch.no_grad():
+        lg_m = ref(ids_m, attention_mask=mask_m)
+    assert torch.equal(O.mask_mmu(ids_m, d.eoi_id), mask_m.float())
+    assert report("mmu logits", O.showo_logits(sd, d, ids_m, attention_mask=mask_m), lg_m) < 2e-4
+    out.update(mmu_ids=ids_m.numpy(), mmu_mask=mask_m.numpy().astype(np.float32), mmu_logits=lg_m.numpy())
+    # ---- (3) mixed training batch: 2 t2i + 1 lm + 2 mmu, three CE losses + grads of a few tensors
+    L = ids.shape[1]
+    img_gt = rs.randint(0, d.codebook, size=(2, d.num_vq_tokens)) + d.image_offset
+    masked = rs.rand(2, d.num_vq_tokens) < 0.6
+    img_in = np.where(masked, d.mask_token_id, img_gt)
+    ids_t = t2i_ids(d, [6, 9], rs, image_tokens=img_in)
+    lab_t = ids_t.clone()
+    lab_t[:, -(d.num_vq_tokens + 1):-1] = torch.from_numpy(np.where(masked, img_gt, -100))
+    lab_t[lab_t == d.pad_id] = -100
+    ids_l = torch.from_numpy(rs.randint(0, d.llm_vocab - 20, size=(1, L))).long()
+    lab_l = ids_l.clone()
+    ids_u = mmu_ids(d, 2, L - d.num_vq_tokens - 4, rs)
+    lab_u = ids_u.clone()
+    lab_u[:, : d.num_vq_tokens + 3] = -100
+    ids_all = torch.cat([ids_t, ids_l, ids_u])
+    labels = torch.cat([lab_t, lab_l, lab_u])
+    m_t = P.create_attention_mask_predict_next(ids_t, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id,
+                                               rm_pad_in_image=True)
+    # lm flow: rm_pad_in_image is left False by the trainer (training/train.py:530-533)
+    m_l = P.create_attention_mask_predict_next(ids_l, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id)
+    assert torch.equal(O.mask_t2i(ids_l, d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False), m_l.float())
+    m_u = P.create_attention_mask_for_mmu(ids_u, eoi_id=d.eoi_id)
+    mask_all = torch.cat([m_t, m_l, m_u]).float()
+    ref.zero_grad()
+    lg_a, l1, l2, l3 = ref(ids_all, attention_mask=mask_all, labels=labels, batch_size_t2i=2, batch_size_lm=1,
+                           batch_size_mmu=2, max_seq_length=d.max_text_len)
+    loss = 1.0 * l1 + 0.1 * l2 + 1.0 * l3
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    o = O.showo_forward(sd, d, ids_all, attention_mask=mask_all, labels=labels, batch_size_t2i=2,
+                        batch_size_lm=1, batch_size_mmu=2, max_seq_length=d.max_text_len)
+    for n_, a, b in zip(("loss_t2i", "loss_lm", "loss_mmu"), o[1:], (l1, l2, l3)):
+        assert report(n_, a, b.detach()) < 1e-4
+    out.update(train_ids=ids_all.numpy(), train_labels=labels.numpy(), train_mask=mask_all.numpy(),
+               train_logits=lg_a.detach().numpy(),
+               train_losses=np.array([l1.item(), l2.item(), l3.item()], dtype=np.float64))
+    for k in ("showo.model.layers.0.self_attn.q_proj.weight", "showo.model.layers.1.mlp.fc2.weight",
+              "showo.lm_head.bias", "showo.model.layers.0.input_layernorm.weight",
+              "showo.model.layers.1.self_attn.k_layernorm.bias", "showo.model.final_layernorm.weight",
+              "showo.model.layers.0.self_attn.dense.bias", "showo.model.layers.0.mlp.fc1.bias"):
+        out["grad::" + k] = grads[k].numpy()
+    out["grad::embed_rows"] = grads["showo.model.embed_tokens.weight"][ids_all[0, :8]].numpy()
+    out["grad::embed_row_ids"] = ids_all[0, :8].numpy()
+    # ---- (4) quirk: batch_size_mmu=0 selects the whole batch (modeling_showo.py:95-98)
+    with torch.no_grad():
+        _, q1, q2, q3 = ref(ids_all, attention_mask=mask_all, labels=labels, batch_size_t2i=2, batch_size_lm=3,
+                            batch_size_mmu=0, max_seq_length=d.max_text_len)
+    oq = O.showo_forward(sd, d, ids_all, attention_mask=mask_all, labels=labels, batch_size_t2i=2,
+                         batch_size_lm=3, batch_size_mmu=0, max_seq_length=d.max_text_len)
+    assert report("quirk loss_mmu", oq[3], q3) < 1e-4
+    out["quirk_losses"] = np.array([q1.item(), q2.item(), q3.item()], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "showo_tiny_forward.npz"), **out)
+
+    # ---- (5) t2i_generate trajectory with recorded noise
+    print("[tiny t2i_generate]")
+    steps, w = 6, 1.75
+    rs = np.random.RandomState(4)
+    ids_c = t2i_ids(d, [7, 4, 9], rs)
+    ids_u = t2i_ids(d, [3, 3, 3], rs)
+    # one sample is an inpainting case: some tokens already known
+    known = rs.rand(d.num_vq_tokens) < 0.4
+    ids_c[2, -(d.num_vq_tokens + 1):-1] = torch.from_numpy(
+        np.where(known, rs.randint(0, d.codebook, size=d.num_vq_tokens) + d.image_offset, d.mask_token_id))
+    ids_c0 = ids_c.clone()
+    mask = P.create_attention_mask_predict_next(torch.cat([ids_c, ids_u]), pad_id=d.pad_id, soi_id=d.soi_id,
+                                                eoi_id=d.eoi_id, rm_pad_in_image=True)
+    gen = torch.Generator().manual_seed(7)
+    rec = dict(exp=[], uni=[], multi=[], fwd_in=[], fwd_out=[])
+    real_multinomial = torch.multinomial
+    real_uniform = torch.Tensor.uniform_
+    real_forward = ref.forward
+
+    def rec_multinomial(p, n, generator=None, **kw):
+        st = generator.get_state()
+        q = torch.empty_like(p).exponential_(1, generator=generator)
+        mine = torch.argmax(p / q, dim=-1, keepdim=True)
+        generator.set_state(st)
+        res = real_multinomial(p, n, generator=generator, **kw)
+        assert torch.equal(res, mine), "torch.multinomial != argmax(p/Exp(1))"
+        rec["exp"].append(q.clone())
+        rec["multi"].append(res.clone())
+        return res
+
+    def rec_uniform(self, a=0, b=1, generator=None):
+        r = real_uniform(self, a, b, generator=generator)
+        rec["uni"].append(r.clone())
+        return r
+
+    def rec_forward(x, **kw):
+        rec["fwd_in"].append(x.clone())
+        y = real_forward(x, **kw)
+        rec["fwd_out"].append(y.clone())
+        return y
+
+    torch.multinomial = rec_multinomial
+    torch.Tensor.uniform_ = rec_uniform
+    ref.forward = rec_forward
+    try:
+        with torch.no_grad():
+            ids_run = ids_c.clone()
+            res = ref.t2i_generate(input_ids=ids_run, uncond_input_ids=ids_u.clone(), attention_mask=mask,
+                                   temperature=1.0, timesteps=steps, guidance_scale=w,
+                                   noise_schedule=R.load_reference().sampling.cosine_schedule, generator=gen,
+                                   config=gen_config(d))
+    finally:
+        torch.multinomial = real_multinomial
+        torch.Tensor.uniform_ = real_uniform
+        ref.forward = real_forward
+    noise = O.RecordedNoise(rec["exp"], rec["uni"])
+    tr = []
+    o_ids = ids_c0.clone()
+    o_res = O.t2i_generate(sd, d, o_ids, ids_u.clone(), mask, 1.0, steps, w, noise=noise, trace=tr)
+    assert torch.equal(o_res, res), "oracle t2i_generate trajectory differs from the reference"
+    assert torch.equal(o_ids, ids_run)
+    for s in range(steps):
+        assert torch.equal(tr[s]["input_ids"], rec["fwd_in"][s][:3])
+    print("  oracle t2i_generate == reference (ids bit-exact over", steps, "steps)")
+    ml, tp = O.t2i_step_constants(steps, d.num_vq_tokens)
+    np.savez_compressed(
+        os.path.join(GOLD, "showo_tiny_t2i.npz"),
+        ids_cond=ids_c0.numpy(), ids_uncond=ids_u.numpy(), mask=mask.numpy().astype(np.float32),
+        steps=steps, guidance=w, exp_noise=torch.stack(rec["exp"]).numpy(), uniform=torch.stack(rec["uni"]).numpy(),
+        multinomial=torch.stack(rec["multi"]).numpy(), fwd_in=torch.stack(rec["fwd_in"]).numpy(),
+        fwd_logits=torch.stack(rec["fwd_out"]).numpy(), result=res.numpy(), final_input_ids=ids_run.numpy(),
+        mask_len=np.array(ml), temps=np.array(tp))
+
+    # ---- (6) mmu_generate (top_k=1 → deterministic)
+    print("[tiny mmu_generate]")
+    rs = np.random.RandomState(5)
+    ids_m = mmu_ids(d, 1, 5, rs)
+    mask_m = P.create_attention_mask_for_mmu(ids_m, eoi_id=d.eoi_id)
+    toks = ref.mmu_generate(ids_m.clone(), attention_mask=mask_m.clone(), max_new_tokens=6, top_k=1)
+    toks_o = O.mmu_generate(sd, d, ids_m.clone(), attention_mask=mask_m.float().clone(), max_new_tokens=6, top_k=1)
+    assert [int(t) for t in toks] == [int(t) for t in toks_o], (toks, toks_o)
+    print("  tokens", [int(t) for t in toks])
+    np.savez_compressed(os.path.join(GOLD, "showo_tiny_mmu.npz"), ids=ids_m.numpy(),
+                        mask=mask_m.numpy().astype(np.float32), tokens=np.array([int(t) for t in toks]))
+
+
+def make_magvit():
+    print("[magvit full-arch, small images]")
+    sd_np = Wt.make_magvit_state(seed=21)
+    ref = R.build_reference_magvit()
+    ref.load_state_dict(O.to_torch(sd_np), strict=True)
+    sd = O.to_torch(sd_np)
+    rs = np.random.RandomState(6)
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(2, 3, 64, 64)).astype(np.float32))
+    with torch.no_grad():
+        z = ref.quantize(ref.encoder(x))  # dict
+        z_enc = ref.encoder(x)
+        ids = ref.get_code(x)
+        zq_ref, ids2 = ref.encode(x)
+        img = ref.decode_code(ids)
+        ids_ns = torch.from_numpy(rs.randint(0, 8192, size=(1, 8))).long()
+        img_ns = ref.decode_code(ids_ns, shape=(2, 4))
+    assert torch.equal(ids, ids2)
+    o_ids, o_z = O.magvit_get_code(sd, x, return_z=True)
+    report("encoder z", o_z, z_enc)
+    agree = (o_ids == ids).float().mean().item()
+    print("  get_code agreement oracle/ref:", agree)
+    assert agree == 1.0
+    assert report("decode_code", O.magvit_decode_code(sd, ids), img) < 1e-3
+    assert report("decode_code shape=(2,4)", O.magvit_decode_code(sd, ids_ns, shape=(2, 4)), img_ns) < 1e-3
+    np.savez_compressed(os.path.join(GOLD, "magvit_small.npz"), seed=21, x=x.numpy(), z=z_enc.numpy(),
+                        ids=ids.numpy(), image=img.numpy(), ids_ns=ids_ns.numpy(), image_ns=img_ns.numpy())
+    # LFQ known-answer vectors straight from the reference quantizer (edge cases of SURVEY §8c.1)
+    zz = rs.standard_normal(size=(3, 13, 4, 5)).astype(np.float32)
+    zz[0, :, 0, 0] = 0.0
+    zz[0, :, 0, 1] = -0.0
+    zz[0, :, 0, 2] = 1e-9
+    zz[0, :, 0, 3] = -1e-9
+    zz[0, :, 1, 0] = np.float32(1e-45)  # denormal
+    zz[0, :, 1, 1] = -np.float32(1e-45)
+    zz[1, ::2, 2, 2] = 0.0
+    zt = torch.from_numpy(zz)
+    with torch.no_grad():
+        q = ref.quantize(zt)
+        kid = ref.quantize.get_indices(q["z"]).reshape(3, -1)
+        back = ref.quantize.get_codebook_entry(kid[:, :16], shape=(4, 4))
+    assert np.array_equal(O.lfq_pack_np(zz), kid.numpy())
+    assert np.array_equal(O.lfq_unpack_np(kid[:, :16].numpy(), shape=(4, 4)), back.numpy())
+    np.savez_compressed(os.path.join(GOLD, "lfq_kat.npz"), z=zz, ids=kid.numpy(), back=back.numpy())
+    print("  LFQ KATs ok")
+
+
+def make_full_showo():
+    print("[full-size showo: logits subset]  (needs ~20 GB RAM, a few minutes)")
+    d = Wt.ShowoDims()
+    sd_np = Wt.make_showo_state(d, seed=0)
+    ref = ref_showo_from_state(d, sd_np)
+    P = R.load_reference().prompting
+    rs = np.random.RandomState(8)
+    ids = t2i_ids(d, [7, 3], rs, bos=50256)
+    mask = P.create_attention_mask_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id,
+                                                rm_pad_in_image=True)
+    with torch.no_grad():
+        lg = ref(ids, attention_mask=mask)
+    rows = np.array([0, 100, 122, 128, 129, 130, 257, 386])
+    cols = np.concatenate([np.arange(0, d.vocab, 11), np.arange(d.image_offset, d.image_offset + 64)])
+    sub = lg[:, rows][:, :, cols].numpy()
+    sd = O.to_torch(sd_np)
+    o = O.showo_logits(sd, d, ids, attention_mask=mask)
+    report("full logits", o, lg)
+    np.savez_compressed(os.path.join(GOLD, "showo_full_logits_subset.npz"), seed=0, ids=ids.numpy(), rows=rows,
+                        cols=cols, logits=sub, logit_absmax=float(lg.abs().max()), logit_std=float(lg.std()))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_grad_enabled(True)
+    if a.only in ("", "tiny"):
+        make_tiny_showo()
+    if a.only in ("", "magvit"):
+        make_magvit()
+    if a.full or a.only == "full":
+        make_full_showo()
+    print("done")
