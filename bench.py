@@ -1,0 +1,162 @@
+"""bench.py — t2i images/s @256x256 (18 denoise steps, CFG on, batch 8) + decode_code on MI355X.
+
+One "step" = one pass of the hot path over one batch: Showo.t2i_generate (18 mask-predict steps on a
+[16,387] CFG batch) followed by MAGVITv2.decode_code of the 8 results (BASELINE.json configs[1]).
+Inputs (ids, mask) are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+Multi-GPU: images are independent -> N replicas, no data-path collective ("weak" scaling).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def build_inputs(d, B, O):
+    rs = np.random.RandomState(0)
+    rows_c, rows_u = [], []
+    for i in range(B):
+        k = 5 + (i * 5) % 36  # text lengths 5..40: different pad counts exercise the per-sample mask
+        text = [d.t2i_id, 50256] + rs.randint(0, 50256, size=k - 3).tolist() + [50256]
+        rows_c.append([d.pad_id] * (129 - k) + text + [d.soi_id] + [d.mask_token_id] * d.num_vq_tokens + [d.eoi_id])
+        rows_u.append([d.pad_id] * 126 + [d.t2i_id, 50256, 50256] + [d.soi_id] + [d.mask_token_id] * d.num_vq_tokens + [d.eoi_id])
+    ic, iu = torch.tensor(rows_c), torch.tensor(rows_u)
+    mask = O.mask_t2i(torch.cat([ic, iu]), d.pad_id, d.soi_id, d.eoi_id)
+    return ic, iu, mask
+
+
+def cpu_baseline(d, sd_t, O, steps_sample=3):
+    """oracle (CPU restatement of the reference, fp32, all host cores) on a bounded sample: `steps_sample`
+    denoise steps of ONE prompt with CFG ([2,387]) + one decode is timed and extrapolated to 18 steps."""
+    torch.set_num_threads(os.cpu_count())
+    ic, iu, mask = build_inputs(d, 1, O)
+    t0 = time.time()
+    O.t2i_generate(sd_t, d, ic.clone(), iu.clone(), mask, 1.0, steps_sample, 5.0)
+    t_steps = time.time() - t0
+    per_step = t_steps / steps_sample
+    est = 18 * per_step  # decode (0.3 TFLOP of 38.4) is <1% and is left out of the CPU estimate, favouring the CPU
+    return {"value": 1.0 / est, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps_sample} of 18 denoise steps of 1 prompt (CFG, [2,387], fp32 oracle) timed = {t_steps:.1f}s, "
+                      f"scaled x18/{steps_sample}; decode_code omitted (<1% of FLOPs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import showo_amd
+    import showo_oracle as O
+    import weights as Wt
+    L = showo_amd._lib
+    d = Wt.ShowoDims()
+    B = a.batch
+    # random-init weights of the true architecture (no checkpoints offline): generated on the GPU, N(0, 0.02)
+    torch.manual_seed(0)
+    model = showo_amd.Showo(False, d.vocab, d.llm_vocab, codebook_size=d.codebook, num_vq_tokens=d.num_vq_tokens,
+                            max_batch=2 * B, max_seq=387)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "layernorm" in n and n.endswith("weight"):
+                p.normal_(1.0, 0.1)
+            elif n.endswith("bias"):
+                p.normal_(0.0, 0.02)
+    vq = showo_amd.MAGVITv2(max_batch=B, max_res=256).cuda().eval()
+    cfg = showo_amd.gen_config()
+    ic, iu, mask = build_inputs(d, B, O)
+    ic_d, iu_d, mask_d = ic.cuda(), iu.cuda(), mask.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1 + rank)
+
+    def step():
+        ids = ic_d.clone()
+        toks = model.t2i_generate(input_ids=ids, uncond_input_ids=iu_d, attention_mask=mask_d, temperature=1.0, timesteps=18,
+                                  guidance_scale=5.0, generator=gen, config=cfg)
+        toks = torch.clamp(toks, max=d.codebook - 1, min=0)
+        return vq.decode_code(toks)
+
+    for _ in range(a.warmup):
+        img = step()
+    assert tuple(img.shape) == (B, 3, 256, 256) and torch.isfinite(img).all()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    L.call("showo_prof_reset")
+    L.call("showo_prof_enable", 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    L.call("showo_prof_enable", 0)
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_gemm, n_gemm, fl_gemm = C.c_double(), C.c_int64(), C.c_double()
+    L.call("showo_prof_read", 0, C.byref(ms_gemm), C.byref(n_gemm), C.byref(fl_gemm))
+    ms_attn, n_attn, fl_attn = C.c_double(), C.c_int64(), C.c_double()
+    L.call("showo_prof_read", 1, C.byref(ms_attn), C.byref(n_attn), C.byref(fl_attn))
+    ms_conv, n_conv, fl_conv = C.c_double(), C.c_int64(), C.c_double()
+    L.call("showo_prof_read", 2, C.byref(ms_conv), C.byref(n_conv), C.byref(fl_conv))
+    L.call("showo_prof_reset")
+
+    if rank == 0:
+        images = B * a.steps * world
+        value = images / dt
+        peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+        ach = fl_gemm.value / (ms_gemm.value * 1e-3) / 1e12 if ms_gemm.value > 0 else 0.0
+        out = {
+            "metric": "t2i images/sec @256x256 (18 denoise steps)", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg2: configs/showo_demo.yaml t2i 256x256, batch 8 prompts, CFG 5.0 (forward on [16,387]), "
+                                   "18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M",
+                       "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
+                       "algorithmic_tflop_per_image": 38.4, "end_to_end_algorithmic_tflops": value * 38.4},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM: qkv/dense/fc1/fc2/lm_head)",
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "launches": int(n_gemm.value), "avg_launch_ms": ms_gemm.value / max(1, n_gemm.value),
+                         "time_share_of_step": ms_gemm.value * 1e-3 / dt,
+                         "attention": {"achieved": fl_attn.value / max(1e-9, ms_attn.value * 1e-3) / 1e12, "time_share": ms_attn.value * 1e-3 / dt},
+                         "vq_conv": {"achieved": fl_conv.value / max(1e-9, ms_conv.value * 1e-3) / 1e12, "time_share": ms_conv.value * 1e-3 / dt}},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            sd_t = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            out["cpu_baseline"] = cpu_baseline(d, sd_t, O)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+/*
+ * showo_hip.h — C ABI of libshowo_hip.so: the MI355X (gfx950) native Show-o hot path.
+ *
+ * The reference (showlab/Show-o) is pure Python/PyTorch and has no FFI of its own; its boundary for this
+ * path is the Python class API `models.Showo` / `models.MAGVITv2` (reference models/__init__.py:1-4).
+ * This header is the plain-C surface those classes' replacements (show-o_amd/modeling_*.py) bind through
+ * ctypes.  Every entry point names the reference code it replaces (paths relative to the reference
+ * root).  Conventions:
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on it;
+ *   - return value: 0 on success, non-zero on error; showo_last_error() returns a static description;
+ *   - no allocation ownership crosses the boundary except handles created/destroyed here;
+ *   - bf16 tensors are raw uint16 bit patterns; "ids" are int64 as in the reference.
+ */
+#ifndef SHOWO_HIP_H
+#define SHOWO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHOWO_ABI_VERSION 1
+
+const char* showo_last_error(void);
+int showo_abi_version(void);
+/* number of compute units / wave size of the current device; used by bench/tests for sanity. */
+int showo_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
+
+/* per-launch HIP-event timing of the hot kernels (bench.py roofline leg).  kind: 0 = GEMM, 1 = attention,
+ * 2 = conv.  read() synchronises the device and returns summed elapsed ms, launch count, summed algorithmic flops. */
+int showo_prof_enable(int on);
+int showo_prof_reset(void);
+int showo_prof_read(int kind, double* total_ms, int64_t* launches, double* work);
+
+/* ---------------------------------------------------------------------------------------------
+ * MAGVIT-v2 lookup-free quantizer (reference models/modeling_magvitv2.py:201-206, 208-221, 239-241)
+ * ------------------------------------------------------------------------------------------- */
+/* z: fp32 [B, C, hw] (NCHW flattened) -> ids int64 [B, hw]; bit for channel c (MSB = channel 0) is (z_c > 0). */
+int showo_lfq_pack_nchw(const float* z, int64_t* ids, int B, int C, int hw, void* stream);
+/* same, channel-last input z: fp32 [B, hw, ldz] (first C channels used). */
+int showo_lfq_pack_nhwc(const float* z, int64_t* ids, int B, int C, int hw, int ldz, void* stream);
+/* ids int64 [B, hw] -> z_q fp32 [B, C, hw] of +-1 (get_codebook_entry, NCHW as the reference returns it). */
+int showo_lfq_unpack_nchw(const int64_t* ids, float* zq, int B, int C, int hw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Transformer building blocks (reference models/phi.py)
+ * ------------------------------------------------------------------------------------------- */
+/* nn.LayerNorm over the last dim (phi.py:744,776,937,1065): x fp32 [rows_in, H] -> y bf16 [rows, H].
+ * row_index (optional, int32 [rows]) gathers input rows (used to run the final LN on image rows only). */
+int showo_layernorm_f32_bf16(const float* x, const float* w, const float* b, uint16_t* y, const int32_t* row_index,
+                             int rows, int H, float eps, void* stream);
+
+/* epilogues of showo_gemm_bf16 */
+enum {
+    SHOWO_EPI_BF16 = 0,       /* out bf16 = acc + bias                       (q/k/v proj, phi.py:657-659)        */
+    SHOWO_EPI_GELU_BF16 = 1,  /* out bf16 = gelu_new(acc + bias)              (fc1 + act, phi.py:208-210)         */
+    SHOWO_EPI_F32 = 2,        /* out fp32 = acc + bias                        (lm_head + .float(), phi.py:1182-3) */
+    SHOWO_EPI_RESID_F32 = 3   /* out fp32 = resid + acc + bias (resid may alias out) (dense/fc2 + residual, phi.py:727,790) */
+};
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias[N]); A, W bf16 row-major with leading dims lda, ldw (elements);
+ * K % 64 == 0.  `bias` fp32 or NULL.  `bias_per_row` != 0 adds bias[m] instead of bias[n]. */
+int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
+                    void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, void* stream);
+
+/* fp32 -> bf16 cast (weight packing) */
+int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+
+/* embedding gather (phi.py:1006): ids int64 [T] -> x fp32 [T, H] from table fp32 [V, H]. */
+int showo_embed_f32(const int64_t* ids, const float* table, float* x, int T, int H, int V, void* stream);
+
+/* q/k per-head LayerNorm + partial RoPE + head-major relayout (phi.py:661-694):
+ * qkv bf16 [B*L, 3*nH*64] (q|k|v) -> Q bf16 [B,nH,L,64] (pre-scaled by 1/sqrt(64)), K bf16 [B,nH,L,64],
+ * Vt bf16 [B,nH,64,Lp] (transposed V, Lp % 64 == 0, pad columns zero).  The L new tokens sit at positions
+ * pos0 .. pos0+L-1 (pos0 > 0 = KV-cache append): K rows / Vt columns pos0.. are written, K has Lcap rows per head.
+ * cos/sin: fp32 [max_pos, rot] tables built exactly as PhiRotaryEmbedding does (phi.py:86-102). */
+int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                  const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                  int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream);
+
+/* Compress an additive attention mask [B,1,Lq,Lk] fp32 (values 0 / very negative, as built by
+ * training/prompting_utils.py:466-511, 591-624) into per-row visibility intervals
+ * iv int32 [B, Lq, 4] = (lo1, hi1, lo2, hi2): key c is visible iff lo1<=c<hi1 or lo2<=c<hi2.
+ * flag int32[1] is set to 1 if some row is not representable (more than two runs, or a value that is
+ * neither 0 nor <= -1e9); the attention kernel then adds the dense mask instead. */
+int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag, int B, int Lq, int Lk, void* stream);
+
+/* Fused omni-attention forward (replaces SDPA + dense additive mask, phi.py:715-722):
+ * O[b, l, h*64 + d] bf16 = softmax(Q K^T + M) V.  Q,K,Vt as produced by showo_qk_prep (Q already scaled).
+ * iv/flag from showo_mask_compress; dense_mask may be NULL iff *flag is known to be 0.
+ * Lq query rows (row r attends with mask row r); Lk keys; K holds Lcap rows per head, Vt rows are Lp long.
+ * iv == NULL and flag == NULL: causal (query r sees keys <= r + Lk - Lq). */
+int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
+                   const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * t2i sampler (reference models/modeling_showo.py:140-179, models/sampling.py:14-36)
+ * ------------------------------------------------------------------------------------------- */
+/* One categorical draw per image token from softmax((1+w)*cond - w*uncond) using the algorithm
+ * torch.multinomial uses for one draw (argmax_i p_i / E_i, E~Exp(1)).
+ * logits_c/logits_u: fp32 [B*N, ld] (uncond NULL -> no CFG).  cur: int64 [B,N] current code ids or mask_id.
+ * exp_noise: optional fp32 [B*N, V] injected noise (tests); else Philox(seed, step).
+ * out: sampled int64 [B,N] (known tokens keep their id), sel_prob fp32 [B,N] (FLT_MAX for known tokens). */
+int showo_cfg_softmax_sample(const float* logits_c, const float* logits_u, int ld, float guidance, const int64_t* cur,
+                             int64_t mask_id, const float* exp_noise, uint64_t seed, uint32_t step,
+                             int64_t* sampled, float* sel_prob, int B, int N, int V, void* stream);
+/* mask_by_random_topk + write-back (modeling_showo.py:166-179): per sample b,
+ * mask_len = max(1, min(#unknown-1, mask_len_f)); conf = log(p)+temp*gumbel(u); cut = sort(conf)[mask_len];
+ * masking = conf < cut; ids_cond/ids_uncond[b, img_start + i] = masking ? mask_id : sampled+offset;
+ * cur[b,i] = masking ? mask_id : sampled.  uniform: optional injected fp32 [B,N] draws. */
+int showo_mask_by_topk(const float* sel_prob, const int64_t* sampled, int64_t* cur, int64_t* ids_cond,
+                       int64_t* ids_uncond, int ld_ids, int img_start, int64_t mask_id, int64_t id_offset,
+                       float mask_len_f, float temperature, const float* uniform, uint64_t seed, uint32_t step,
+                       uint8_t* masking_out, int B, int N, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * VQGAN building blocks (reference models/common_modules.py, channel-last activations)
+ * ------------------------------------------------------------------------------------------- */
+/* GroupNorm(32, eps) statistics over x fp32 NHWC [B, HW, C]: stats double [B, 32, 2] = (sum, sumsq); zeroed inside. */
+int showo_gn_stats(const float* x, double* stats, int B, int HW, int C, void* stream);
+/* y bf16 NHWC = act((x - mean) * rstd * gamma + beta); act = swish if do_swish (common_modules.py:16-24). */
+int showo_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, uint16_t* y,
+                   int B, int HW, int C, float eps, int do_swish, void* stream);
+/* 3x3 convolution as implicit GEMM on MFMA.  x bf16 NHWC [B,Hin,Win,Cin]; w bf16 [Cout][3][3][Cin];
+ * out fp32 NHWC [B,Hout,Wout,Cout] = conv + bias (+ resid).  mode: 0 = stride 1 pad 1;
+ * 1 = nearest-2x upsample then stride 1 pad 1 (common_modules.py:36-40); 2 = pad (0,1,0,1) then stride 2
+ * (common_modules.py:83-88).  Cin % 64 == 0 (thin inputs are zero-padded to 64 channels); any Cout. */
+int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, const float* resid, float* out,
+                       int B, int Hin, int Win, int Cin, int Cout, int mode, void* stream);
+/* direct convolution for the thin layers (Cin or Cout in {3,13}): x fp32 NHWC, w fp32 [Cout][k][k][Cin],
+ * out fp32 NHWC; ksize 1 or 3, stride 1, pad (k-1)/2. */
+int showo_conv_small_f32(const float* x, const float* w, const float* bias, float* out, int B, int H, int W,
+                         int Cin, int Cout, int ksize, void* stream);
+/* row softmax with scale: x fp32 [rows, n] -> y bf16 [rows, ldy] = softmax(x * scale) (AttnBlock, common_modules.py:199-201) */
+int showo_softmax_rows_bf16(const float* x, uint16_t* y, int rows, int n, int ldy, float scale, void* stream);
+/* fp32 [P, C] -> bf16 [P, Cpad] with zero-padded channels (feeds the MFMA conv for the 3-/13-channel inputs) */
+int showo_pad_cast_bf16(const float* x, uint16_t* y, int64_t P, int C, int Cpad, void* stream);
+/* ids int64 [B, hw] -> z_q fp32 [B, hw, C] (channel-last form of get_codebook_entry) */
+int showo_lfq_unpack_nhwc(const int64_t* ids, float* zq, int B, int C, int hw, void* stream);
+/* layout changes at the image / latent boundary */
+int showo_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int HW, void* stream);
+int showo_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engines: whole-module entry points.  Handles own packed bf16 weights + workspaces in HBM.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct showo_engine showo_engine;
+typedef struct {
+    int hidden, layers, heads, ffn, vocab;
+    int rotary_dim, max_pos;
+    float ln_eps, rope_theta;
+    int max_batch, max_seq; /* workspace sizing: tokens = max_batch*max_seq */
+} showo_engine_config;
+
+int showo_engine_create(const showo_engine_config* cfg, showo_engine** out);
+void showo_engine_destroy(showo_engine* e);
+/* Load one tensor by its REFERENCE state-dict key, e.g.
+ * "showo.model.layers.3.self_attn.q_proj.weight"; src = device fp32, n = element count.  GEMM weights are
+ * converted to bf16 and q/k/v are packed into one [3H,H] matrix.  cos/sin tables: keys "rope.cos"/"rope.sin". */
+int showo_engine_load(showo_engine* e, const char* key, const float* src, int64_t n, void* stream);
+/* number of tensors still missing (0 = ready) */
+int showo_engine_missing(const showo_engine* e);
+/* Showo.forward without labels (modeling_showo.py:76-79 -> phi.py:953-1183):
+ * ids int64 [B,L] or embeds fp32 [B,L,H] (exactly one non-NULL); mask fp32 [B,1,L,L] or NULL (causal);
+ * logits fp32 [B,L,vocab]. */
+int showo_engine_forward(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B, int L,
+                         float* logits, void* stream);
+/* Final-LN'ed hidden rows + restricted lm_head: logits fp32 [nrows, ncols] for token rows `rows`
+ * (int32 [nrows], index into B*L) and vocabulary columns [col0, col0+ncols).  Same math as the reference
+ * restricted to the entries t2i_generate consumes (modeling_showo.py:144). */
+int showo_engine_forward_rows(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B, int L,
+                              const int32_t* rows, int nrows, int col0, int ncols, float* logits, void* stream);
+/* Showo.t2i_generate (modeling_showo.py:104-181).  ids_cond int64 [B,L] is updated in place like the
+ * reference; ids_uncond may be NULL (no CFG).  mask fp32 [(2)B,1,L,L].  mask_len_host/temps_host: per-step
+ * host constants (floor(N*schedule((k+1)/T)) and the compounding temperature).  use_graph: capture one
+ * denoise step into a hipGraph and replay it.  Optional injected noise (tests): exp_noise [steps,B*N,V],
+ * uniform [steps,B,N].  out sampled int64 [B,N]. */
+int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int64_t* ids_uncond, const float* mask, int B, int L,
+                              int num_vq_tokens, int text_len, int64_t mask_id, int id_offset, int codebook,
+                              float guidance, int steps, const float* mask_len_host, const float* temps_host,
+                              uint64_t seed, const float* exp_noise, const float* uniform, int use_graph,
+                              int64_t* sampled_out, void* stream);
+/* Incremental (KV-cached) decode used by mmu_generate (modeling_showo.py:183-240).  prefill: run the prompt
+ * (ids or embeds, mask [1,1,L,L]) and keep K/V; step: append one token (id or embedding row) whose mask row
+ * is `last prompt mask row + causal` exactly as the reference grows it (modeling_showo.py:203-217).
+ * logits_last fp32 [vocab] = logits of the last position. */
+int showo_engine_prefill(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L,
+                         float* logits_last, void* stream);
+int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* embed, float* logits_last, void* stream);
+/* greedy/top-k=1 pick on device: out int64[1] = argmax(logits) (first maximal index, like torch.topk/multinomial on a one-hot). */
+int showo_argmax_f32(const float* x, int n, int64_t* out, void* stream);
+
+typedef struct showo_vq showo_vq;
+typedef struct {
+    int ch, z_channels;
+    int enc_ch_mult[8], enc_blocks[8], enc_levels;
+    int dec_ch_mult[8], dec_blocks[8], dec_levels;
+    int max_batch, max_res; /* workspace sizing */
+} showo_vq_config;
+int showo_vq_create(const showo_vq_config* cfg, showo_vq** out);
+void showo_vq_destroy(showo_vq* v);
+/* key = reference state-dict key ("decoder.up.3.block.0.conv1.weight", ...); src fp32 in the reference's
+ * layout (conv: [Cout,Cin,kh,kw]); repacked to channel-last bf16 inside. */
+int showo_vq_load(showo_vq* v, const char* key, const float* src, int64_t n, void* stream);
+int showo_vq_missing(const showo_vq* v);
+/* MAGVITv2.decode_code (modeling_magvitv2.py:429-433): ids int64 [B,h*w] -> image fp32 NCHW [B,3,16h,16w]. */
+int showo_vq_decode_code(showo_vq* v, const int64_t* ids, int B, int h, int w, float* image, void* stream);
+/* MAGVITv2.get_code (modeling_magvitv2.py:423-427): pixels fp32 NCHW [B,3,H,W] -> ids int64 [B,(H/16)*(W/16)];
+ * z_out (optional) fp32 [B,13,H/16,W/16] = pre-quantisation latents (for the |z|<eps agreement test). */
+int showo_vq_get_code(showo_vq* v, const float* pixels, int B, int H, int W, int64_t* ids, float* z_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

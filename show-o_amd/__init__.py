@@ -1,0 +1,11 @@
+"""show-o_amd — MI355X (gfx950) native hot path of showlab/Show-o.
+
+Public names mirror the reference's `models/__init__.py:1-4`:
+    Showo, MAGVITv2, get_mask_chedule
+All arithmetic runs in hand-written HIP kernels behind the C ABI of `libshowo_hip.so`
+(include/showo_hip.h); see DESIGN.md / INTEGRATION.md.
+"""
+from .sampling import get_mask_chedule, cosine_schedule  # noqa: F401
+from .modeling_showo import Showo, gen_config  # noqa: F401
+from .modeling_magvitv2 import MAGVITv2  # noqa: F401
+from . import _lib  # noqa: F401

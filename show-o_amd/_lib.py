@@ -1,0 +1,144 @@
+"""ctypes binding of libshowo_hip.so (the C ABI declared in include/showo_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call below passes raw device
+pointers (`tensor.data_ptr()`) and the current HIP stream.  There is NO CPU / eager fallback: if the
+library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshowo_hip.so")
+_lib = None
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_i64 = C.c_int64
+c_u64 = C.c_uint64
+c_u32 = C.c_uint32
+c_f = C.c_float
+
+# name -> argtypes (all return int unless noted).  Mirrors include/showo_hip.h one to one.
+_PROTOS = {
+    "showo_abi_version": [],
+    "showo_device_info": [C.POINTER(c_i), C.POINTER(c_i), C.c_char_p, c_i],
+    "showo_lfq_pack_nchw": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_lfq_pack_nhwc": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "showo_lfq_unpack_nchw": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_lfq_unpack_nhwc": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_layernorm_f32_bf16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "showo_gemm_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_cast_f32_bf16": [c_p, c_p, c_i64, c_p],
+    "showo_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
+    "showo_mask_compress": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_cfg_softmax_sample": [c_p, c_p, c_i, c_f, c_p, c_i64, c_p, c_u64, c_u32, c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_mask_by_topk": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_f, c_f, c_p, c_u64, c_u32, c_p, c_i, c_i, c_p],
+    "showo_gn_stats": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_gn_apply": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
+    "showo_conv3x3_bf16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_conv_small_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_softmax_rows_bf16": [c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "showo_pad_cast_bf16": [c_p, c_p, c_i64, c_i, c_i, c_p],
+    "showo_nchw_to_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_nhwc_to_nchw_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_argmax_f32": [c_p, c_i, c_p, c_p],
+    "showo_engine_create": [c_p, C.POINTER(c_p)],
+    "showo_engine_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
+    "showo_engine_missing": [c_p],
+    "showo_engine_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
+    "showo_engine_forward_rows": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p],
+    "showo_engine_t2i_generate": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i, c_i, c_f, c_i, c_p, c_p, c_u64,
+                                  c_p, c_p, c_i, c_p, c_p],
+    "showo_engine_prefill": [c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "showo_engine_decode_step": [c_p, c_p, c_p, c_p, c_p],
+    "showo_vq_create": [c_p, C.POINTER(c_p)],
+    "showo_vq_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
+    "showo_vq_missing": [c_p],
+    "showo_vq_decode_code": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "showo_vq_get_code": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "showo_prof_enable": [c_i],
+    "showo_prof_reset": [],
+    "showo_prof_read": [c_i, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)],
+}
+_VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p]}
+EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + ["showo_last_error"])
+
+EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("hidden", c_i), ("layers", c_i), ("heads", c_i), ("ffn", c_i), ("vocab", c_i),
+                ("rotary_dim", c_i), ("max_pos", c_i), ("ln_eps", c_f), ("rope_theta", c_f),
+                ("max_batch", c_i), ("max_seq", c_i)]
+
+
+class VQConfig(C.Structure):
+    _fields_ = [("ch", c_i), ("z_channels", c_i),
+                ("enc_ch_mult", c_i * 8), ("enc_blocks", c_i * 8), ("enc_levels", c_i),
+                ("dec_ch_mult", c_i * 8), ("dec_blocks", c_i * 8), ("dec_levels", c_i),
+                ("max_batch", c_i), ("max_res", c_i)]
+
+
+def build(force=False):
+    """Compile libshowo_hip.so in-tree for gfx950 (hipcc cross-compiles; no GPU needed)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["bash", script])
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (fails loudly if it is absent — there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(show-o_amd has no CPU/eager fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_i
+    for name, args in _VOID.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = None
+    lib.showo_last_error.argtypes = []
+    lib.showo_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().showo_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libshowo_hip {what} failed (code {rc}): {msg}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "show-o_amd kernels take device tensors"
+    assert t.is_contiguous(), "show-o_amd kernels take contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("show-o_amd needs an AMD GPU (gfx950); there is no CPU fallback")

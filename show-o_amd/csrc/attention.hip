@@ -1,0 +1,317 @@
+// Omni-attention for gfx950: q/k LayerNorm + partial RoPE + relayout, mask -> interval compression, and a
+// fused flash-style attention forward whose mask is two visibility intervals per query row.
+//
+// Replaces (reference): models/phi.py:661-694 (view/transpose, q_layernorm/k_layernorm, partial rotary),
+// models/phi.py:715-722 (SDPA with the dense additive [B,1,L,L] mask built by
+// training/prompting_utils.py:466-511, 591-624).  Every mask those builders produce has, per query row r,
+// the form  visible(c) = lo1<=c<hi1  or  lo2<=c<hi2  (SURVEY.md §8a A5), so the 4*L*L-byte mask is read
+// once by showo_mask_compress instead of once per layer; anything else falls back to adding the dense mask.
+//
+// Attention kernel structure: one wave = 32 query rows, "swapped" QK^T (S^T = K Q^T on
+// v_mfma_f32_32x32x16_bf16) so that a lane owns one query row: the online-softmax row max / row sum are
+// 15 in-lane ops + one cross-half shuffle, and the probabilities are already in MFMA B-operand order for
+// O^T = V^T P^T.  V is consumed from a transposed image Vt[d][key] written by showo_qk_prep, so the
+// A-operand of the PV product is two contiguous 8-byte loads per lane.  K/V tiles are read straight from
+// L2 (one head's K+V is 97 KB at L=387), waves of a block are independent (no LDS, no barriers).
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include "prof.h"
+#include <cfloat>
+
+using namespace showo;
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------------
+// q/k LayerNorm(64) + partial RoPE + relayout.  grid (ceil(L/64), nH, B), block 256.
+// ------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const bf16_t* qkv;
+    const float *qw, *qb, *kw, *kb, *cosT, *sinT;
+    bf16_t *Q, *K, *Vt;
+    int B, L, nH, rot, pos0, Lcap, Lp;
+    float eps;
+};
+
+__device__ inline float ln_rope_lane(float x, float w, float b, float eps, const float* cosr, const float* sinr, int rot, int d) {
+    float mean = wave_sum(x) * (1.0f / 64.0f);
+    float c = x - mean;
+    float var = wave_sum(c * c) * (1.0f / 64.0f);
+    float y = c * (1.0f / sqrtf(var + eps)) * w + b;
+    // rotate_half over dims [0, rot): pair d with d +- rot/2 (phi.py:163-167)
+    int half = rot >> 1;
+    float partner = __shfl_xor(y, half, 64);  // valid pairing because rot/2 is a power of two (16)
+    if (d < rot) {
+        float r = (d < half) ? -partner : partner;
+        y = y * cosr[d] + r * sinr[d];
+    }
+    return y;
+}
+
+__global__ __launch_bounds__(256) void qk_prep_kernel(PrepArgs a) {
+    __shared__ bf16_t sV[64][66];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
+    const int H3 = 3 * a.nH * 64, Hq = a.nH * 64;
+    const float qw = a.qw[lane], qb = a.qb[lane], kw = a.kw[lane], kb = a.kb[lane];
+    for (int i = 0; i < 16; ++i) {
+        int l = l0 + wave * 16 + i;
+        if (l >= a.L) break;
+        const bf16_t* row = a.qkv + ((int64_t)b * a.L + l) * H3 + head * 64;
+        int pos = a.pos0 + l;
+        const float* cosr = a.cosT + (int64_t)pos * a.rot;
+        const float* sinr = a.sinT + (int64_t)pos * a.rot;
+        float q = ln_rope_lane(bf2f(row[lane]), qw, qb, a.eps, cosr, sinr, a.rot, lane);
+        float k = ln_rope_lane(bf2f(row[Hq + lane]), kw, kb, a.eps, cosr, sinr, a.rot, lane);
+        a.Q[(((int64_t)b * a.nH + head) * a.L + l) * 64 + lane] = f2bf(q * 0.125f);  // 1/sqrt(64), exact in bf16
+        a.K[(((int64_t)b * a.nH + head) * a.Lcap + pos) * 64 + lane] = f2bf(k);
+        sV[wave * 16 + i][lane] = row[2 * Hq + lane];
+    }
+    __syncthreads();
+    bf16_t* vt = a.Vt + ((int64_t)b * a.nH + head) * 64 * a.Lp;
+    if (a.pos0 == 0) {
+        // transposed tile write: thread -> (d, 16 consecutive tokens), zero beyond L so pad keys are finite
+        int d = tid >> 2, ls = (tid & 3) * 16;
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int la = ls + 2 * j, lb = la + 1;
+            uint32_t lo = (l0 + la < a.L) ? sV[la][d] : 0;
+            uint32_t hi = (l0 + lb < a.L) ? sV[lb][d] : 0;
+            w[j] = lo | (hi << 16);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(vt + (int64_t)d * a.Lp + l0 + ls);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else {
+        // append path (KV-cache decode): few tokens, scalar column writes
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            int lt = idx >> 6, d = idx & 63;
+            if (l0 + lt < a.L) vt[(int64_t)d * a.Lp + a.pos0 + l0 + lt] = sV[lt][d];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask -> intervals.  One wave per (b, row); 64 columns per ballot.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_compress_kernel(const float* __restrict__ mask, int32_t* __restrict__ iv,
+                                                            int32_t* __restrict__ flag, int rows, int Lk) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* mr = mask + (int64_t)r * Lk;
+    int runs = 0, bad = 0;
+    int lo[2] = {0, 0}, hi[2] = {0, 0};
+    bool open = false;  // a visible run is open at the chunk boundary (lane-uniform state, kept by all lanes)
+    for (int c0 = 0; c0 < Lk; c0 += 64) {
+        int c = c0 + lane;
+        float v = (c < Lk) ? mr[c] : -FLT_MAX;
+        bool vis = (c < Lk) && (v == 0.0f);
+        bool odd = (c < Lk) && !vis && !(v <= -1.0e9f);  // neither 0 nor "minus infinity"-like (NaN included)
+        unsigned long long bits = __ballot(vis);
+        if (__ballot(odd)) bad = 1;
+        int pos = 0;
+        while (pos < 64) {
+            if (!open) {
+                unsigned long long rest = bits >> pos;
+                if (rest == 0) break;
+                int s = __ffsll((long long)rest) - 1;
+                pos += s;
+                if (runs < 2) lo[runs] = c0 + pos;
+                open = true;
+            } else {
+                unsigned long long rest = (~bits) >> pos;
+                if (rest == 0) { pos = 64; break; }
+                int s = __ffsll((long long)rest) - 1;
+                pos += s;
+                if (runs < 2) hi[runs] = c0 + pos;
+                runs++;
+                open = false;
+            }
+        }
+    }
+    if (open) {
+        if (runs < 2) hi[runs] = Lk;
+        runs++;
+    }
+    if (lane == 0) {
+        if (runs > 2 || bad) atomicOr(flag, 1);
+        int4 o = make_int4(lo[0], runs > 0 ? hi[0] : 0, runs > 1 ? lo[1] : 0, runs > 1 ? hi[1] : 0);
+        *reinterpret_cast<int4*>(iv + (int64_t)r * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused attention forward
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const bf16_t *Q, *K, *Vt;
+    const int32_t* iv;
+    const int32_t* flag;
+    const float* dense;
+    bf16_t* O;
+    int B, nH, Lq, Lk, Lcap, Lp, ldo;
+};
+
+__device__ inline bf16x8 pack8(const float* p) {
+    uint4 u;
+    u.x = pack_bf2(p[0], p[1]);
+    u.y = pack_bf2(p[2], p[3]);
+    u.z = pack_bf2(p[4], p[5]);
+    u.w = pack_bf2(p[6], p[7]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qblk = blockIdx.x * 4 + wave;
+    if (qblk * 32 >= a.Lq) return;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qi = lane & 31, hh = lane >> 5;
+    const int qrow_raw = qblk * 32 + qi;
+    const int qrow = qrow_raw < a.Lq ? qrow_raw : a.Lq - 1;
+    const int64_t bh = (int64_t)b * a.nH + head;
+
+    const bf16_t* Qp = a.Q + (bh * a.Lq + qrow) * 64 + 8 * hh;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const bf16x8*>(Qp + 16 * m);
+
+    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);
+    int lo1, hi1, lo2, hi2;
+    if (dense) {
+        lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0;
+    } else if (a.iv) {
+        int4 v = *reinterpret_cast<const int4*>(a.iv + ((int64_t)b * a.Lq + qrow) * 4);
+        lo1 = v.x; hi1 = v.y; lo2 = v.z; hi2 = v.w;
+    } else {  // no mask given: causal (SDPA is_causal path, phi.py:713)
+        lo1 = 0; hi1 = qrow + 1 + (a.Lk - a.Lq); lo2 = 0; hi2 = 0;
+    }
+    hi1 = min(hi1, a.Lk);
+    hi2 = min(hi2, a.Lk);
+    int kmin = wave_min_i(min(lo1 < hi1 ? lo1 : 0x7fffffff, lo2 < hi2 ? lo2 : 0x7fffffff));
+    int kmax = wave_max_i(max(lo1 < hi1 ? hi1 : 0, lo2 < hi2 ? hi2 : 0));
+    const float* drow = dense ? a.dense + ((int64_t)b * a.Lq + qrow) * a.Lk : nullptr;
+
+    const bf16_t* Kb = a.K + bh * a.Lcap * 64 + 8 * hh;
+    const bf16_t* Vb = a.Vt + bh * 64 * a.Lp + 4 * hh;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+    for (int kt = (kmin >= 0x7fffffff ? 0 : (kmin & ~31)); kt < kmax; kt += 32) {
+        int krow = kt + qi;
+        krow = krow < a.Lk ? krow : a.Lk - 1;
+        const bf16_t* Kp = Kb + (int64_t)krow * 64;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + 16 * m);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m], s, 0, 0, 0);
+        }
+        float sv[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int key = kt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            bool vis = ((key >= lo1) & (key < hi1)) | ((key >= lo2) & (key < hi2));
+            float x = s[r];
+            if (dense) x += (key < a.Lk) ? drow[key] : 0.f;
+            sv[r] = vis ? x : -INFINITY;
+            mx = fmaxf(mx, sv[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float m_new = fmaxf(m_run, mx);
+        float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * LOG2E);
+        float p[16];
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = __builtin_amdgcn_exp2f((sv[r] - m_use) * LOG2E);
+            ps += p[r];
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
+        // O^T[d][q] += Vt[d][keys] * P^T[keys][q]; lane's 8 k-slots of product kk are keys
+        // kt + 16kk + 4hh + {0..3} and kt + 16kk + 8 + 4hh + {0..3}  (same keys as p[8kk .. 8kk+7])
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16_t* v0 = Vb + (int64_t)qi * a.Lp + kt + 16 * kk;
+            const bf16_t* v1 = Vb + (int64_t)(32 + qi) * a.Lp + kt + 16 * kk;
+            uint2 a0 = *reinterpret_cast<const uint2*>(v0), a1 = *reinterpret_cast<const uint2*>(v0 + 8);
+            uint2 b0 = *reinterpret_cast<const uint2*>(v1), b1 = *reinterpret_cast<const uint2*>(v1 + 8);
+            bf16x8 vf0 = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+            bf16x8 vf1 = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pb1 : pb0, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pb1 : pb0, o1, 0, 0, 0);
+        }
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float inv = 1.0f / l_tot;
+    if (qrow_raw < a.Lq) {
+        bf16_t* op = a.O + ((int64_t)b * a.Lq + qrow_raw) * a.ldo + head * 64 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w0, w1;
+            w0.x = pack_bf2(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = pack_bf2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = pack_bf2(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = pack_bf2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 8 * g) = w0;        // d = 8g + 4hh + {0..3}
+            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;   // d = 32 + 8g + 4hh + {0..3}
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
+                             const float* kln_b, const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K,
+                             uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
+                             void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if (rot != 32 && rot != 16 && rot != 64 && rot != 8) return set_error_msg(1, "qk_prep: rotary dim must be a power of two <= 64");
+    if ((Lp % 64) || Lp < pos0 + L || Lcap < pos0 + L) return set_error_msg(1, "qk_prep: bad Lp/Lcap");
+    PrepArgs a;
+    a.qkv = qkv; a.qw = qln_w; a.qb = qln_b; a.kw = kln_w; a.kb = kln_b; a.cosT = cos_tab; a.sinT = sin_tab;
+    a.Q = Q; a.K = K; a.Vt = Vt; a.B = B; a.L = L; a.nH = nH; a.rot = rot; a.pos0 = pos0; a.Lcap = Lcap; a.Lp = Lp;
+    a.eps = eps;
+    qk_prep_kernel<<<dim3((L + 63) / 64, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag, int B, int Lq, int Lk, void* stream) {
+    int rows = B * Lq;
+    if (rows <= 0) return 0;
+    SHOWO_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), (hipStream_t)stream));
+    mask_compress_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(mask, iv, flag, rows, Lk);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv,
+                              const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
+                              int Lcap, int Lp, int ldo, void* stream) {
+    if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+    if ((Lp % 64) || Lp < Lk || Lcap < Lk || (ldo % 4)) return set_error_msg(1, "attn: bad Lp/Lcap/ldo");
+    AttnArgs a;
+    a.Q = Q; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = flag; a.dense = dense_mask; a.O = O;
+    a.B = B; a.nH = nH; a.Lq = Lq; a.Lk = Lk; a.Lcap = Lcap; a.Lp = Lp; a.ldo = ldo;
+    int qblocks = (Lq + 31) / 32;
+    ProfScope prof(PROF_ATTN, 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // dense QK^T + PV flops
+    attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,271 @@
+// HBM-bound elementwise / reduction kernels of the Show-o hot path (gfx950).
+//   LFQ sign-pack / unpack        (reference models/modeling_magvitv2.py:201-221, 239-241)
+//   LayerNorm fp32 -> bf16        (reference models/phi.py:744, 776, 1065)
+//   embedding gather, casts, row softmax, NCHW<->NHWC
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include <cfloat>
+
+using namespace showo;
+
+// ------------------------------------------------------------------------------------------------
+// LFQ: 13 sign tests per token -> one int64 id.  52 B read + 8 B written per token (algorithmic bytes).
+// NCHW: one thread per token, channel loop strided by hw: lanes of a wave read consecutive tokens of the
+// same channel -> fully coalesced 256 B segments.
+// ------------------------------------------------------------------------------------------------
+__global__ void lfq_pack_nchw_kernel(const float* __restrict__ z, int64_t* __restrict__ ids, int C, int hw, int64_t total) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t b = t / hw;
+    int p = (int)(t - b * hw);
+    const float* zp = z + b * (int64_t)C * hw + p;
+    int64_t id = 0;
+    for (int c = 0; c < C; ++c) id = (id << 1) | (zp[(int64_t)c * hw] > 0.0f ? 1 : 0);
+    ids[t] = id;
+}
+
+__global__ void lfq_pack_nhwc_kernel(const float* __restrict__ z, int64_t* __restrict__ ids, int C, int ldz, int64_t total) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const float* zp = z + t * ldz;
+    int64_t id = 0;
+    for (int c = 0; c < C; ++c) id = (id << 1) | (zp[c] > 0.0f ? 1 : 0);
+    ids[t] = id;
+}
+
+__global__ void lfq_unpack_nchw_kernel(const int64_t* __restrict__ ids, float* __restrict__ zq, int C, int hw, int64_t total) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t b = t / hw;
+    int p = (int)(t - b * hw);
+    int64_t id = ids[t];
+    float* zp = zq + b * (int64_t)C * hw + p;
+    for (int c = 0; c < C; ++c) zp[(int64_t)c * hw] = ((id >> (C - 1 - c)) & 1) ? 1.0f : -1.0f;
+}
+
+extern "C" int showo_lfq_pack_nchw(const float* z, int64_t* ids, int B, int C, int hw, void* stream) {
+    int64_t total = (int64_t)B * hw;
+    if (total == 0) return 0;
+    if (C < 1 || C > 62) return set_error_msg(1, "lfq: C must be in [1,62]");
+    lfq_pack_nchw_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(z, ids, C, hw, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int showo_lfq_pack_nhwc(const float* z, int64_t* ids, int B, int C, int hw, int ldz, void* stream) {
+    int64_t total = (int64_t)B * hw;
+    if (total == 0) return 0;
+    if (C < 1 || C > 62 || ldz < C) return set_error_msg(1, "lfq: bad C/ldz");
+    lfq_pack_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(z, ids, C, ldz, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int showo_lfq_unpack_nchw(const int64_t* ids, float* zq, int B, int C, int hw, void* stream) {
+    int64_t total = (int64_t)B * hw;
+    if (total == 0) return 0;
+    if (C < 1 || C > 62) return set_error_msg(1, "lfq: C must be in [1,62]");
+    lfq_unpack_nchw_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ids, zq, C, hw, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, float4 loads, two-pass (mean, then centred variance) in fp32.
+// Row (8 KB at H=2048) stays in L1/L2 between passes; output bf16x4 stores.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, bf16_t* __restrict__ y,
+                                                        const int32_t* __restrict__ row_index, int rows, int H, float eps) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    int64_t src = row_index ? (int64_t)row_index[r] : (int64_t)r;
+    const float* xr = x + src * H;
+    bf16_t* yr = y + (int64_t)r * H;
+    const bool vec = (H & 3) == 0;
+    float s = 0.f;
+    if (vec) {
+        for (int i = lane * 4; i < H; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(xr + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = lane; i < H; i += 64) s += xr[i];
+    }
+    float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    if (vec) {
+        for (int i = lane * 4; i < H; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(xr + i);
+            float a = v.x - mean, c = v.y - mean, d = v.z - mean, e = v.w - mean;
+            q += (a * a + c * c) + (d * d + e * e);
+        }
+    } else {
+        for (int i = lane; i < H; i += 64) { float a = xr[i] - mean; q += a * a; }
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    if (vec) {
+        for (int i = lane * 4; i < H; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(xr + i);
+            float4 g = *reinterpret_cast<const float4*>(w + i);
+            float4 bb = *reinterpret_cast<const float4*>(b + i);
+            uint2 o;
+            o.x = pack_bf2((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y);
+            o.y = pack_bf2((v.z - mean) * rstd * g.z + bb.z, (v.w - mean) * rstd * g.w + bb.w);
+            *reinterpret_cast<uint2*>(yr + i) = o;
+        }
+    } else {
+        for (int i = lane; i < H; i += 64) yr[i] = f2bf((xr[i] - mean) * rstd * w[i] + b[i]);
+    }
+}
+
+extern "C" int showo_layernorm_f32_bf16(const float* x, const float* w, const float* b, uint16_t* y,
+                                        const int32_t* row_index, int rows, int H, float eps, void* stream) {
+    if (rows <= 0) return 0;
+    layernorm_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, w, b, y, row_index, rows, H, eps);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 v = *reinterpret_cast<const float4*>(s + i);
+        uint2 o;
+        o.x = pack_bf2(v.x, v.y);
+        o.y = pack_bf2(v.z, v.w);
+        *reinterpret_cast<uint2*>(d + i) = o;
+    }
+    // tail (n % 4) handled by the first threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int64_t j = (n & ~(int64_t)3) + threadIdx.x;
+        d[j] = f2bf(s[j]);
+    }
+}
+extern "C" int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 7)) return set_error_msg(1, "cast: src must be 16B and dst 8B aligned");
+    int64_t groups = (n + 3) / 4;
+    int blocks = (int)((groups + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    cast_f32_bf16_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, dst, n);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// embedding gather: one wave per token row, float4 copies.  Out-of-range ids poison the row with NaN so a
+// bad id can never pass silently (the reference would raise an index error).
+__global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, float* __restrict__ x,
+                             int T, int H, int V) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int t = blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    int64_t id = ids[t];
+    float* xr = x + (int64_t)t * H;
+    if (id < 0 || id >= V) {
+        for (int i = lane; i < H; i += 64) xr[i] = __builtin_nanf("");
+        return;
+    }
+    const float* src = table + id * H;
+    if ((H & 3) == 0) {
+        for (int i = lane * 4; i < H; i += 256) *reinterpret_cast<float4*>(xr + i) = *reinterpret_cast<const float4*>(src + i);
+    } else {
+        for (int i = lane; i < H; i += 64) xr[i] = src[i];
+    }
+}
+extern "C" int showo_embed_f32(const int64_t* ids, const float* table, float* x, int T, int H, int V, void* stream) {
+    if (T <= 0) return 0;
+    embed_kernel<<<dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(ids, table, x, T, H, V);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// row softmax (VQGAN AttnBlock): one wave per row; n <= a few thousand.
+__global__ void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int rows, int n, int ldy, float scale) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* xr = x + (int64_t)r * n;
+    float m = -FLT_MAX;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, xr[i] * scale);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += __expf(xr[i] * scale - m);
+    s = wave_sum(s);
+    float inv = 1.0f / s;
+    for (int i = lane; i < n; i += 64) y[(int64_t)r * ldy + i] = f2bf(__expf(xr[i] * scale - m) * inv);
+    for (int i = n + lane; i < ldy; i += 64) y[(int64_t)r * ldy + i] = 0;
+}
+extern "C" int showo_softmax_rows_bf16(const float* x, uint16_t* y, int rows, int n, int ldy, float scale, void* stream) {
+    if (rows <= 0) return 0;
+    softmax_rows_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, y, rows, n, ldy, scale);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// NCHW <-> NHWC fp32 (only at the image / latent boundary; C is 3 or 13 there, so a simple kernel suffices)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into NHWC output
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t bp = i / C;
+    int64_t b = bp / HW;
+    int p = (int)(bp - b * HW);
+    y[i] = x[(b * C + c) * (int64_t)HW + p];
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into NCHW output
+    if (i >= total) return;
+    int p = (int)(i % HW);
+    int64_t bc = i / HW;
+    int64_t b = bc / C;
+    int c = (int)(bc - b * C);
+    y[i] = x[(b * HW + p) * (int64_t)C + c];
+}
+extern "C" int showo_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int HW, void* stream) {
+    int64_t total = (int64_t)B * C * HW;
+    if (total == 0) return 0;
+    nchw_to_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, C, HW, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int showo_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int HW, void* stream) {
+    int64_t total = (int64_t)B * C * HW;
+    if (total == 0) return 0;
+    nhwc_to_nchw_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, C, HW, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// argmax (first maximal index) of a single fp32 vector — top_k=1 decode (modeling_showo.py:220-228)
+__global__ void argmax_kernel(const float* __restrict__ x, int n, int64_t* __restrict__ out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = x[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        out[0] = bi;
+    }
+}
+extern "C" int showo_argmax_f32(const float* x, int n, int64_t* out, void* stream) {
+    if (n <= 0) return set_error_msg(1, "argmax: n must be > 0");
+    argmax_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(x, n, out);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

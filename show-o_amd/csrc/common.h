@@ -1,0 +1,94 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) Show-o hot path.
+// Wave = 64 lanes everywhere in this tree; nothing here is portable to 32-wide hardware by design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace showo {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ inline float bf2f(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+
+// round-to-nearest-even, NaN preserved as quiet NaN
+__host__ __device__ inline bf16_t f2bf(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ inline uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Philox4x32-10 counter RNG (Salmon et al. 2011) — the on-device noise source of the sampler.
+struct Philox {
+    uint32_t k0, k1;
+    __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ inline void round(uint32_t (&c)[4], uint32_t ka, uint32_t kb) const {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ ka, n1 = lo1, n2 = hi0 ^ c[3] ^ kb, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __device__ inline void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
+        uint32_t c[4] = {c0, c1, c2, c3};
+        uint32_t ka = k0, kb = k1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            round(c, ka, kb);
+            ka += 0x9E3779B9u;
+            kb += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+// uniform in (0,1): never 0 or 1
+__device__ inline float u32_to_unit(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+}  // namespace showo
+
+#define SHOWO_CHECK_HIP(expr)                                  \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) return showo::set_error_hip(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+namespace showo {
+int set_error_hip(hipError_t e, const char* what, const char* file, int line);
+int set_error_msg(int code, const char* msg);
+}

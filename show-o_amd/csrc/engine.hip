@@ -1,0 +1,398 @@
+// Show-o transformer engine: packed bf16 weights + workspaces resident in HBM, whole-module entry points.
+// Replaces (reference): PhiForCausalLM/PhiModel forward (models/phi.py:953-1183), Showo.forward without
+// labels (models/modeling_showo.py:76-79), Showo.t2i_generate (models/modeling_showo.py:104-181) and the
+// incremental form of Showo.mmu_generate (models/modeling_showo.py:183-240; the reference re-runs the whole
+// sequence per token, here K/V of earlier rows are cached, which is exact because the mask it grows never
+// lets an old row see a new column, modeling_showo.py:203-217).
+//
+// Data layout in HBM (T = B*L tokens, H hidden, F ffn):
+//   x      fp32 [T,H]    residual stream (kept fp32; both GEMM epilogues accumulate into it in place)
+//   h      bf16 [T,H]    LayerNorm output (shared by the attention and MLP branches, phi.py:776-790)
+//   qkv    bf16 [T,3H]   fused q|k|v projection
+//   Q,K    bf16 [B,nH,L,64]; Vt bf16 [B,nH,64,Lp]    head-major operands of the attention kernel
+//   attn   bf16 [T,H]; ffn bf16 [T,F]
+//   weights: Wqkv [3H,H], Wd [H,H], W1 [F,H], W2 [H,F], Wlm [V,H] bf16 row-major (= nn.Linear layout,
+//   K-contiguous, exactly what the MFMA GEMM's operand loader wants); biases / LayerNorm params fp32.
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace showo;
+
+namespace {
+
+struct Layer {
+    bf16_t *wqkv = nullptr, *wd = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bd = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln_w = nullptr, *ln_b = nullptr, *qln_w = nullptr, *qln_b = nullptr, *kln_w = nullptr, *kln_b = nullptr;
+};
+
+__global__ void init_cur_kernel(const int64_t* ids, int ld, int img_start, int64_t mask_id, int64_t offset, int64_t* cur, int N,
+                                int total) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int b = i / N, n = i - b * N;
+    int64_t v = ids[(int64_t)b * ld + img_start + n];
+    cur[i] = (v == mask_id) ? mask_id : v - offset;
+}
+// uncond rows = uncond prefix (first `prefix` tokens) + cond tokens from `prefix` on (modeling_showo.py:137-138)
+__global__ void build_ids_kernel(const int64_t* cond, const int64_t* uncond, int64_t* all, int B, int L, int prefix) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    int b = i / L, l = i - b * L;
+    int64_t c = cond[i];
+    all[i] = c;
+    if (uncond) all[(int64_t)(B + b) * L + l] = (l < prefix) ? uncond[i] : c;
+}
+__global__ void rows_index_kernel(int32_t* rows, int nseq, int L, int img_start, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseq * N) return;
+    int b = i / N, n = i - b * N;
+    rows[i] = b * L + img_start + n;
+}
+__global__ void set_iv_kernel(int32_t* iv, int a, int b, int c, int d) {
+    if (threadIdx.x == 0) { iv[0] = a; iv[1] = b; iv[2] = c; iv[3] = d; }
+}
+__global__ void copy_i64_kernel(const int64_t* s, int64_t* d, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = s[i];
+}
+
+}  // namespace
+
+struct showo_engine {
+    showo_engine_config cfg;
+    int H, nL, nH, F, V;
+    int64_t maxT;
+    std::vector<void*> allocs;
+    std::set<std::string> loaded;
+    int expected = 0;
+    // weights
+    float* embed = nullptr;
+    std::vector<Layer> layers;
+    float *fln_w = nullptr, *fln_b = nullptr, *blm = nullptr, *cosT = nullptr, *sinT = nullptr;
+    bf16_t* wlm = nullptr;
+    // workspace
+    float* x = nullptr;
+    bf16_t *h = nullptr, *qkv = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *attn = nullptr, *ffn = nullptr, *hf = nullptr;
+    int32_t *iv = nullptr, *flag = nullptr, *rows = nullptr;
+    // t2i state
+    int64_t *ids_all = nullptr, *cur = nullptr, *sampled = nullptr;
+    float *sel = nullptr, *row_logits = nullptr;
+    int64_t row_logits_cap = 0;
+    // decode (KV cache) state: per-layer caches, capacity cap tokens
+    bf16_t *kcache = nullptr, *vtcache = nullptr;
+    int cache_cap = 0, cache_len = 0, prompt_len = 0;
+    int last_iv[4] = {0, 0, 0, 0};
+    int32_t* iv1 = nullptr;
+    int64_t* tok1 = nullptr;
+
+    template <class T>
+    int alloc(T** p, int64_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T));
+        if (e != hipSuccess) return set_error_hip(e, "hipMalloc", __FILE__, __LINE__);
+        allocs.push_back(q);
+        *p = (T*)q;
+        return 0;
+    }
+};
+
+#define TRY(expr)            \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** out) {
+    if (!c || !out) return set_error_msg(1, "engine_create: null argument");
+    if (c->hidden % 64 || c->hidden != c->heads * 64) return set_error_msg(1, "engine: head_dim must be 64");
+    if (c->ffn % 64) return set_error_msg(1, "engine: ffn must be a multiple of 64");
+    showo_engine* e = new showo_engine();
+    e->cfg = *c;
+    e->H = c->hidden; e->nL = c->layers; e->nH = c->heads; e->F = c->ffn; e->V = c->vocab;
+    e->maxT = (int64_t)c->max_batch * c->max_seq;
+    const int H = e->H, F = e->F, V = e->V;
+    int rc = 0;
+    rc |= e->alloc(&e->embed, (int64_t)V * H);
+    e->layers.resize(e->nL);
+    for (auto& l : e->layers) {
+        rc |= e->alloc(&l.wqkv, (int64_t)3 * H * H); rc |= e->alloc(&l.bqkv, 3 * H);
+        rc |= e->alloc(&l.wd, (int64_t)H * H); rc |= e->alloc(&l.bd, H);
+        rc |= e->alloc(&l.w1, (int64_t)F * H); rc |= e->alloc(&l.b1, F);
+        rc |= e->alloc(&l.w2, (int64_t)H * F); rc |= e->alloc(&l.b2, H);
+        rc |= e->alloc(&l.ln_w, H); rc |= e->alloc(&l.ln_b, H);
+        rc |= e->alloc(&l.qln_w, 64); rc |= e->alloc(&l.qln_b, 64);
+        rc |= e->alloc(&l.kln_w, 64); rc |= e->alloc(&l.kln_b, 64);
+    }
+    rc |= e->alloc(&e->fln_w, H); rc |= e->alloc(&e->fln_b, H);
+    rc |= e->alloc(&e->wlm, (int64_t)V * H); rc |= e->alloc(&e->blm, V);
+    rc |= e->alloc(&e->cosT, (int64_t)c->max_pos * c->rotary_dim);
+    rc |= e->alloc(&e->sinT, (int64_t)c->max_pos * c->rotary_dim);
+    const int64_t T = e->maxT;
+    const int Lp = ((c->max_seq + 63) / 64) * 64;
+    rc |= e->alloc(&e->x, T * H); rc |= e->alloc(&e->h, T * H); rc |= e->alloc(&e->qkv, T * 3 * H);
+    rc |= e->alloc(&e->Q, T * H); rc |= e->alloc(&e->K, T * H);
+    rc |= e->alloc(&e->Vt, (int64_t)c->max_batch * H * Lp);
+    rc |= e->alloc(&e->attn, T * H); rc |= e->alloc(&e->ffn, T * F); rc |= e->alloc(&e->hf, T * H);
+    rc |= e->alloc(&e->iv, T * 4); rc |= e->alloc(&e->flag, 4); rc |= e->alloc(&e->rows, T);
+    rc |= e->alloc(&e->ids_all, T); rc |= e->alloc(&e->cur, T); rc |= e->alloc(&e->sampled, T); rc |= e->alloc(&e->sel, T);
+    rc |= e->alloc(&e->iv1, 4); rc |= e->alloc(&e->tok1, 1);
+    if (rc) { showo_engine_destroy(e); return rc; }
+    hipMemset(e->Vt, 0, (size_t)c->max_batch * H * Lp * sizeof(bf16_t));
+    hipMemset(e->flag, 0, 16);
+    e->expected = 1 + e->nL * 18 + 2 + 2 + 2;
+    *out = e;
+    return 0;
+}
+
+extern "C" void showo_engine_destroy(showo_engine* e) {
+    if (!e) return;
+    for (void* p : e->allocs) hipFree(p);
+    delete e;
+}
+
+extern "C" int showo_engine_missing(const showo_engine* e) { return e ? e->expected - (int)e->loaded.size() : -1; }
+
+static int copy_f32(float* dst, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+    if (n != expect) return set_error_msg(2, "engine_load: element count mismatch");
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return set_error_hip(e, "hipMemcpyAsync", __FILE__, __LINE__);
+    return 0;
+}
+static int cast_w(bf16_t* dst, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+    if (n != expect) return set_error_msg(2, "engine_load: element count mismatch");
+    return showo_cast_f32_bf16(src, dst, n, s);
+}
+
+extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* src, int64_t n, void* stream) {
+    if (!e || !key || !src) return set_error_msg(1, "engine_load: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t H = e->H, F = e->F, V = e->V;
+    std::string k(key);
+    int rc = -1;
+    int li = -1;
+    char sub[128];
+    if (k == "showo.model.embed_tokens.weight") rc = copy_f32(e->embed, src, n, V * H, s);
+    else if (k == "showo.model.final_layernorm.weight") rc = copy_f32(e->fln_w, src, n, H, s);
+    else if (k == "showo.model.final_layernorm.bias") rc = copy_f32(e->fln_b, src, n, H, s);
+    else if (k == "showo.lm_head.weight") rc = cast_w(e->wlm, src, n, V * H, s);
+    else if (k == "showo.lm_head.bias") rc = copy_f32(e->blm, src, n, V, s);
+    else if (k == "rope.cos") rc = copy_f32(e->cosT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
+    else if (k == "rope.sin") rc = copy_f32(e->sinT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
+    else if (sscanf(key, "showo.model.layers.%d.%127s", &li, sub) == 2 && li >= 0 && li < e->nL) {
+        Layer& l = e->layers[li];
+        std::string t(sub);
+        if (t == "self_attn.q_proj.weight") rc = cast_w(l.wqkv, src, n, H * H, s);
+        else if (t == "self_attn.k_proj.weight") rc = cast_w(l.wqkv + H * H, src, n, H * H, s);
+        else if (t == "self_attn.v_proj.weight") rc = cast_w(l.wqkv + 2 * H * H, src, n, H * H, s);
+        else if (t == "self_attn.q_proj.bias") rc = copy_f32(l.bqkv, src, n, H, s);
+        else if (t == "self_attn.k_proj.bias") rc = copy_f32(l.bqkv + H, src, n, H, s);
+        else if (t == "self_attn.v_proj.bias") rc = copy_f32(l.bqkv + 2 * H, src, n, H, s);
+        else if (t == "self_attn.dense.weight") rc = cast_w(l.wd, src, n, H * H, s);
+        else if (t == "self_attn.dense.bias") rc = copy_f32(l.bd, src, n, H, s);
+        else if (t == "self_attn.q_layernorm.weight") rc = copy_f32(l.qln_w, src, n, 64, s);
+        else if (t == "self_attn.q_layernorm.bias") rc = copy_f32(l.qln_b, src, n, 64, s);
+        else if (t == "self_attn.k_layernorm.weight") rc = copy_f32(l.kln_w, src, n, 64, s);
+        else if (t == "self_attn.k_layernorm.bias") rc = copy_f32(l.kln_b, src, n, 64, s);
+        else if (t == "mlp.fc1.weight") rc = cast_w(l.w1, src, n, F * H, s);
+        else if (t == "mlp.fc1.bias") rc = copy_f32(l.b1, src, n, F, s);
+        else if (t == "mlp.fc2.weight") rc = cast_w(l.w2, src, n, H * F, s);
+        else if (t == "mlp.fc2.bias") rc = copy_f32(l.b2, src, n, H, s);
+        else if (t == "input_layernorm.weight") rc = copy_f32(l.ln_w, src, n, H, s);
+        else if (t == "input_layernorm.bias") rc = copy_f32(l.ln_b, src, n, H, s);
+    }
+    if (rc == -1) return set_error_msg(3, "engine_load: unknown state-dict key");
+    if (rc == 0) e->loaded.insert(k);
+    return rc;
+}
+
+// ---- the 24-layer stack.  K/V destination is either the per-call workspace or a layer slice of the cache.
+static int run_layers(showo_engine* e, int B, int L, int pos0, bool use_cache, const int32_t* iv, const int32_t* flag,
+                      const float* dense, hipStream_t s) {
+    const int H = e->H, F = e->F, nH = e->nH;
+    const int T = B * L;
+    const int Lk = pos0 + L;
+    const int Lcap = use_cache ? e->cache_cap : L;
+    const int Lp = use_cache ? e->cache_cap : ((L + 63) / 64) * 64;
+    for (int li = 0; li < e->nL; ++li) {
+        Layer& l = e->layers[li];
+        bf16_t* Kd = use_cache ? e->kcache + (int64_t)li * nH * e->cache_cap * 64 : e->K;
+        bf16_t* Vd = use_cache ? e->vtcache + (int64_t)li * nH * 64 * e->cache_cap : e->Vt;
+        TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
+        TRY(showo_gemm_bf16(e->h, H, l.wqkv, H, l.bqkv, 0, e->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
+        TRY(showo_qk_prep(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd, B, L, nH,
+                          e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+        TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
+        TRY(showo_gemm_bf16(e->attn, H, l.wd, H, l.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+        TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, s));
+        TRY(showo_gemm_bf16(e->ffn, F, l.w2, F, l.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+    }
+    return 0;
+}
+
+static int check_ready(showo_engine* e, int B, int L) {
+    if (!e) return set_error_msg(1, "engine: null handle");
+    if (showo_engine_missing(e) != 0) return set_error_msg(4, "engine: weights missing (showo_engine_missing() != 0)");
+    if ((int64_t)B * L > e->maxT || B > e->cfg.max_batch || L > e->cfg.max_seq || L > e->cfg.max_pos)
+        return set_error_msg(5, "engine: batch/sequence exceeds the configured workspace");
+    return 0;
+}
+
+static int embed_in(showo_engine* e, const int64_t* ids, const float* embeds, int T, hipStream_t s) {
+    if ((ids == nullptr) == (embeds == nullptr)) return set_error_msg(1, "engine: exactly one of ids / embeds must be given");
+    if (ids) return showo_embed_f32(ids, e->embed, e->x, T, e->H, e->V, s);
+    SHOWO_CHECK_HIP(hipMemcpyAsync(e->x, embeds, (size_t)T * e->H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+static int hidden(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B, int L, hipStream_t s) {
+    TRY(check_ready(e, B, L));
+    TRY(embed_in(e, ids, embeds, B * L, s));
+    const int32_t *iv = nullptr, *flag = nullptr;
+    if (mask) {
+        TRY(showo_mask_compress(mask, e->iv, e->flag, B, L, L, s));
+        iv = e->iv; flag = e->flag;
+    }
+    return run_layers(e, B, L, 0, false, iv, flag, mask, s);
+}
+
+static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
+    if (col0 < 0 || ncols <= 0 || col0 + ncols > e->V) return set_error_msg(1, "engine: bad vocabulary slice");
+    TRY(showo_layernorm_f32_bf16(e->x, e->fln_w, e->fln_b, e->hf, rows, nrows, e->H, e->cfg.ln_eps, s));
+    return showo_gemm_bf16(e->hf, e->H, e->wlm + (int64_t)col0 * e->H, e->H, e->blm + col0, 0, logits, ncols, nullptr, 0,
+                           nrows, ncols, e->H, SHOWO_EPI_F32, s);
+}
+
+extern "C" int showo_engine_forward(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B, int L,
+                                    float* logits, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TRY(hidden(e, ids, embeds, mask, B, L, s));
+    return head_rows(e, nullptr, B * L, 0, e->V, logits, s);
+}
+
+extern "C" int showo_engine_forward_rows(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B,
+                                         int L, const int32_t* rows, int nrows, int col0, int ncols, float* logits,
+                                         void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (nrows > e->maxT) return set_error_msg(5, "engine: too many rows");
+    TRY(hidden(e, ids, embeds, mask, B, L, s));
+    return head_rows(e, rows, nrows, col0, ncols, logits, s);
+}
+
+extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int64_t* ids_uncond, const float* mask, int B,
+                                         int L, int N, int text_len, int64_t mask_id, int id_offset, int codebook,
+                                         float guidance, int steps, const float* mask_len_host, const float* temps_host,
+                                         uint64_t seed, const float* exp_noise, const float* uniform, int use_graph,
+                                         int64_t* sampled_out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const bool cfg = (ids_uncond != nullptr) && guidance > 0.f;  // modeling_showo.py:136
+    const int nseq = cfg ? 2 * B : B;
+    TRY(check_ready(e, nseq, L));
+    if (N + 2 > L || steps < 1 || !mask_len_host || !temps_host) return set_error_msg(1, "t2i: bad arguments");
+    if (id_offset + codebook > e->V) return set_error_msg(1, "t2i: codebook slice exceeds the vocabulary");
+    const int img_start = L - (N + 1);  // input_ids[:, -(N+1):-1]
+    const int nrows = nseq * N;
+    if ((int64_t)nrows * codebook > e->row_logits_cap) {
+        e->row_logits_cap = (int64_t)nrows * codebook;
+        TRY(e->alloc(&e->row_logits, e->row_logits_cap));
+    }
+    const int thr = 256;
+    build_ids_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(ids_cond, cfg ? ids_uncond : nullptr, e->ids_all, B, L,
+                                                                       text_len + 1);
+    init_cur_kernel<<<dim3((B * N + thr - 1) / thr), dim3(thr), 0, s>>>(ids_cond, L, img_start, mask_id, id_offset, e->cur, N, B * N);
+    rows_index_kernel<<<dim3((nrows + thr - 1) / thr), dim3(thr), 0, s>>>(e->rows, nseq, L, img_start, N);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    const int32_t *iv = nullptr, *flag = nullptr;
+    if (mask) {
+        TRY(showo_mask_compress(mask, e->iv, e->flag, nseq, L, L, s));  // the mask is step-invariant: compress once
+        iv = e->iv; flag = e->flag;
+    }
+    (void)use_graph;  // graph capture of the step lands with the device-side step constants
+    for (int step = 0; step < steps; ++step) {
+        TRY(showo_embed_f32(e->ids_all, e->embed, e->x, nseq * L, e->H, e->V, s));
+        TRY(run_layers(e, nseq, L, 0, false, iv, flag, mask, s));
+        TRY(head_rows(e, e->rows, nrows, id_offset, codebook, e->row_logits, s));
+        const float* lu = cfg ? e->row_logits + (int64_t)B * N * codebook : nullptr;
+        TRY(showo_cfg_softmax_sample(e->row_logits, lu, codebook, guidance, e->cur, mask_id,
+                                     exp_noise ? exp_noise + (int64_t)step * B * N * codebook : nullptr, seed, (uint32_t)step,
+                                     e->sampled, e->sel, B, N, codebook, s));
+        TRY(showo_mask_by_topk(e->sel, e->sampled, e->cur, e->ids_all, cfg ? e->ids_all + (int64_t)B * L : nullptr, L, img_start,
+                               mask_id, id_offset, mask_len_host[step], temps_host[step],
+                               uniform ? uniform + (int64_t)step * B * N : nullptr, seed, (uint32_t)step, nullptr, B, N, s));
+    }
+    copy_i64_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(e->ids_all, ids_cond, B * L);  // in-place update like the reference
+    copy_i64_kernel<<<dim3((B * N + thr - 1) / thr), dim3(thr), 0, s>>>(e->sampled, sampled_out, B * N);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- KV-cached decode ---------------------------------------------------------------------------------
+static int ensure_cache(showo_engine* e, int need) {
+    if (need <= e->cache_cap) return 0;
+    int cap = ((need + 63) / 64) * 64;
+    if (cap > e->cfg.max_pos) cap = ((e->cfg.max_pos + 63) / 64) * 64;
+    if (need > cap) return set_error_msg(5, "decode: sequence exceeds max_position_embeddings");
+    if (e->cache_cap != 0) return set_error_msg(5, "decode: cache capacity exceeded");
+    // allocate once at the maximum the position table allows (2048 tokens: 2 x 201 MB at full size)
+    cap = ((e->cfg.max_pos + 63) / 64) * 64;
+    int64_t n = (int64_t)e->nL * e->nH * cap * 64;
+    TRY(e->alloc(&e->kcache, n));
+    TRY(e->alloc(&e->vtcache, n));
+    hipMemset(e->kcache, 0, (size_t)n * sizeof(bf16_t));
+    hipMemset(e->vtcache, 0, (size_t)n * sizeof(bf16_t));
+    e->cache_cap = cap;
+    return 0;
+}
+
+extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L,
+                                    float* logits_last, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TRY(check_ready(e, 1, L));
+    TRY(ensure_cache(e, L + 1));
+    TRY(embed_in(e, ids, embeds, L, s));
+    const int32_t *iv = nullptr, *flag = nullptr;
+    if (mask) {
+        TRY(showo_mask_compress(mask, e->iv, e->flag, 1, L, L, s));
+        iv = e->iv; flag = e->flag;
+    }
+    TRY(run_layers(e, 1, L, 0, true, iv, flag, mask, s));
+    e->prompt_len = L;
+    e->cache_len = L;
+    if (mask) {
+        int32_t f = 0;
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv, e->iv + (int64_t)(L - 1) * 4, 16, hipMemcpyDeviceToHost, s));
+        SHOWO_CHECK_HIP(hipMemcpyAsync(&f, e->flag, 4, hipMemcpyDeviceToHost, s));
+        SHOWO_CHECK_HIP(hipStreamSynchronize(s));
+        if (f) return set_error_msg(6, "decode: prompt mask is not interval-representable; KV-cached decode unsupported");
+    } else {
+        e->last_iv[0] = 0; e->last_iv[1] = L; e->last_iv[2] = 0; e->last_iv[3] = 0;
+    }
+    set_iv_kernel<<<1, 64, 0, s>>>(e->rows, L - 1, 0, 0, 0);  // rows[0] = L-1
+    return head_rows(e, e->rows, 1, 0, e->V, logits_last, s);
+}
+
+extern "C" int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* embed, float* logits_last, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!e || e->cache_len <= 0) return set_error_msg(1, "decode_step: prefill first");
+    const int P = e->cache_len;  // position of the new token
+    if (P + 1 > e->cache_cap || P + 1 > e->cfg.max_pos) return set_error_msg(5, "decode_step: cache full");
+    TRY(embed_in(e, id, embed, 1, s));
+    // mask row of the new token = last prompt row + [prompt_len, P] (modeling_showo.py:203-217)
+    int a = e->last_iv[0], b = e->last_iv[1], c = e->last_iv[2], d = e->last_iv[3];
+    const int L0 = e->prompt_len;
+    if (b == L0 && a < b) b = P + 1;
+    else if (d == L0 && c < d) d = P + 1;
+    else if (!(c < d)) { c = L0; d = P + 1; }
+    else if (!(a < b)) { a = L0; b = P + 1; }
+    else return set_error_msg(6, "decode_step: mask row needs more than two intervals");
+    set_iv_kernel<<<1, 64, 0, s>>>(e->iv1, a, b, c, d);
+    hipMemsetAsync(e->flag, 0, 4, s);
+    TRY(run_layers(e, 1, 1, P, true, e->iv1, e->flag, nullptr, s));
+    e->cache_len = P + 1;
+    return head_rows(e, nullptr, 1, 0, e->V, logits_last, s);
+}

@@ -1,0 +1,82 @@
+// error reporting for the C ABI
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include <cstdio>
+#include <cstring>
+
+namespace showo {
+static thread_local char g_err[512] = "";
+int set_error_hip(hipError_t e, const char* what, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return 1000 + (int)e;
+}
+int set_error_msg(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+}  // namespace showo
+
+extern "C" const char* showo_last_error(void) { return showo::g_err; }
+extern "C" int showo_abi_version(void) { return SHOWO_ABI_VERSION; }
+extern "C" int showo_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return showo::set_error_hip(e, "hipGetDevice", __FILE__, __LINE__);
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return showo::set_error_hip(e, "hipGetDeviceProperties", __FILE__, __LINE__);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, p.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 0;
+}
+
+// ---- per-launch event timing -------------------------------------------------------------------------
+#include "prof.h"
+#include <vector>
+namespace showo {
+struct ProfRec { int kind; double work; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+ProfScope::ProfScope(int kind, double work, hipStream_t stream) : idx(-1), s(stream) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.kind = kind; r.work = work;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    idx = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s);
+}
+}  // namespace showo
+
+extern "C" int showo_prof_enable(int on) {
+    showo::g_prof_on = on != 0;
+    return 0;
+}
+extern "C" int showo_prof_reset(void) {
+    for (auto& r : showo::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    showo::g_prof.clear();
+    return 0;
+}
+// kind: 0 gemm, 1 attention, 2 conv.  Returns summed elapsed ms, launch count and summed work (flops).
+extern "C" int showo_prof_read(int kind, double* total_ms, int64_t* launches, double* work) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return showo::set_error_hip(e, "hipDeviceSynchronize", __FILE__, __LINE__);
+    double ms = 0, w = 0;
+    int64_t n = 0;
+    for (auto& r : showo::g_prof) {
+        if (r.kind != kind) continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; w += r.work; n++; }
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (work) *work = w;
+    return 0;
+}

@@ -1,0 +1,326 @@
+// bf16 MFMA GEMM for gfx950: C[M,N] = A[M,K] * W[N,K]^T with fused epilogues, and the same core used
+// as an implicit-GEMM 3x3 convolution (NHWC, K = 9*Cin).
+//
+// Replaces (reference; paths relative to the reference root): q/k/v/dense projections models/phi.py:657-659,727;
+// PhiMLP fc1+gelu_new+fc2 models/phi.py:208-212; lm_head models/phi.py:1182-1183; VQGAN Conv2d 3x3 / 1x1
+// models/common_modules.py:27-90,168-211,298-357.
+//
+// Structure (v1, "2-barrier LDS-staged" tier of the CDNA4 playbook):
+//   block = 256 threads = 4 waves (2x2), block tile 128(n) x 128(m) x 64(k), wave tile 64x64 as 4x4
+//   v_mfma_f32_16x16x32_bf16 fragments.  The MFMA A-operand is the WEIGHT tile and the B-operand the
+//   ACTIVATION tile, so each lane ends up with 4 consecutive output columns (n) of one output row (m):
+//   epilogue loads/stores are 8-16 B vectors and bias is a float4.
+//   Both operands are K-contiguous; they are staged global -> VGPR -> LDS (double-buffered, register
+//   prefetch of the next k-tile under the MFMAs) into a [128][64] bf16 image whose 16-B chunks are
+//   XOR-swizzled with (row & 7) so the ds_read_b128 fragment reads are at most 2-way conflicted.
+//   Block ids are remapped so that the blocks resident on one XCD (id % 8) walk the same weight panel.
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include "prof.h"
+
+using namespace showo;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_TILE = 128 * 64;  // bf16 elements per operand tile
+
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    const float* bias; int bias_per_row;
+    void* out; int ldo;
+    const float* resid; int ldr;
+    int M, N, K;
+    int vec_out;  // 1: out/resid rows allow 4-wide vector access
+};
+
+struct ConvArgs {
+    const bf16_t* X;   // NHWC bf16 input
+    int B, Hin, Win, Cin, Hout, Wout, mode;
+};
+
+// ---- activation-operand loaders: setup(i, m) once per staged row, load(i, k) per k-tile -> 16-B chunk
+struct LinearLoader {
+    const bf16_t* A; int lda; int M;
+    const bf16_t* rowp[4];
+    __device__ inline void setup(int i, int m) {
+        int mm = m < M ? m : M - 1;
+        rowp[i] = A + (int64_t)mm * lda;
+    }
+    __device__ inline void tile(int) {}
+    __device__ inline uint4 load(int i, int k) const { return *reinterpret_cast<const uint4*>(rowp[i] + k); }
+};
+
+struct ConvLoader {
+    ConvArgs c; int M;
+    int oy[4], ox[4];
+    const bf16_t* img[4];
+    int ky, kx, cbase;  // per k-tile (block-uniform)
+    __device__ inline void setup(int i, int m) {
+        int mm = m < M ? m : M - 1;
+        int hw = c.Hout * c.Wout;
+        int b = mm / hw;
+        int p = mm - b * hw;
+        oy[i] = p / c.Wout;
+        ox[i] = p - oy[i] * c.Wout;
+        img[i] = c.X + (int64_t)b * c.Hin * c.Win * c.Cin;
+    }
+    // k0 = first k of the 64-wide tile; Cin % 64 == 0 guarantees the tile never straddles a tap
+    __device__ inline void tile(int k0) {
+        int tap = k0 / c.Cin;
+        cbase = k0 - tap * c.Cin;
+        ky = tap / 3;
+        kx = tap - ky * 3;
+    }
+    __device__ inline uint4 load(int i, int k) const {
+        int iy, ix;
+        bool ok;
+        if (c.mode == 2) {  // pad (0,1,0,1) then stride 2 (common_modules.py:83-88)
+            iy = 2 * oy[i] + ky; ix = 2 * ox[i] + kx;
+            ok = iy < c.Hin && ix < c.Win;
+        } else if (c.mode == 1) {  // nearest 2x upsample, then pad 1 (common_modules.py:36-40)
+            int uy = oy[i] + ky - 1, ux = ox[i] + kx - 1;
+            ok = uy >= 0 && ux >= 0 && uy < c.Hout && ux < c.Wout;
+            iy = uy >> 1; ix = ux >> 1;
+        } else {
+            iy = oy[i] + ky - 1; ix = ox[i] + kx - 1;
+            ok = iy >= 0 && ix >= 0 && iy < c.Hin && ix < c.Win;
+        }
+        if (!ok) return make_uint4(0, 0, 0, 0);
+        // k & 63 = this thread's chunk offset inside the tile
+        return *reinterpret_cast<const uint4*>(img[i] + ((int64_t)iy * c.Win + ix) * c.Cin + cbase + (k & 63));
+    }
+};
+
+__device__ inline float gelu_new_fast(float x) {
+    // gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+
+template <int EPI, class Loader>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
+    Loader ld = ld_in;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);          // [2][128*64]
+    bf16_t* sA = sW + 2 * LDS_TILE;                              // [2][128*64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    // XCD-aware bijective remap: blocks with equal (id % 8) share an L2; give each XCD a contiguous id range
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = bid / tilesM, tm = bid - tn * tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // staging assignment: thread -> chunk c (16 B) of rows r0 + 32*i
+    const int sc = tid & 7, sr0 = tid >> 3;
+    uint4 ra[4], rw[4];
+    const int nk = g.K / BK;
+
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = sr0 + 32 * i;
+        int n = n0 + row;
+        n = n < g.N ? n : g.N - 1;
+        wrow[i] = g.W + (int64_t)n * g.ldw;
+        ld.setup(i, m0 + row);
+    }
+    auto gload = [&](int kt) {
+        int k = kt * BK + sc * 8;
+        ld.tile(kt * BK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rw[i] = *reinterpret_cast<const uint4*>(wrow[i] + k);
+            ra[i] = ld.load(i, k);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = sr0 + 32 * i;
+            int off = row * 64 + ((sc ^ (row & 7)) << 3);
+            *reinterpret_cast<uint4*>(sW + buf * LDS_TILE + off) = rw[i];
+            *reinterpret_cast<uint4*>(sA + buf * LDS_TILE + off) = ra[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wn = wave >> 1, wm = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const bf16_t* bW = sW + cur * LDS_TILE;
+        const bf16_t* bA = sA + cur * LDS_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], af[4];
+            const int chunk = kk * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = wn * 64 + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const bf16x8*>(bW + row * 64 + ((chunk ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = wm * 64 + j * 16 + fr;
+                af[j] = *reinterpret_cast<const bf16x8*>(bA + row * 64 + ((chunk ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m][n .. n+3] for each (i,j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fg * 4;
+        float bn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && !g.bias_per_row) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bn[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + fr;
+            if (m >= g.M || n >= g.N) continue;
+            float v[4];
+            const float bm = (g.bias && g.bias_per_row) ? g.bias[m] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bn[r] + bm;
+            const bool full = (n + 3 < g.N) && g.vec_out;
+            if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
+                if (EPI == SHOWO_EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_new_fast(v[r]);
+                }
+                bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
+                if (full) {
+                    uint2 pk;
+                    pk.x = pack_bf2(v[0], v[1]);
+                    pk.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(o) = pk;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) o[r] = f2bf(v[r]);
+                }
+            } else {
+                float* o = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n;
+                if (EPI == SHOWO_EPI_RESID_F32) {
+                    const float* rs = g.resid + (int64_t)m * g.ldr + n;
+                    if (full) {
+                        float4 rv = *reinterpret_cast<const float4*>(rs);
+                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) v[r] += rs[r];
+                    }
+                }
+                if (full) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) o[r] = v[r];
+                }
+            }
+        }
+    }
+}
+
+constexpr int SMEM_BYTES = 4 * LDS_TILE * 2;  // 64 KiB
+
+template <int EPI, class Loader>
+int launch(const GemmArgs& g, const Loader& ld, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = gemm_kernel<EPI, Loader>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm)", __FILE__, __LINE__);
+        attr_set = true;
+    }
+    int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    kfn<<<dim3(tilesM * tilesN), dim3(256), SMEM_BYTES, s>>>(g, ld);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "gemm launch", __FILE__, __LINE__);
+    return 0;
+}
+
+template <class Loader>
+int dispatch(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case SHOWO_EPI_BF16: return launch<SHOWO_EPI_BF16>(g, ld, s);
+        case SHOWO_EPI_GELU_BF16: return launch<SHOWO_EPI_GELU_BF16>(g, ld, s);
+        case SHOWO_EPI_F32: return launch<SHOWO_EPI_F32>(g, ld, s);
+        case SHOWO_EPI_RESID_F32: return launch<SHOWO_EPI_RESID_F32>(g, ld, s);
+    }
+    return set_error_msg(1, "gemm: unknown epilogue");
+}
+
+}  // namespace
+
+extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
+                               void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue,
+                               void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K % BK) != 0) return set_error_msg(1, "gemm: K must be a positive multiple of 64");
+    if ((lda % 8) || (ldw % 8) || (((uintptr_t)A) & 15) || (((uintptr_t)W) & 15))
+        return set_error_msg(1, "gemm: A/W must be 16B aligned with lda,ldw multiples of 8");
+    if (epilogue == SHOWO_EPI_RESID_F32 && !resid) return set_error_msg(1, "gemm: resid required");
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.bias_per_row = bias_per_row;
+    g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+    bool f32 = (epilogue == SHOWO_EPI_F32 || epilogue == SHOWO_EPI_RESID_F32);
+    uintptr_t align = f32 ? 15 : 7;
+    g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & align) == 0);
+    if (epilogue == SHOWO_EPI_RESID_F32) g.vec_out = g.vec_out && ((ldr % 4) == 0) && ((((uintptr_t)resid) & 15) == 0);
+    LinearLoader ld;
+    ld.A = A; ld.lda = lda; ld.M = M;
+    ProfScope prof(PROF_GEMM, 2.0 * M * N * K, (hipStream_t)stream);
+    return dispatch(g, ld, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, const float* resid, float* out,
+                                  int B, int Hin, int Win, int Cin, int Cout, int mode, void* stream) {
+    if (B <= 0) return 0;
+    if (Cin % 64) return set_error_msg(1, "conv3x3: Cin % 64 == 0 required (pad thin inputs to 64 channels)");
+    if (mode < 0 || mode > 2) return set_error_msg(1, "conv3x3: bad mode");
+    ConvArgs c;
+    c.X = x; c.B = B; c.Hin = Hin; c.Win = Win; c.Cin = Cin; c.mode = mode;
+    if (mode == 1) { c.Hout = Hin * 2; c.Wout = Win * 2; }
+    else if (mode == 2) { c.Hout = Hin / 2; c.Wout = Win / 2; }
+    else { c.Hout = Hin; c.Wout = Win; }
+    GemmArgs g;
+    g.A = nullptr; g.lda = 0; g.W = w; g.ldw = 9 * Cin; g.bias = bias; g.bias_per_row = 0;
+    g.out = out; g.ldo = Cout; g.resid = resid; g.ldr = Cout;
+    g.M = B * c.Hout * c.Wout; g.N = Cout; g.K = 9 * Cin;
+    g.vec_out = ((Cout % 4) == 0) && ((((uintptr_t)out) & 15) == 0) && (!resid || (((uintptr_t)resid) & 15) == 0);
+    ConvLoader ld;
+    ld.c = c; ld.M = g.M;
+    // algorithmic flops of the convolution: real (unpadded) taps x channels
+    ProfScope prof(PROF_CONV, 2.0 * g.M * Cout * 9.0 * Cin, (hipStream_t)stream);
+    return dispatch(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
+}

@@ -1,0 +1,213 @@
+// Mask-predict (MaskGIT) sampler kernels for gfx950.
+// Replaces (reference): models/modeling_showo.py:140-179 (CFG combine, slice, softmax, multinomial,
+// confidence gather, mask_len clamp, write-back) and models/sampling.py:10-16,31-36 (log, gumbel_noise,
+// mask_by_random_topk).  Arithmetic order follows the reference expression by expression (explicit
+// __fmul_rn/__fadd_rn so hipcc cannot contract them into FMAs); only the libm-level functions
+// (exp/log) can differ in the last ulp from the CPU.
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include <cfloat>
+
+using namespace showo;
+
+namespace {
+
+struct SampleArgs {
+    const float *lc, *lu;
+    int ld;
+    float a1, a2;  // (1+w), w as fp32 scalars (python float -> fp32 tensor op)
+    const int64_t* cur;
+    int64_t mask_id;
+    const float* exp_noise;
+    uint64_t seed;
+    uint32_t step;
+    int64_t* sampled;
+    float* sel;
+    int N, V;
+};
+
+// one block per image token row; z staged in LDS (V*4 bytes, 32 KB at V=8192)
+__global__ __launch_bounds__(256) void cfg_softmax_sample_kernel(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sz[];
+    __shared__ float red_f[4];
+    __shared__ int red_i[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c = a.cur[row];
+    if (c != a.mask_id) {  // known token: keeps its id, confidence = finfo.max (modeling_showo.py:154,164)
+        if (tid == 0) { a.sampled[row] = c; a.sel[row] = FLT_MAX; }
+        return;
+    }
+    const float* lc = a.lc + (int64_t)row * a.ld;
+    const float* lu = a.lu ? a.lu + (int64_t)row * a.ld : nullptr;
+    float mx = -INFINITY;
+    for (int i = tid; i < a.V; i += 256) {
+        float z = lu ? __fsub_rn(__fmul_rn(a.a1, lc[i]), __fmul_rn(a.a2, lu[i])) : lc[i];
+        sz[i] = z;
+        mx = fmaxf(mx, z);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < a.V; i += 256) {
+        float e = expf(sz[i] - mx);
+        sz[i] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red_f[wave] = s;
+    __syncthreads();
+    s = (red_f[0] + red_f[1]) + (red_f[2] + red_f[3]);
+    __syncthreads();
+    // argmax_i p_i / E_i  (what torch.multinomial(p, 1) computes: q.exponential_(1); argmax(p / q))
+    Philox ph(a.seed);
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int i0 = tid * 4; i0 < a.V; i0 += 1024) {
+        float e4[4];
+        if (a.exp_noise) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e4[j] = (i0 + j < a.V) ? a.exp_noise[(int64_t)row * a.V + i0 + j] : 1.f;
+        } else {
+            uint32_t r4[4];
+            ph.gen((uint32_t)(i0 >> 2), (uint32_t)row, a.step, 0x51u, r4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e4[j] = -logf(u32_to_unit(r4[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = i0 + j;
+            if (i < a.V) {
+                float p = __fdiv_rn(sz[i], s);
+                float sc = __fdiv_rn(p, e4[j]);
+                if (sc > best || (sc == best && i < bi)) { best = sc; bi = i; }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { red_f[wave] = best; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (red_f[w] > best || (red_f[w] == best && red_i[w] < bi)) { best = red_f[w]; bi = red_i[w]; }
+        a.sampled[row] = bi;
+        a.sel[row] = __fdiv_rn(sz[bi], s);
+    }
+}
+
+struct TopkArgs {
+    const float* sel;
+    const int64_t* sampled;
+    int64_t *cur, *ids_c, *ids_u;
+    int ld_ids, img_start;
+    int64_t mask_id, id_offset;
+    float mask_len_f, temp;
+    const float* uniform;
+    uint64_t seed;
+    uint32_t step;
+    uint8_t* masking_out;
+    int N;
+};
+
+// one block per sample; confidences in LDS; k-th smallest by rank counting (N <= 4096)
+__global__ __launch_bounds__(256) void mask_by_topk_kernel(TopkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float conf[];
+    __shared__ int cnt_unknown;
+    __shared__ float cut_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { cnt_unknown = 0; cut_s = INFINITY; }
+    __syncthreads();
+    Philox ph(a.seed);
+    int local_unknown = 0;
+    for (int i = tid; i < a.N; i += 256) {
+        int64_t idx = (int64_t)b * a.N + i;
+        if (a.cur[idx] == a.mask_id) local_unknown++;
+        float u;
+        if (a.uniform) {
+            u = a.uniform[idx];
+        } else {
+            uint32_t r4[4];
+            ph.gen((uint32_t)i, (uint32_t)b, a.step, 0x6bu, r4);
+            u = u32_to_unit(r4[0]);
+        }
+        // gumbel_noise: -log(-log(u)) with log(t) = log(clamp(t, 1e-20)) (sampling.py:10-16)
+        float g = -logf(fmaxf(-logf(fmaxf(u, 1e-20f)), 1e-20f));
+        conf[i] = __fadd_rn(logf(fmaxf(a.sel[idx], 1e-20f)), __fmul_rn(a.temp, g));
+    }
+    if (local_unknown) atomicAdd(&cnt_unknown, local_unknown);
+    __syncthreads();
+    // mask_len = max(1, min(unknown - 1, floor(N * ratio)))  (modeling_showo.py:166-171), as floats then .long()
+    float ml = fmaxf(1.0f, fminf((float)(cnt_unknown - 1), a.mask_len_f));
+    int k = (int)ml;
+    if (k > a.N - 1) k = a.N - 1;
+    for (int i = tid; i < a.N; i += 256) {
+        float x = conf[i];
+        int less = 0, leq = 0;
+        for (int j = 0; j < a.N; ++j) {
+            float y = conf[j];
+            less += (y < x);
+            leq += (y <= x);
+        }
+        if (less <= k && k < leq) cut_s = x;  // same value from every writer
+    }
+    __syncthreads();
+    const float cut = cut_s;
+    for (int i = tid; i < a.N; i += 256) {
+        int64_t idx = (int64_t)b * a.N + i;
+        bool m = conf[i] < cut;
+        int64_t sid = a.sampled[idx];
+        int64_t tok = m ? a.mask_id : sid + a.id_offset;
+        a.ids_c[(int64_t)b * a.ld_ids + a.img_start + i] = tok;
+        if (a.ids_u) a.ids_u[(int64_t)b * a.ld_ids + a.img_start + i] = tok;
+        a.cur[idx] = m ? a.mask_id : sid;
+        if (a.masking_out) a.masking_out[idx] = m ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int showo_cfg_softmax_sample(const float* logits_c, const float* logits_u, int ld, float guidance,
+                                        const int64_t* cur, int64_t mask_id, const float* exp_noise, uint64_t seed,
+                                        uint32_t step, int64_t* sampled, float* sel_prob, int B, int N, int V,
+                                        void* stream) {
+    int rows = B * N;
+    if (rows <= 0) return 0;
+    if (V <= 0 || V > 40000) return set_error_msg(1, "sampler: V out of range (LDS staging supports V <= 40000)");
+    SampleArgs a;
+    a.lc = logits_c; a.lu = logits_u; a.ld = ld;
+    a.a1 = (float)(1.0 + (double)guidance); a.a2 = guidance;
+    a.cur = cur; a.mask_id = mask_id; a.exp_noise = exp_noise; a.seed = seed; a.step = step;
+    a.sampled = sampled; a.sel = sel_prob; a.N = N; a.V = V;
+    size_t smem = (size_t)V * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cfg_softmax_sample_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160000));
+        attr_set = true;
+    }
+    cfg_softmax_sample_kernel<<<dim3(rows), dim3(256), smem, (hipStream_t)stream>>>(a);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_mask_by_topk(const float* sel_prob, const int64_t* sampled, int64_t* cur, int64_t* ids_cond,
+                                  int64_t* ids_uncond, int ld_ids, int img_start, int64_t mask_id, int64_t id_offset,
+                                  float mask_len_f, float temperature, const float* uniform, uint64_t seed,
+                                  uint32_t step, uint8_t* masking_out, int B, int N, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (N > 4096) return set_error_msg(1, "mask_by_topk: N <= 4096 supported");
+    TopkArgs a;
+    a.sel = sel_prob; a.sampled = sampled; a.cur = cur; a.ids_c = ids_cond; a.ids_u = ids_uncond;
+    a.ld_ids = ld_ids; a.img_start = img_start; a.mask_id = mask_id; a.id_offset = id_offset;
+    a.mask_len_f = mask_len_f; a.temp = temperature; a.uniform = uniform; a.seed = seed; a.step = step;
+    a.masking_out = masking_out; a.N = N;
+    mask_by_topk_kernel<<<dim3(B), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream>>>(a);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

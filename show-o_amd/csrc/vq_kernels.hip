@@ -1,0 +1,173 @@
+// HBM-bound VQGAN kernels for gfx950 (channel-last activations):
+//   GroupNorm(32, eps=1e-6) statistics + normalise(+swish) -> bf16   (reference models/common_modules.py:16-24)
+//   thin 1x1/3x3 fp32 convolution for the 13-channel latent convs     (reference models/modeling_magvitv2.py:131-139, 360-362)
+//   channel pad + cast fp32 -> bf16 (feeds the MFMA implicit-GEMM conv in gemm.hip)
+#include "common.h"
+#include "../../include/showo_hip.h"
+
+using namespace showo;
+
+namespace {
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_PIX_PER_BLOCK = 512;
+
+// stats[b][g] = (sum, sumsq) in double.  Thread t owns channel quad f = t % (C/4) for all of its pixels,
+// so its partial sums belong to exactly one group (C % 128 == 0  =>  channels-per-group % 4 == 0).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C) {
+    __shared__ float ssum[GN_GROUPS], ssq[GN_GROUPS];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid < GN_GROUPS) { ssum[tid] = 0.f; ssq[tid] = 0.f; }
+    __syncthreads();
+    const int quads = C >> 2, ppp = 256 / quads;  // pixels per pass
+    const int f = tid % quads, pl = tid / quads;
+    const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
+    const int pend = min(p0 + GN_PIX_PER_BLOCK, HW);
+    const float* xb = x + (int64_t)b * HW * C;
+    float s = 0.f, q = 0.f;
+    for (int p = p0 + pl; p < pend; p += ppp) {
+        float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C + f * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const int g = (f * 4) / (C / GN_GROUPS);
+    atomicAdd(&ssum[g], s);
+    atomicAdd(&ssq[g], q);
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+        atomicAdd(&stats[((int64_t)b * GN_GROUPS + tid) * 2 + 0], (double)ssum[tid]);
+        atomicAdd(&stats[((int64_t)b * GN_GROUPS + tid) * 2 + 1], (double)ssq[tid]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, int HW, int C, float eps, int do_swish) {
+    __shared__ float smean[GN_GROUPS], srstd[GN_GROUPS];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid < GN_GROUPS) {
+        double n = (double)HW * (C / GN_GROUPS);
+        double mean = stats[((int64_t)b * GN_GROUPS + tid) * 2] / n;
+        double var = stats[((int64_t)b * GN_GROUPS + tid) * 2 + 1] / n - mean * mean;
+        if (var < 0) var = 0;
+        smean[tid] = (float)mean;
+        srstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int quads = C >> 2, ppp = 256 / quads;
+    const int f = tid % quads, pl = tid / quads;
+    const int g = (f * 4) / (C / GN_GROUPS);
+    const float mean = smean[g], rstd = srstd[g];
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + f * 4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + f * 4);
+    const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
+    const int pend = min(p0 + GN_PIX_PER_BLOCK, HW);
+    const float* xb = x + (int64_t)b * HW * C;
+    bf16_t* yb = y + (int64_t)b * HW * C;
+    for (int p = p0 + pl; p < pend; p += ppp) {
+        float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C + f * 4);
+        float o[4] = {(v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y,
+                      (v.z - mean) * rstd * ga.z + be.z, (v.w - mean) * rstd * ga.w + be.w};
+        if (do_swish) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = o[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[j]));
+        }
+        uint2 pk;
+        pk.x = pack_bf2(o[0], o[1]);
+        pk.y = pack_bf2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(yb + (int64_t)p * C + f * 4) = pk;
+    }
+}
+
+// thin direct conv (fp32): one thread per output element; used only for the 13->13 1x1 latent convs
+__global__ void conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ out, int H, int W, int Cin, int Cout, int ks, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int co = (int)(i % Cout);
+    int64_t p = i / Cout;
+    int ox = (int)(p % W);
+    int64_t t = p / W;
+    int oy = (int)(t % H);
+    int64_t b = t / H;
+    int pad = (ks - 1) / 2;
+    float acc = bias ? bias[co] : 0.f;
+    for (int ky = 0; ky < ks; ++ky) {
+        int iy = oy + ky - pad;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < ks; ++kx) {
+            int ix = ox + kx - pad;
+            if (ix < 0 || ix >= W) continue;
+            const float* xp = x + ((b * H + iy) * W + ix) * (int64_t)Cin;
+            const float* wp = w + ((int64_t)(co * ks + ky) * ks + kx) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) acc += xp[ci] * wp[ci];
+        }
+    }
+    out[i] = acc;
+}
+
+// fp32 [P, C] -> bf16 [P, Cpad] (zero padded channels)
+__global__ void pad_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int C, int Cpad, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int c = (int)(i % Cpad);
+    int64_t p = i / Cpad;
+    y[i] = (c < C) ? f2bf(x[p * C + c]) : (bf16_t)0;
+}
+
+__global__ void lfq_unpack_nhwc_kernel(const int64_t* __restrict__ ids, float* __restrict__ zq, int C, int64_t total) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t id = ids[t];
+    float* zp = zq + t * C;
+    for (int c = 0; c < C; ++c) zp[c] = ((id >> (C - 1 - c)) & 1) ? 1.0f : -1.0f;
+}
+
+}  // namespace
+
+extern "C" int showo_gn_stats(const float* x, double* stats, int B, int HW, int C, void* stream) {
+    if (B <= 0 || HW <= 0) return 0;
+    if ((C % 128) || C > 1024) return set_error_msg(1, "gn_stats: C must be a multiple of 128 and <= 1024");
+    SHOWO_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_GROUPS * B, (hipStream_t)stream));
+    gn_stats_kernel<<<dim3((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK, B), dim3(256), 0, (hipStream_t)stream>>>(x, stats, HW, C);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, uint16_t* y,
+                              int B, int HW, int C, float eps, int do_swish, void* stream) {
+    if (B <= 0 || HW <= 0) return 0;
+    if ((C % 128) || C > 1024) return set_error_msg(1, "gn_apply: C must be a multiple of 128 and <= 1024");
+    gn_apply_kernel<<<dim3((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK, B), dim3(256), 0, (hipStream_t)stream>>>(
+        x, stats, gamma, beta, y, HW, C, eps, do_swish);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_conv_small_f32(const float* x, const float* w, const float* bias, float* out, int B, int H, int W,
+                                    int Cin, int Cout, int ksize, void* stream) {
+    int64_t total = (int64_t)B * H * W * Cout;
+    if (total <= 0) return 0;
+    if (ksize != 1 && ksize != 3) return set_error_msg(1, "conv_small: ksize must be 1 or 3");
+    conv_small_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, w, bias, out, H, W, Cin,
+                                                                                                  Cout, ksize, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_pad_cast_bf16(const float* x, uint16_t* y, int64_t P, int C, int Cpad, void* stream) {
+    int64_t total = P * Cpad;
+    if (total <= 0) return 0;
+    pad_cast_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, C, Cpad, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_lfq_unpack_nhwc(const int64_t* ids, float* zq, int B, int C, int hw, void* stream) {
+    int64_t total = (int64_t)B * hw;
+    if (total <= 0) return 0;
+    if (C < 1 || C > 62) return set_error_msg(1, "lfq: C must be in [1,62]");
+    lfq_unpack_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ids, zq, C, total);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,331 @@
+"""`Showo` — drop-in replacement of the reference class `models.modeling_showo.Showo`
+(reference models/modeling_showo.py:23-240) backed by the gfx950 engine in libshowo_hip.so.
+
+Same constructor arguments, attributes (`config.mask_token_id`, `mask_token_id`, `vocab_size`,
+`output_size`, `showo.model.embed_tokens`, `showo.resize_token_embeddings`, `mm_projector`) and state-dict
+keys as the reference, so `inference_t2i.py` / `inference_mmu.py` call it unchanged.
+The torch modules below are *parameter containers only* (they give `state_dict()` / `load_state_dict()`
+the reference's names and shapes); all arithmetic runs in HIP kernels through the C ABI.  There is no
+PyTorch fallback: without a GPU or without the built library every compute entry point raises.
+"""
+import types
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .sampling import cosine_schedule, t2i_step_constants
+
+# microsoft/phi-1_5 architecture numbers (what AutoConfig.from_pretrained(llm_model_path) yields in the
+# reference, models/modeling_showo.py:42; PhiConfig defaults)
+PHI_1_5 = dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=24, num_attention_heads=32,
+               max_position_embeddings=2048, layer_norm_eps=1e-5, rope_theta=10000.0, partial_rotary_factor=0.5)
+
+
+class _Cfg(dict):
+    """attribute-style config like the reference's diffusers FrozenDict (`model.config.mask_token_id`)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def get(self, k, default=None):
+        return dict.get(self, k, default)
+
+
+class _PhiAttentionParams(nn.Module):
+    def __init__(self, hidden, head_dim, eps):
+        super().__init__()
+        self.q_proj = nn.Linear(hidden, hidden, bias=True)
+        self.k_proj = nn.Linear(hidden, hidden, bias=True)
+        self.v_proj = nn.Linear(hidden, hidden, bias=True)
+        self.dense = nn.Linear(hidden, hidden, bias=True)
+        self.q_layernorm = nn.LayerNorm(head_dim, eps=eps)  # forced on by PhiForCausalLM (reference models/phi.py:1088)
+        self.k_layernorm = nn.LayerNorm(head_dim, eps=eps)
+
+
+class _PhiMLPParams(nn.Module):
+    def __init__(self, hidden, ffn):
+        super().__init__()
+        self.fc1 = nn.Linear(hidden, ffn)
+        self.fc2 = nn.Linear(ffn, hidden)
+
+
+class _PhiLayerParams(nn.Module):
+    def __init__(self, hidden, ffn, head_dim, eps):
+        super().__init__()
+        self.self_attn = _PhiAttentionParams(hidden, head_dim, eps)
+        self.mlp = _PhiMLPParams(hidden, ffn)
+        self.input_layernorm = nn.LayerNorm(hidden, eps=eps)
+
+
+class _PhiModelParams(nn.Module):
+    def __init__(self, vocab, hidden, ffn, layers, head_dim, eps):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(vocab, hidden)
+        self.layers = nn.ModuleList([_PhiLayerParams(hidden, ffn, head_dim, eps) for _ in range(layers)])
+        self.final_layernorm = nn.LayerNorm(hidden, eps=eps)
+
+
+class _PhiForCausalLMParams(nn.Module):
+    """Names mirror reference models/phi.py:1084-1095 (`model`, untied biased `lm_head`)."""
+
+    def __init__(self, vocab, hidden, ffn, layers, head_dim, eps):
+        super().__init__()
+        self.model = _PhiModelParams(vocab, hidden, ffn, layers, head_dim, eps)
+        self.lm_head = nn.Linear(hidden, vocab, bias=True)
+        self.vocab_size = vocab
+        for m in self.modules():  # Phi init: N(0, 0.02), zero biases (reference models/phi.py:833-842)
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, std=0.02)
+
+    def resize_token_embeddings(self, new_vocab):
+        """reference: PreTrainedModel.resize_token_embeddings called at models/modeling_showo.py:46."""
+        old = self.model.embed_tokens.weight.shape[0]
+        if new_vocab == old:
+            return self.model.embed_tokens
+        hidden = self.model.embed_tokens.weight.shape[1]
+        dev = self.model.embed_tokens.weight.device
+        emb = nn.Embedding(new_vocab, hidden, device=dev)
+        head = nn.Linear(hidden, new_vocab, bias=True, device=dev)
+        nn.init.normal_(emb.weight, std=0.02)
+        nn.init.normal_(head.weight, std=0.02)
+        nn.init.zeros_(head.bias)
+        n = min(old, new_vocab)
+        with torch.no_grad():
+            emb.weight[:n] = self.model.embed_tokens.weight[:n]
+            head.weight[:n] = self.lm_head.weight[:n]
+            head.bias[:n] = self.lm_head.bias[:n]
+        self.model.embed_tokens, self.lm_head, self.vocab_size = emb, head, new_vocab
+        return emb
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+
+class Showo(nn.Module):
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, w_clip_vit, vocab_size, llm_vocab_size, llm_model_path='', codebook_size=8192,
+                 num_vq_tokens=256, load_from_showo=True, **kwargs):
+        super().__init__()
+        arch = dict(PHI_1_5)
+        arch.update({k: kwargs[k] for k in PHI_1_5 if k in kwargs})
+        self.arch = arch
+        self.config = _Cfg(w_clip_vit=w_clip_vit, vocab_size=vocab_size, llm_vocab_size=llm_vocab_size,
+                           llm_model_path=llm_model_path, codebook_size=codebook_size, num_vq_tokens=num_vq_tokens,
+                           load_from_showo=load_from_showo, mask_token_id=vocab_size - 1)
+        self.vocab_size = vocab_size
+        hidden, heads = arch["hidden_size"], arch["num_attention_heads"]
+        if hidden // heads != 64:
+            raise ValueError("the gfx950 attention kernel is built for head_dim 64 (Phi-1.5)")
+        # the reference builds Phi with its native vocabulary and then resizes (modeling_showo.py:43-46); the
+        # end state (embed + untied lm_head of `vocab_size` rows) is what we allocate directly.
+        self.showo = _PhiForCausalLMParams(vocab_size, hidden, arch["intermediate_size"], arch["num_hidden_layers"],
+                                           64, arch["layer_norm_eps"])
+        self.output_size = self.vocab_size
+        if w_clip_vit:
+            self.mm_projector = nn.Sequential(nn.Linear(1024, 2048), nn.GELU(), nn.Linear(2048, 2048))
+        self._engine = None
+        self._engine_key = None
+        self._engine_versions = None
+        self.max_batch = int(kwargs.get("max_batch", 32))
+        self.max_seq = int(kwargs.get("max_seq", 1280))
+
+    # ---- reference attribute passthrough (`model.mask_token_id`, reference models/modeling_utils.py:139-155)
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            cfg = self.__dict__.get("config")
+            if cfg is not None and name in cfg:
+                return cfg[name]
+            raise
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        self.gradient_checkpointing = True
+
+    @classmethod
+    def from_state_dict(cls, state_dict, device="cuda", **ctor):
+        m = cls(**ctor)
+        m.load_state_dict(state_dict, strict=True)
+        return m.to(device)
+
+    # ---- engine management -------------------------------------------------------------------------
+    def configure_workspace(self, max_batch, max_seq):
+        """Size the engine's HBM workspaces (tokens = max_batch * max_seq).  Re-creates the engine."""
+        self.max_batch, self.max_seq = int(max_batch), int(max_seq)
+        self._drop_engine()
+
+    def _drop_engine(self):
+        if self._engine is not None:
+            _lib.load().showo_engine_destroy(self._engine)
+        self._engine, self._engine_versions = None, None
+
+    def __del__(self):
+        try:
+            self._drop_engine()
+        except Exception:
+            pass
+
+    def _engine_params(self):
+        return [(k, v) for k, v in self.showo.state_dict(prefix="showo.").items()]
+
+    def _rope_tables(self, device):
+        # exactly PhiRotaryEmbedding._set_cos_sin_cache (reference models/phi.py:86-102), fp32, on the host
+        a = self.arch
+        dim = int(a["partial_rotary_factor"] * 64)
+        inv_freq = 1.0 / (a["rope_theta"] ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+        t = torch.arange(a["max_position_embeddings"], dtype=torch.int64).type_as(inv_freq)
+        freqs = torch.outer(t, inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().contiguous().to(device), emb.sin().contiguous().to(device)
+
+    def engine(self):
+        """Create the HIP engine if needed and (re)upload weights whose version changed."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = self.showo.lm_head.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("Showo parameters must live on the GPU (model.to('cuda')); no CPU path exists")
+        a = self.arch
+        if self._engine is None:
+            import ctypes as C
+            cfg = _lib.EngineConfig(hidden=a["hidden_size"], layers=a["num_hidden_layers"], heads=a["num_attention_heads"],
+                                    ffn=a["intermediate_size"], vocab=self.vocab_size,
+                                    rotary_dim=int(a["partial_rotary_factor"] * 64), max_pos=a["max_position_embeddings"],
+                                    ln_eps=a["layer_norm_eps"], rope_theta=a["rope_theta"],
+                                    max_batch=self.max_batch, max_seq=self.max_seq)
+            h = C.c_void_p()
+            _lib.check(lib.showo_engine_create(C.byref(cfg), C.byref(h)), "showo_engine_create")
+            self._engine = h
+            self._engine_versions = {}
+            cos, sin = self._rope_tables(dev)
+            _lib.call("showo_engine_load", self._engine, b"rope.cos", _lib.ptr(cos), cos.numel(), _lib.stream())
+            _lib.call("showo_engine_load", self._engine, b"rope.sin", _lib.ptr(sin), sin.numel(), _lib.stream())
+            torch.cuda.current_stream().synchronize()
+        for k, v in self._engine_params():
+            ver = (v.data_ptr(), v._version)
+            if self._engine_versions.get(k) != ver:
+                src = v.detach()
+                if src.dtype != torch.float32 or not src.is_contiguous():
+                    src = src.float().contiguous()
+                _lib.call("showo_engine_load", self._engine, k.encode(), _lib.ptr(src), src.numel(), _lib.stream())
+                self._engine_versions[k] = ver
+                if src is not v:
+                    torch.cuda.current_stream().synchronize()  # keep the temporary alive until consumed
+        missing = lib.showo_engine_missing(self._engine)
+        if missing:
+            raise RuntimeError(f"engine is missing {missing} tensors")
+        return self._engine
+
+    # ---- Showo.forward (reference models/modeling_showo.py:59-102) -------------------------------------
+    def forward(self, input_ids, input_embeddings=None, attention_mask=None, labels=None, label_smoothing=0.0,
+                batch_size_t2i=0, batch_size_lm=0, batch_size_mmu=0, max_seq_length=128, labels_mask_text=None,
+                labels_mask_image=None, **kwargs):
+        eng = self.engine()
+        if input_embeddings is None:
+            B, L = input_ids.shape
+            ids = input_ids.to(torch.int64).contiguous()
+            emb = None
+            dev = ids.device
+        else:
+            B, L = input_embeddings.shape[:2]
+            ids = None
+            emb = input_embeddings.detach().float().contiguous()
+            dev = emb.device
+        mask = None
+        if attention_mask is not None:
+            if tuple(attention_mask.shape) != (B, 1, L, L):  # same check as the eager path, reference models/phi.py:368-372
+                raise ValueError(f"Attention mask should be of size {(B, 1, L, L)}, but is {tuple(attention_mask.shape)}")
+            mask = attention_mask.detach().float().contiguous()
+        logits = torch.empty((B, L, self.vocab_size), dtype=torch.float32, device=dev)
+        _lib.call("showo_engine_forward", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), B, L, _lib.ptr(logits),
+                  _lib.stream())
+        if labels is None:
+            return logits
+        raise NotImplementedError("training losses/backward on the HIP path land in a later round (SURVEY.md §8 rows T1/T2)")
+
+    # ---- Showo.t2i_generate (reference models/modeling_showo.py:104-181) -----------------------------------
+    def t2i_generate(self, input_ids=None, uncond_input_ids=None, attention_mask=None, temperature=1.0, timesteps=18,
+                     guidance_scale=0, noise_schedule=cosine_schedule, generator=None, config=None,
+                     _exp_noise=None, _uniform=None, **kwargs):
+        eng = self.engine()
+        N = config.model.showo.num_vq_tokens
+        offset = config.model.showo.llm_vocab_size + config.model.showo.num_new_special_tokens
+        text_len = config.dataset.preprocessing.max_seq_length
+        B, L = input_ids.shape
+        if input_ids.dtype != torch.int64 or not input_ids.is_contiguous():
+            raise ValueError("input_ids must be a contiguous int64 tensor (it is updated in place like the reference)")
+        codebook = self.vocab_size - 1 - offset  # logits[..., offset:-1] (reference :144)
+        unc = None
+        if uncond_input_ids is not None and guidance_scale > 0:
+            unc = uncond_input_ids.to(torch.int64).contiguous()
+        mask = None if attention_mask is None else attention_mask.detach().float().contiguous()
+        import ctypes as C
+        ml, tp = t2i_step_constants(timesteps, N, temperature, noise_schedule)
+        ml_a = (C.c_float * timesteps)(*ml)
+        tp_a = (C.c_float * timesteps)(*tp)
+        if generator is not None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
+        else:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        out = torch.empty((B, N), dtype=torch.int64, device=input_ids.device)
+        _lib.call("showo_engine_t2i_generate", eng, _lib.ptr(input_ids), _lib.ptr(unc), _lib.ptr(mask), B, L, N, text_len,
+                  self.config.mask_token_id, offset, codebook, float(guidance_scale), timesteps,
+                  C.cast(ml_a, C.c_void_p), C.cast(tp_a, C.c_void_p), seed, _lib.ptr(_exp_noise), _lib.ptr(_uniform),
+                  int(kwargs.get("use_graph", 0)), _lib.ptr(out), _lib.stream())
+        return out
+
+    # ---- Showo.mmu_generate (reference models/modeling_showo.py:183-240) -----------------------------------
+    @torch.no_grad()
+    def mmu_generate(self, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, temperature=1.0,
+                     top_k=None, eot_token=None):
+        eng = self.engine()
+        if top_k != 1:
+            raise NotImplementedError("mmu_generate on the HIP path implements the reference caller's setting top_k=1 "
+                                      "(inference_mmu.py:81); stochastic decode lands in a later round")
+        dev = idx.device if idx is not None else input_embeddings.device
+        if input_embeddings is not None:
+            if input_embeddings.shape[0] != 1:
+                raise ValueError("mmu_generate has batch-1 semantics (reference modeling_showo.py:204,229)")
+            L = input_embeddings.shape[1]
+            emb = input_embeddings.detach().float().contiguous()
+            ids = None
+        else:
+            if idx.shape[0] != 1:
+                raise ValueError("mmu_generate has batch-1 semantics (reference modeling_showo.py:204,229)")
+            L = idx.shape[1]
+            ids = idx.to(torch.int64).contiguous()
+            emb = None
+        mask = None if attention_mask is None else attention_mask.detach().float().reshape(1, 1, L, L).contiguous()
+        logits = torch.empty((self.vocab_size,), dtype=torch.float32, device=dev)
+        tok = torch.empty((1,), dtype=torch.int64, device=dev)
+        _lib.call("showo_engine_prefill", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), L, _lib.ptr(logits), _lib.stream())
+        result = []
+        for _ in range(max_new_tokens):
+            # logits / temperature does not change the arg-max for temperature > 0; top_k=1 makes the reference's
+            # multinomial a deterministic arg-max
+            _lib.call("showo_argmax_f32", _lib.ptr(logits), self.vocab_size, _lib.ptr(tok), _lib.stream())
+            result.append(tok[0].clone())
+            if eot_token is not None and int(tok.item()) == eot_token:
+                break
+            if len(result) == max_new_tokens:
+                break
+            # the next input is embed_tokens(token) in both reference branches (modeling_showo.py:231-235); the engine
+            # gathers that row from its own copy of the table
+            _lib.call("showo_engine_decode_step", eng, _lib.ptr(tok), None, _lib.ptr(logits), _lib.stream())
+        return result
+
+
+def gen_config(llm_vocab_size=50295, num_new_special_tokens=10, num_vq_tokens=256, max_seq_length=128):
+    """The subset of the OmegaConf config that t2i_generate reads (reference modeling_showo.py:123-133)."""
+    ns = types.SimpleNamespace
+    return ns(model=ns(showo=ns(num_vq_tokens=num_vq_tokens, num_new_special_tokens=num_new_special_tokens,
+                                llm_vocab_size=llm_vocab_size)),
+              dataset=ns(preprocessing=ns(max_seq_length=max_seq_length)))

@@ -1,0 +1,449 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes) and checked against the
+CPU oracle (oracle/showo_oracle.py) / committed golden fixtures.  Tolerances are stated per test:
+integer / index work is bit-exact; bf16 MFMA paths are compared with the fp32 oracle evaluated on the SAME
+bf16-rounded operands, so the bound is the accumulation-order + output-rounding error only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from util import O, dev, from_bf16_bits, to_bf16_bits, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    return util.lib()
+
+
+def S():
+    return util.lib().stream()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------- LFQ
+def test_lfq_pack_unpack_bit_exact():
+    g = util.golden("lfq_kat.npz")
+    z = dev(g["z"])
+    B, Cc, h, w = z.shape
+    ids = torch.empty((B, h * w), dtype=torch.int64, device="cuda")
+    L().call("showo_lfq_pack_nchw", L().ptr(z), L().ptr(ids), B, Cc, h * w, S())
+    assert np.array_equal(ids.cpu().numpy(), g["ids"])  # includes +-0, +-1e-9, denormals
+    sub = dev(g["ids"][:, :16])
+    back = torch.empty((B, 13, 4, 4), dtype=torch.float32, device="cuda")
+    L().call("showo_lfq_unpack_nchw", L().ptr(sub), L().ptr(back), B, 13, 16, S())
+    assert np.array_equal(back.cpu().numpy(), g["back"])
+    # full-size random: 8 images x 1024 tokens, NCHW and NHWC forms, vs the numpy oracle
+    rs = np.random.RandomState(0)
+    zz = rs.standard_normal((8, 13, 32, 32)).astype(np.float32)
+    zz[rs.rand(*zz.shape) < 0.01] = 0.0
+    ids = torch.empty((8, 1024), dtype=torch.int64, device="cuda")
+    zd = dev(zz)
+    L().call("showo_lfq_pack_nchw", L().ptr(zd), L().ptr(ids), 8, 13, 1024, S())
+    want = O.lfq_pack_np(zz)
+    assert np.array_equal(ids.cpu().numpy(), want)
+    znhwc = zd.permute(0, 2, 3, 1).contiguous()
+    ids2 = torch.empty_like(ids)
+    L().call("showo_lfq_pack_nhwc", L().ptr(znhwc), L().ptr(ids2), 8, 13, 1024, 13, S())
+    assert torch.equal(ids, ids2)
+    # property at full size: unpack(pack(z)) == sign pattern, pack(unpack(id)) == id over the whole codebook
+    allids = torch.arange(8192, dtype=torch.int64, device="cuda").reshape(2, 4096)
+    zq = torch.empty((2, 13, 4096), dtype=torch.float32, device="cuda")
+    L().call("showo_lfq_unpack_nchw", L().ptr(allids), L().ptr(zq), 2, 13, 4096, S())
+    rt = torch.empty_like(allids)
+    L().call("showo_lfq_pack_nchw", L().ptr(zq), L().ptr(rt), 2, 13, 4096, S())
+    assert torch.equal(rt, allids)
+    assert set(zq.unique().tolist()) == {-1.0, 1.0}
+    zq2 = torch.empty((2, 4096, 13), dtype=torch.float32, device="cuda")
+    L().call("showo_lfq_unpack_nhwc", L().ptr(allids), L().ptr(zq2), 2, 13, 4096, S())
+    assert torch.equal(zq2.permute(0, 2, 1).contiguous(), zq)
+    # empty input is a no-op
+    L().call("showo_lfq_pack_nchw", None, None, 0, 13, 16, S())
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,H", [(37, 2048), (5, 128), (3, 100)])
+def test_layernorm(rows, H):
+    torch.manual_seed(0)
+    x = torch.randn(rows, H) * 3 + 0.5
+    w, b = torch.randn(H) * 0.1 + 1, torch.randn(H) * 0.05
+    y = torch.empty((rows, H), dtype=torch.int16, device="cuda")
+    L().call("showo_layernorm_f32_bf16", L().ptr(dev(x)), L().ptr(dev(w)), L().ptr(dev(b)), L().ptr(y), None, rows, H, 1e-5, S())
+    want = O.layer_norm(x, w, b, 1e-5)
+    got = from_bf16_bits(y).cpu()
+    assert (got - want).abs().max() <= 2 ** -8 * want.abs().max() + 1e-6  # one bf16 rounding of the fp32 result
+    idx = torch.tensor([rows - 1, 0, rows // 2], dtype=torch.int32)
+    y2 = torch.empty((3, H), dtype=torch.int16, device="cuda")
+    L().call("showo_layernorm_f32_bf16", L().ptr(dev(x)), L().ptr(dev(w)), L().ptr(dev(b)), L().ptr(y2), L().ptr(dev(idx)), 3, H, 1e-5, S())
+    assert torch.equal(y2.cpu(), y.cpu()[idx.long()])
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm(A, W, bias, epi, resid=None, per_row=False, ldo=None):
+    M, K = A.shape
+    N = W.shape[0]
+    Ad, Wd = to_bf16_bits(A).cuda().contiguous(), to_bf16_bits(W).cuda().contiguous()
+    bd = None if bias is None else dev(bias)
+    ldo = ldo or N
+    f32 = epi in (2, 3)
+    out = torch.full((M, ldo), float("nan") if f32 else 0, dtype=torch.float32 if f32 else torch.int16, device="cuda")
+    rd = None if resid is None else dev(resid)
+    L().call("showo_gemm_bf16", L().ptr(Ad), K, L().ptr(Wd), K, L().ptr(bd), int(per_row), L().ptr(out), ldo, L().ptr(rd),
+             ldo if rd is not None else 0, M, N, K, epi, S())
+    sync()
+    return (out if f32 else from_bf16_bits(out)).cpu()[:, :N]
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 130, 64), (1, 512, 256), (774, 2048, 2048), (300, 439, 128)])
+def test_gemm_epilogues(M, N, K):
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K)
+    W = torch.randn(N, K) * 0.05
+    bias = torch.randn(N)
+    ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double()
+    tol = 1e-3 * float(ref.abs().max())
+    got = _gemm(A, W, bias, 2)  # fp32 out
+    assert (got.double() - ref).abs().max() < tol, (got.double() - ref).abs().max()
+    got = _gemm(A, W, bias, 0)  # bf16 out
+    assert (got.double() - ref).abs().max() < 2 ** -8 * float(ref.abs().max()) + tol
+    got = _gemm(A, W, bias, 1)  # gelu_new bf16
+    want = O.gelu_new(ref.float()).double()
+    assert (got.double() - want).abs().max() < 2 ** -8 * float(want.abs().max()) + tol
+    resid = torch.randn(M, N)
+    got = _gemm(A, W, bias, 3, resid=resid)
+    assert (got.double() - (ref + resid.double())).abs().max() < tol
+    if M >= 100:
+        brow = torch.randn(M)
+        got = _gemm(A, W, brow, 2, per_row=True)
+        ref2 = bf16_round(A).double() @ bf16_round(W).double().T + brow.double()[:, None]
+        assert (got.double() - ref2).abs().max() < tol
+
+
+def test_gemm_inplace_residual_and_errors():
+    torch.manual_seed(1)
+    M, N, K = 130, 256, 128
+    A, W, bias, x = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N), torch.randn(M, N)
+    Ad, Wd = to_bf16_bits(A).cuda(), to_bf16_bits(W).cuda()
+    xd = dev(x)
+    L().call("showo_gemm_bf16", L().ptr(Ad), K, L().ptr(Wd), K, L().ptr(dev(bias)), 0, L().ptr(xd), N, L().ptr(xd), N, M, N, K, 3, S())
+    ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double() + x.double()
+    assert (xd.cpu().double() - ref).abs().max() < 1e-3 * float(ref.abs().max())
+    with pytest.raises(RuntimeError):  # K not a multiple of 64 is rejected, not silently mis-computed
+        L().call("showo_gemm_bf16", L().ptr(Ad), K, L().ptr(Wd), K, None, 0, L().ptr(xd), N, None, 0, M, N, 100, 2, S())
+
+
+# ------------------------------------------------------------------------------- qk-prep + attention
+def _rope_tables(rot=32, max_pos=2048):
+    return O.rope_tables(rot, max_pos, 10000.0)
+
+
+def _prep(qkv, qw, qb, kw, kb, B, Lq, nH, pos0=0, Lcap=None, Lp=None, Kbuf=None, Vbuf=None):
+    cos, sin = _rope_tables()
+    Lcap = Lcap or Lq
+    Lp = Lp or ((Lq + 63) // 64) * 64
+    Q = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
+    K = Kbuf if Kbuf is not None else torch.zeros((B, nH, Lcap, 64), dtype=torch.int16, device="cuda")
+    Vt = Vbuf if Vbuf is not None else torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda")
+    L().call("showo_qk_prep", L().ptr(to_bf16_bits(qkv).cuda().contiguous()), L().ptr(dev(qw)), L().ptr(dev(qb)), L().ptr(dev(kw)),
+             L().ptr(dev(kb)), L().ptr(dev(cos)), L().ptr(dev(sin)), L().ptr(Q), L().ptr(K), L().ptr(Vt), B, Lq, nH, 32, 1e-5,
+             pos0, Lcap, Lp, S())
+    sync()
+    return Q, K, Vt
+
+
+def _prep_oracle(qkv, qw, qb, kw, kb, B, Lq, nH, pos0=0):
+    x = bf16_round(qkv).view(B, Lq, 3, nH, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))  # [B,nH,L,64]
+    cos, sin = _rope_tables()
+    q = O.layer_norm(q, qw, qb, 1e-5)
+    k = O.layer_norm(k, kw, kb, 1e-5)
+    cs, sn = cos[pos0:pos0 + Lq], sin[pos0:pos0 + Lq]
+    return O.apply_partial_rope(q, cs, sn, 32), O.apply_partial_rope(k, cs, sn, 32), v
+
+
+@pytest.mark.parametrize("B,Lq,nH", [(2, 27, 2), (1, 387, 3), (2, 70, 1)])
+def test_qk_prep(B, Lq, nH):
+    torch.manual_seed(0)
+    qkv = torch.randn(B * Lq, 3 * nH * 64)
+    qw, qb, kw, kb = torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05
+    Q, K, Vt = _prep(qkv, qw, qb, kw, kb, B, Lq, nH)
+    q, k, v = _prep_oracle(qkv, qw, qb, kw, kb, B, Lq, nH)
+    assert (from_bf16_bits(Q).cpu() - q * 0.125).abs().max() < 2 ** -8 * float((q * 0.125).abs().max()) + 1e-6
+    assert (from_bf16_bits(K).cpu() - k).abs().max() < 2 ** -8 * float(k.abs().max()) + 1e-6
+    vt = from_bf16_bits(Vt).cpu()
+    assert torch.equal(vt[..., :Lq], v.transpose(2, 3).contiguous())  # pure relayout: bit-exact
+    assert (vt[..., Lq:] == 0).all()  # pad keys are zero (finite) by contract
+
+
+def _attn(Q, K, Vt, B, nH, Lq, Lk, mask=None, causal=False, Lcap=None):
+    Lp = Vt.shape[-1]
+    Lcap = Lcap or K.shape[2]
+    Od = torch.zeros((B, Lq, nH * 64), dtype=torch.int16, device="cuda")
+    if causal:
+        L().call("showo_attn_fwd", L().ptr(Q), L().ptr(K), L().ptr(Vt), None, None, None, L().ptr(Od), B, nH, Lq, Lk, Lcap, Lp, nH * 64, S())
+        return from_bf16_bits(Od).cpu(), None
+    md = dev(mask)
+    iv = torch.zeros((B, Lq, 4), dtype=torch.int32, device="cuda")
+    flag = torch.zeros(4, dtype=torch.int32, device="cuda")
+    L().call("showo_mask_compress", L().ptr(md), L().ptr(iv), L().ptr(flag), B, Lq, Lk, S())
+    L().call("showo_attn_fwd", L().ptr(Q), L().ptr(K), L().ptr(Vt), L().ptr(iv), L().ptr(flag), L().ptr(md), L().ptr(Od), B, nH, Lq, Lk, Lcap,
+             Lp, nH * 64, S())
+    sync()
+    return from_bf16_bits(Od).cpu(), (iv.cpu(), int(flag[0]))
+
+
+def _attn_oracle(Q, K, Vt, mask, Lq, Lk):
+    q = from_bf16_bits(Q).cpu()  # already scaled by 1/8
+    k = from_bf16_bits(K).cpu()[:, :, :Lk]
+    v = from_bf16_bits(Vt).cpu()[..., :Lk].transpose(2, 3)
+    s = q @ k.transpose(2, 3) + mask
+    a = torch.softmax(s, dim=-1)
+    o = a @ v  # [B,nH,Lq,64]
+    B, nH = o.shape[:2]
+    return o.transpose(1, 2).reshape(B, Lq, nH * 64)
+
+
+def _mask_cases(d, Lq):
+    """the mask families of SURVEY.md §8a A5 at sequence length Lq (image block = Lq - text - 2)"""
+    rs = np.random.RandomState(1)
+    T = min(129, Lq // 3)
+    N = Lq - T - 2
+    rows = []
+    for k in (3, T, T // 2 + 1):
+        words = rs.randint(0, 100, size=k).tolist()
+        rows.append([d.pad_id] * (T - k) + words + [d.soi_id] + [d.mask_token_id] * N + [d.eoi_id])
+    ids = torch.tensor(rows)
+    yield "t2i", O.mask_t2i(ids, d.pad_id, d.soi_id, d.eoi_id)
+    ids_m = torch.tensor([[d.mmu_id, d.soi_id] + [7] * N + [d.eoi_id] + [5] * (Lq - N - 3)] * 2)
+    yield "mmu", O.mask_mmu(ids_m, d.eoi_id)
+    yield "lm_causal", O.mask_t2i(torch.full((2, Lq), 5), d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False)
+
+
+@pytest.mark.parametrize("Lq,nH", [(27, 2), (387, 2), (1155, 1)])
+def test_attention_mask_families(Lq, nH):
+    d = util.tiny_dims()
+    torch.manual_seed(Lq)
+    for name, mask in _mask_cases(d, Lq):
+        B = mask.shape[0]
+        qkv = torch.randn(B * Lq, 3 * nH * 64) * 2
+        qw, qb, kw, kb = torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05
+        Q, K, Vt = _prep(qkv, qw, qb, kw, kb, B, Lq, nH)
+        got, (iv, flag) = _attn(Q, K, Vt, B, nH, Lq, Lq, mask)
+        assert flag == 0, f"{name}: reference-built masks must be interval-representable"
+        # intervals reproduce the dense mask exactly
+        vis = (mask[:, 0] == 0)
+        c = torch.arange(Lq)[None, None, :]
+        rec = ((c >= iv[..., 0:1]) & (c < iv[..., 1:2])) | ((c >= iv[..., 2:3]) & (c < iv[..., 3:4]))
+        assert torch.equal(rec, vis), name
+        want = _attn_oracle(Q, K, Vt, mask, Lq, Lq)
+        err = (got - want).abs().max()
+        # P and O are rounded to bf16 once each: 2^-8 relative to max|V| is the expected scale
+        assert err < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3, (name, float(err))
+
+
+def test_attention_mmu_vit_and_dense_fallback():
+    torch.manual_seed(3)
+    nH, Lq = 2, 700
+    mask = O.mask_mmu_vit(1, Lq, system_prompt_len=28)  # causal + columns [30,606) visible: two intervals
+    qkv = torch.randn(Lq, 3 * nH * 64)
+    p = [torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05]
+    Q, K, Vt = _prep(qkv, *p, 1, Lq, nH)
+    got, (iv, flag) = _attn(Q, K, Vt, 1, nH, Lq, Lq, mask)
+    assert flag == 0
+    want = _attn_oracle(Q, K, Vt, mask, Lq, Lq)
+    assert (got - want).abs().max() < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+    # arbitrary (non-interval) visibility + a soft additive bias -> dense path must be taken and be right
+    Lq = 150
+    vis = torch.rand(2, 1, Lq, Lq) < 0.5
+    vis |= torch.eye(Lq, dtype=torch.bool)[None, None]
+    mask = torch.where(vis, torch.zeros(()), torch.full((), O.NEG_MASK))
+    mask[:, :, :, 3] = -1.5  # soft bias column
+    qkv = torch.randn(2 * Lq, 3 * nH * 64)
+    Q, K, Vt = _prep(qkv, *p, 2, Lq, nH)
+    got, (iv, flag) = _attn(Q, K, Vt, 2, nH, Lq, Lq, mask)
+    assert flag == 1
+    want = _attn_oracle(Q, K, Vt, mask, Lq, Lq)
+    assert (got - want).abs().max() < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+    # no mask -> causal
+    got, _ = _attn(Q, K, Vt, 2, nH, Lq, Lq, causal=True)
+    cm = torch.where(torch.tril(torch.ones(Lq, Lq, dtype=torch.bool)), torch.zeros(()), torch.full((), O.NEG_MASK))[None, None]
+    want = _attn_oracle(Q, K, Vt, cm, Lq, Lq)
+    assert (got - want).abs().max() < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+
+
+def test_attention_online_softmax_rescale_branch():
+    """force the running-max rescale: one key in a late tile dominates one query row (CDNA playbook rule 26)"""
+    torch.manual_seed(5)
+    nH, Lq = 1, 200
+    qkv = torch.randn(Lq, 3 * 64)
+    p = [torch.ones(64), torch.zeros(64), torch.ones(64), torch.zeros(64)]
+    Q, K, Vt = _prep(qkv, *p, 1, Lq, nH)
+    Qf, Kf = from_bf16_bits(Q), from_bf16_bits(K)
+    Kf[0, 0, 170] = Qf[0, 0, 180] * 8 * 6.0  # q180 . k170 is huge -> max jumps at key tile 160..191
+    K2 = to_bf16_bits(Kf.cpu()).cuda().contiguous()
+    mask = torch.zeros(1, 1, Lq, Lq)
+    got, _ = _attn(Q, K2, Vt, 1, nH, Lq, Lq, mask)
+    want = _attn_oracle(Q, K2, Vt, mask, Lq, Lq)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+
+
+def test_kv_cache_append_matches_full():
+    """qk_prep append path + Lq=1 attention == last row of the full computation (exactness of the KV cache)"""
+    torch.manual_seed(7)
+    nH, L0, cap = 2, 45, 128
+    qkv = torch.randn(L0 + 1, 3 * nH * 64)
+    p = [torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05]
+    Qf, Kf, Vf = _prep(qkv, *p, 1, L0 + 1, nH)
+    mask = O.mask_t2i(torch.full((1, L0 + 1), 5), 0, 1, 2, rm_pad_in_image=False)
+    full, _ = _attn(Qf, Kf, Vf, 1, nH, L0 + 1, L0 + 1, mask)
+    Kc = torch.zeros((1, nH, cap, 64), dtype=torch.int16, device="cuda")
+    Vc = torch.zeros((1, nH, 64, cap), dtype=torch.int16, device="cuda")
+    _prep(qkv[:L0], *p, 1, L0, nH, pos0=0, Lcap=cap, Lp=cap, Kbuf=Kc, Vbuf=Vc)
+    Q1, _, _ = _prep(qkv[L0:], *p, 1, 1, nH, pos0=L0, Lcap=cap, Lp=cap, Kbuf=Kc, Vbuf=Vc)
+    assert torch.equal(Kc[:, :, :L0 + 1].cpu(), Kf.cpu())
+    assert torch.equal(Vc[..., :L0 + 1].cpu(), Vf[..., :L0 + 1].cpu())
+    one, _ = _attn(Q1, Kc, Vc, 1, nH, 1, L0 + 1, causal=True, Lcap=cap)
+    assert torch.equal(one[0, 0], full[0, L0])
+
+
+# --------------------------------------------------------------------------------------------- sampler
+def test_sampler_teacher_forced_against_reference_trajectory():
+    """feed the reference's own per-step logits + its recorded noise into the HIP sampler: ids must match."""
+    g = util.golden("showo_tiny_t2i.npz")
+    d = util.tiny_dims()
+    steps, w = int(g["steps"]), float(g["guidance"])
+    B, N, V = g["ids_cond"].shape[0], d.num_vq_tokens, d.codebook
+    off, mask_id = d.image_offset, d.mask_token_id
+    Lseq = g["ids_cond"].shape[1]
+    img0 = Lseq - (N + 1)
+    ml, tp = util.pkg().sampling.t2i_step_constants(steps, N)
+    mismatches = 0
+    for s in range(steps):
+        ids_in = torch.from_numpy(g["fwd_in"][s])  # [2B, L] as fed to the reference model at this step
+        lg = torch.from_numpy(g["fwd_logits"][s])[:, img0:img0 + N, off:off + V].contiguous()  # [2B,N,V]
+        cur = ids_in[:B, img0:img0 + N].clone()
+        cur = torch.where(cur == mask_id, cur, cur - off)
+        lc, lu = dev(lg[:B].reshape(B * N, V)), dev(lg[B:].reshape(B * N, V))
+        curd = dev(cur)
+        sampled = torch.empty((B, N), dtype=torch.int64, device="cuda")
+        sel = torch.empty((B, N), dtype=torch.float32, device="cuda")
+        en = dev(g["exp_noise"][s].reshape(B * N, V))
+        L().call("showo_cfg_softmax_sample", L().ptr(lc), L().ptr(lu), V, w, L().ptr(curd), mask_id, L().ptr(en), 0, s,
+                 L().ptr(sampled), L().ptr(sel), B, N, V, S())
+        # oracle for this step from the same inputs
+        z = (1 + w) * lg[:B] - w * lg[B:]
+        probs = z.softmax(-1)
+        want = torch.argmax(probs.reshape(B * N, V) / torch.from_numpy(g["exp_noise"][s]).reshape(B * N, V), -1).view(B, N)
+        unknown = cur == mask_id
+        want = torch.where(unknown, want, cur)
+        assert torch.equal(want[unknown], torch.from_numpy(g["multinomial"][s]).view(B, N)[unknown])  # oracle == reference draw
+        got = sampled.cpu()
+        mismatches += int((got != want).sum())
+        assert torch.equal(got[~unknown], cur[~unknown])
+        selw = torch.where(unknown, torch.gather(probs, -1, want[..., None])[..., 0], torch.tensor(torch.finfo(torch.float32).max))
+        ok = got == want
+        assert torch.allclose(sel.cpu()[ok], selw[ok], rtol=2e-5, atol=1e-9)
+        # mask_by_topk with the reference's uniform draws; feed the ORACLE's sampled/sel so the step is isolated
+        ids_c = dev(ids_in[:B].clone())
+        ids_u = dev(ids_in[B:].clone())
+        masking = torch.zeros((B, N), dtype=torch.uint8, device="cuda")
+        cur2 = dev(cur)
+        L().call("showo_mask_by_topk", L().ptr(dev(selw)), L().ptr(dev(want)), L().ptr(cur2), L().ptr(ids_c), L().ptr(ids_u), Lseq, img0,
+                 mask_id, off, ml[s], tp[s], L().ptr(dev(g["uniform"][s].reshape(B, N))), 0, s, L().ptr(masking), B, N, S())
+        sync()
+        if s + 1 < steps:
+            nxt = torch.from_numpy(g["fwd_in"][s + 1])
+            assert torch.equal(ids_c.cpu(), nxt[:B]), f"step {s}: re-masked ids differ from the reference"
+            assert torch.equal(ids_u.cpu()[:, img0:img0 + N], nxt[B:, img0:img0 + N])
+        else:
+            assert torch.equal(ids_c.cpu(), torch.from_numpy(g["final_input_ids"]))
+    assert mismatches == 0, f"{mismatches} sampled ids differ from the reference draw"
+
+
+def test_sampler_philox_distribution():
+    """chi-square of the on-device Philox sampler against the softmax it samples from (no injected noise)."""
+    torch.manual_seed(0)
+    V, rows = 16, 20000
+    logit = torch.randn(V)
+    lc = dev(logit[None].repeat(rows, 1))
+    cur = torch.full((rows,), 99, dtype=torch.int64, device="cuda")
+    sampled = torch.empty((rows,), dtype=torch.int64, device="cuda")
+    sel = torch.empty((rows,), dtype=torch.float32, device="cuda")
+    L().call("showo_cfg_softmax_sample", L().ptr(lc), None, V, 0.0, L().ptr(cur), 99, None, 1234, 0, L().ptr(sampled), L().ptr(sel), rows, 1, V, S())
+    p = logit.softmax(-1).double()
+    cnt = torch.bincount(sampled.cpu(), minlength=V).double()
+    chi2 = float(((cnt - rows * p) ** 2 / (rows * p)).sum())
+    assert chi2 < 50.0, chi2  # dof = 15; P(chi2 > 50) ~ 1e-5
+    assert torch.allclose(sel.cpu().double(), p[sampled.cpu()], rtol=1e-5)
+    # different step -> different draws
+    s2 = torch.empty_like(sampled)
+    L().call("showo_cfg_softmax_sample", L().ptr(lc), None, V, 0.0, L().ptr(cur), 99, None, 1234, 1, L().ptr(s2), L().ptr(sel), rows, 1, V, S())
+    assert (s2 != sampled).float().mean() > 0.3
+
+
+# ------------------------------------------------------------------------------------ VQGAN kernels
+def test_groupnorm_and_conv():
+    torch.manual_seed(0)
+    B, H, W, Cin, Cout = 2, 12, 10, 128, 256
+    x = torch.randn(B, Cin, H, W) * 2 + 0.3
+    gam, bet = torch.randn(Cin) * .1 + 1, torch.randn(Cin) * .05
+    xn = dev(x.permute(0, 2, 3, 1))
+    stats = torch.zeros((B, 32, 2), dtype=torch.float64, device="cuda")
+    y = torch.empty((B, H * W, Cin), dtype=torch.int16, device="cuda")
+    L().call("showo_gn_stats", L().ptr(xn), L().ptr(stats), B, H * W, Cin, S())
+    L().call("showo_gn_apply", L().ptr(xn), L().ptr(stats), L().ptr(dev(gam)), L().ptr(dev(bet)), L().ptr(y), B, H * W, Cin, 1e-6, 1, S())
+    want = O.swish(O.group_norm(x, gam, bet)).permute(0, 2, 3, 1).reshape(B, H * W, Cin)
+    got = from_bf16_bits(y).cpu()
+    assert (got - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-5
+    # conv modes on the bf16 image, vs F.conv2d on the same rounded operands
+    import torch.nn.functional as F
+    a = from_bf16_bits(y).cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+    wgt = torch.randn(Cout, Cin, 3, 3) * 0.03
+    bias = torch.randn(Cout)
+    wp = to_bf16_bits(wgt.permute(0, 2, 3, 1).contiguous()).cuda()
+    wr = bf16_round(wgt)
+    for mode, (Ho, Wo) in ((0, (H, W)), (1, (2 * H, 2 * W)), (2, (H // 2, W // 2))):
+        out = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        res = torch.randn(B, Ho * Wo, Cout)
+        L().call("showo_conv3x3_bf16", L().ptr(y), L().ptr(wp), L().ptr(dev(bias)), L().ptr(dev(res)), L().ptr(out), B, H, W, Cin, Cout, mode, S())
+        if mode == 0:
+            ref = F.conv2d(a, wr, bias, padding=1)
+        elif mode == 1:
+            ref = F.conv2d(a.repeat_interleave(2, 2).repeat_interleave(2, 3), wr, bias, padding=1)
+        else:
+            ref = F.conv2d(F.pad(a, (0, 1, 0, 1)), wr, bias, stride=2)
+        ref = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout) + res
+        err = (out.cpu() - ref).abs().max()
+        assert err < 1e-3 * float(ref.abs().max()), (mode, float(err))
+    # thin output (Cout = 3, like decoder.conv_out)
+    w3 = torch.randn(3, Cin, 3, 3) * 0.03
+    out = torch.empty((B, H * W, 3), dtype=torch.float32, device="cuda")
+    L().call("showo_conv3x3_bf16", L().ptr(y), L().ptr(to_bf16_bits(w3.permute(0, 2, 3, 1).contiguous()).cuda()), None, None, L().ptr(out), B, H, W,
+             Cin, 3, 0, S())
+    ref = F.conv2d(a, bf16_round(w3), None, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 3)
+    assert (out.cpu() - ref).abs().max() < 1e-3 * float(ref.abs().max())
+
+
+def test_softmax_rows_and_small_conv():
+    torch.manual_seed(1)
+    x = torch.randn(40, 100) * 3
+    y = torch.full((40, 128), 7, dtype=torch.int16, device="cuda")
+    L().call("showo_softmax_rows_bf16", L().ptr(dev(x)), L().ptr(y), 40, 100, 128, 0.5, S())
+    got = from_bf16_bits(y).cpu()
+    assert (got[:, :100] - torch.softmax(x * 0.5, -1)).abs().max() < 2 ** -8
+    assert (got[:, 100:] == 0).all()
+    import torch.nn.functional as F
+    z = torch.randn(2, 13, 5, 4)
+    wq, bq = torch.randn(13, 13, 1, 1), torch.randn(13)
+    out = torch.empty((2, 20, 13), dtype=torch.float32, device="cuda")
+    L().call("showo_conv_small_f32", L().ptr(dev(z.permute(0, 2, 3, 1))), L().ptr(dev(wq.permute(0, 2, 3, 1))), L().ptr(dev(bq)), L().ptr(out), 2, 5, 4,
+             13, 13, 1, S())
+    ref = F.conv2d(z, wq, bq).permute(0, 2, 3, 1).reshape(2, 20, 13)
+    assert (out.cpu() - ref).abs().max() < 1e-5
