@@ -20,6 +20,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
 
 def build_inputs(d, B, O):
     rs = np.random.RandomState(0)
@@ -39,9 +45,13 @@ def cpu_baseline(d, sd_t, O, steps_sample=3):
     denoise steps of ONE prompt with CFG ([2,387]) + one decode is timed and extrapolated to 18 steps."""
     torch.set_num_threads(os.cpu_count())
     ic, iu, mask = build_inputs(d, 1, O)
-    t0 = time.time()
-    O.t2i_generate(sd_t, d, ic.clone(), iu.clone(), mask, 1.0, steps_sample, 5.0)
-    t_steps = time.time() - t0
+    with torch.no_grad():
+        t0 = time.time()
+        O.t2i_generate(sd_t, d, ic.clone(), iu.clone(), mask, 1.0, 1, 5.0)  # warm-up step (page-in, thread pool)
+        log(f"cpu baseline warm-up step {time.time() - t0:.1f}s on {torch.get_num_threads()} threads")
+        t0 = time.time()
+        O.t2i_generate(sd_t, d, ic.clone(), iu.clone(), mask, 1.0, steps_sample, 5.0)
+        t_steps = time.time() - t0
     per_step = t_steps / steps_sample
     est = 18 * per_step  # decode (0.3 TFLOP of 38.4) is <1% and is left out of the CPU estimate, favouring the CPU
     return {"value": 1.0 / est, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -67,6 +77,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    log(f"rank {rank}/{world} start")
     import showo_amd
     import showo_oracle as O
     import weights as Wt
@@ -75,19 +86,25 @@ def main():
     B = a.batch
     # random-init weights of the true architecture (no checkpoints offline): generated on the GPU, N(0, 0.02)
     torch.manual_seed(0)
-    model = showo_amd.Showo(False, d.vocab, d.llm_vocab, codebook_size=d.codebook, num_vq_tokens=d.num_vq_tokens,
-                            max_batch=2 * B, max_seq=387)
-    model = model.cuda().eval()
+    with torch.device("meta"):
+        model = showo_amd.Showo(False, d.vocab, d.llm_vocab, codebook_size=d.codebook, num_vq_tokens=d.num_vq_tokens,
+                                max_batch=2 * B, max_seq=387)
+    model = model.to_empty(device="cuda").eval()
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "layernorm" in n and n.endswith("weight"):
                 p.normal_(1.0, 0.1)
-            elif n.endswith("bias"):
+            elif "layernorm" in n or n.endswith("bias"):
                 p.normal_(0.0, 0.02)
+            else:
+                p.normal_(0.0, 0.02)  # Phi init (reference models/phi.py:833-842)
+    log("showo params on GPU")
     vq = showo_amd.MAGVITv2(max_batch=B, max_res=256).cuda().eval()
+    log("vq params on GPU")
     cfg = showo_amd.gen_config()
     ic, iu, mask = build_inputs(d, B, O)
     ic_d, iu_d, mask_d = ic.cuda(), iu.cuda(), mask.cuda()
+    log("inputs built")
     gen = torch.Generator(device="cuda").manual_seed(1 + rank)
 
     def step():
@@ -97,7 +114,13 @@ def main():
         toks = torch.clamp(toks, max=d.codebook - 1, min=0)
         return vq.decode_code(toks)
 
-    for _ in range(a.warmup):
+    img = None
+    for i in range(a.warmup):
+        t1 = time.time()
+        img = step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i}: {time.time() - t1:.2f}s")
+    if img is None:
         img = step()
     assert tuple(img.shape) == (B, 3, 256, 256) and torch.isfinite(img).all()
 
@@ -116,6 +139,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.call("showo_prof_enable", 0)
+    log(f"timed {a.steps} steps in {dt:.2f}s")
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,6 +173,7 @@ def main():
                          "vq_conv": {"achieved": fl_conv.value / max(1e-9, ms_conv.value * 1e-3) / 1e12, "time_share": ms_conv.value * 1e-3 / dt}},
         }
         if not a.no_cpu_baseline and world == 1:
+            log("cpu baseline: copying weights to host")
             sd_t = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
             out["cpu_baseline"] = cpu_baseline(d, sd_t, O)
         else:

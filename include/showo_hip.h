@@ -62,6 +62,9 @@ enum {
 int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
                     void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, void* stream);
 
+/* kernel selection for tests/benchmarks: 0 = by shape (default), 1 = 128x128 register-staged, 2 = 256x256 global_load_lds */
+int showo_gemm_set_impl(int impl);
+
 /* fp32 -> bf16 cast (weight packing) */
 int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 

@@ -31,6 +31,7 @@ _PROTOS = {
     "showo_lfq_unpack_nhwc": [c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_layernorm_f32_bf16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "showo_gemm_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_set_impl": [c_i],
     "showo_cast_f32_bf16": [c_p, c_p, c_i64, c_p],
     "showo_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],

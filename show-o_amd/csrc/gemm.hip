@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/showo_hip.h"
 #include "prof.h"
+#include <cstdlib>
 
 using namespace showo;
 
@@ -97,6 +98,63 @@ __device__ inline float gelu_new_fast(float x) {
     // gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
     float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+
+__device__ inline void load_bias4(const GemmArgs& g, int n, float (&bn)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bn[r] = 0.f;
+    if (g.bias && !g.bias_per_row) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bn[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
+    }
+}
+
+// one MFMA C fragment: this lane holds out[m][n .. n+3]
+template <int EPI>
+__device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, int m, int n, const float (&bn)[4]) {
+    if (m >= g.M || n >= g.N) return;
+    float v[4];
+    const float bm = (g.bias && g.bias_per_row) ? g.bias[m] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] + bn[r] + bm;
+    const bool full = (n + 3 < g.N) && g.vec_out;
+    if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
+        if (EPI == SHOWO_EPI_GELU_BF16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_new_fast(v[r]);
+        }
+        bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
+        if (full) {
+            uint2 pk;
+            pk.x = pack_bf2(v[0], v[1]);
+            pk.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(o) = pk;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < g.N) o[r] = f2bf(v[r]);
+        }
+    } else {
+        float* o = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n;
+        if (EPI == SHOWO_EPI_RESID_F32) {
+            const float* rs = g.resid + (int64_t)m * g.ldr + n;
+            if (full) {
+                float4 rv = *reinterpret_cast<const float4*>(rs);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) v[r] += rs[r];
+            }
+        }
+        if (full) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < g.N) o[r] = v[r];
+        }
+    }
 }
 
 template <int EPI, class Loader>
@@ -196,58 +254,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + fg * 4;
-        float bn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias && !g.bias_per_row) {
+        float bn[4];
+        load_bias4(g, n, bn);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bn[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + fr;
-            if (m >= g.M || n >= g.N) continue;
-            float v[4];
-            const float bm = (g.bias && g.bias_per_row) ? g.bias[m] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bn[r] + bm;
-            const bool full = (n + 3 < g.N) && g.vec_out;
-            if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
-                if (EPI == SHOWO_EPI_GELU_BF16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_new_fast(v[r]);
-                }
-                bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
-                if (full) {
-                    uint2 pk;
-                    pk.x = pack_bf2(v[0], v[1]);
-                    pk.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(o) = pk;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) o[r] = f2bf(v[r]);
-                }
-            } else {
-                float* o = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n;
-                if (EPI == SHOWO_EPI_RESID_F32) {
-                    const float* rs = g.resid + (int64_t)m * g.ldr + n;
-                    if (full) {
-                        float4 rv = *reinterpret_cast<const float4*>(rs);
-                        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < g.N) v[r] += rs[r];
-                    }
-                }
-                if (full) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) o[r] = v[r];
-                }
-            }
-        }
+        for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + wm * 64 + j * 16 + fr, n, bn);
     }
 }
 
@@ -280,7 +290,208 @@ int dispatch(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) {
     return set_error_msg(1, "gemm: unknown epilogue");
 }
 
+
+// =====================================================================================================
+// v2: 256 x 256 x 64 tile, 8 waves (4 along n x 2 along m, wave tile 64 x 128), operands streamed
+// HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip) into two 64 KiB buffers; the LDS image is
+// lane-linear per wave-instruction (8 rows x 128 B), so the (row & 7) XOR swizzle is applied to the per-lane
+// SOURCE address and again on the ds_read (CDNA4 playbook: "swizzle both sides or neither").
+// One barrier per k-tile; the next tile's DMA is in flight under the 64 MFMAs of the current one.
+// =====================================================================================================
+constexpr int B2 = 256;
+constexpr int LDS_TILE2 = 256 * 64;
+constexpr int SMEM2_BYTES = 4 * LDS_TILE2 * 2;  // 128 KiB
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];  // source of out-of-image conv taps
+
+struct LinearPtr {
+    const bf16_t* A; int lda; int M;
+    const bf16_t* rowp[4];
+    __device__ inline void setup(int i, int m) {
+        int mm = m < M ? m : M - 1;
+        rowp[i] = A + (int64_t)mm * lda;
+    }
+    __device__ inline void tile(int) {}
+    __device__ inline const bf16_t* ptr(int i, int k0, int coff) const { return rowp[i] + k0 + coff; }
+};
+
+struct ConvPtr {
+    ConvArgs c; int M;
+    int oy[4], ox[4];
+    const bf16_t* img[4];
+    int ky, kx, cbase;
+    __device__ inline void setup(int i, int m) {
+        int mm = m < M ? m : M - 1;
+        int hw = c.Hout * c.Wout;
+        int b = mm / hw;
+        int p = mm - b * hw;
+        oy[i] = p / c.Wout;
+        ox[i] = p - oy[i] * c.Wout;
+        img[i] = c.X + (int64_t)b * c.Hin * c.Win * c.Cin;
+    }
+    __device__ inline void tile(int k0) {
+        int tap = k0 / c.Cin;
+        cbase = k0 - tap * c.Cin;
+        ky = tap / 3;
+        kx = tap - ky * 3;
+    }
+    __device__ inline const bf16_t* ptr(int i, int, int coff) const {
+        int iy, ix;
+        bool ok;
+        if (c.mode == 2) {
+            iy = 2 * oy[i] + ky; ix = 2 * ox[i] + kx;
+            ok = iy < c.Hin && ix < c.Win;
+        } else if (c.mode == 1) {
+            int uy = oy[i] + ky - 1, ux = ox[i] + kx - 1;
+            ok = uy >= 0 && ux >= 0 && uy < c.Hout && ux < c.Wout;
+            iy = uy >> 1; ix = ux >> 1;
+        } else {
+            iy = oy[i] + ky - 1; ix = ox[i] + kx - 1;
+            ok = iy >= 0 && ix >= 0 && iy < c.Hin && ix < c.Win;
+        }
+        if (!ok) return reinterpret_cast<const bf16_t*>(g_zero_page);
+        return img[i] + ((int64_t)iy * c.Win + ix) * c.Cin + cbase + coff;
+    }
+};
+
+__device__ inline void glds16(const bf16_t* src, bf16_t* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int EPI, class Loader>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, Loader ld_in) {
+    Loader ld = ld_in;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);  // [2][256*64]
+    bf16_t* sA = sW + 2 * LDS_TILE2;                     // [2][256*64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = (g.M + B2 - 1) / B2, tilesN = (g.N + B2 - 1) / B2;
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = bid / tilesM, tm = bid - tn * tilesM;
+    const int m0 = tm * B2, n0 = tn * B2;
+    const int nk = g.K / BK;
+
+    // staging: wave w issues row-groups w, w+8, w+16, w+24 (8 rows x 128 B each) of both operands
+    const int srow = lane >> 3;                       // row inside the group
+    const int coff = ((lane & 7) ^ srow) << 3;        // swizzled source chunk (elements)
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = (wave + 8 * i) * 8 + srow;
+        int n = n0 + row;
+        n = n < g.N ? n : g.N - 1;
+        wrow[i] = g.W + (int64_t)n * g.ldw;
+        ld.setup(i, m0 + row);
+    }
+    auto stage = [&](int buf, int kt) {
+        const int k0 = kt * BK;
+        ld.tile(k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int goff = (wave + 8 * i) * 512;  // 8 rows * 64 elements
+            glds16(wrow[i] + k0 + coff, sW + buf * LDS_TILE2 + goff);
+            glds16(ld.ptr(i, k0, coff), sA + buf * LDS_TILE2 + goff);
+        }
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave & 3, wm = wave >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const bf16_t* bW = sW + cur * LDS_TILE2;
+        const bf16_t* bA = sA + cur * LDS_TILE2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], af[8];
+            const int chunk = kk * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = wn * 64 + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const bf16x8*>(bW + row * 64 + ((chunk ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int row = wm * 128 + j * 16 + fr;
+                af[j] = *reinterpret_cast<const bf16x8*>(bA + row * 64 + ((chunk ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // drains the in-flight DMA (vmcnt(0)) and fences the buffer swap
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fg * 4;
+        float bn[4];
+        load_bias4(g, n, bn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) store_frag<EPI>(g, acc[i][j], m0 + wm * 128 + j * 16 + fr, n, bn);
+    }
+}
+
+template <int EPI, class Loader>
+int launch2(const GemmArgs& g, const Loader& ld, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = gemm256_kernel<EPI, Loader>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm256)", __FILE__, __LINE__);
+        attr_set = true;
+    }
+    int tilesM = (g.M + B2 - 1) / B2, tilesN = (g.N + B2 - 1) / B2;
+    kfn<<<dim3(tilesM * tilesN), dim3(512), SMEM2_BYTES, s>>>(g, ld);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "gemm256 launch", __FILE__, __LINE__);
+    return 0;
+}
+
+template <class Loader>
+int dispatch2(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case SHOWO_EPI_BF16: return launch2<SHOWO_EPI_BF16>(g, ld, s);
+        case SHOWO_EPI_GELU_BF16: return launch2<SHOWO_EPI_GELU_BF16>(g, ld, s);
+        case SHOWO_EPI_F32: return launch2<SHOWO_EPI_F32>(g, ld, s);
+        case SHOWO_EPI_RESID_F32: return launch2<SHOWO_EPI_RESID_F32>(g, ld, s);
+    }
+    return set_error_msg(1, "gemm: unknown epilogue");
+}
+
+// 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel, 0 = pick by shape
+int g_gemm_forced = -1;
+int gemm_impl_choice(int M, int N) {
+    if (g_gemm_forced < 0) {
+        const char* e = getenv("SHOWO_GEMM_IMPL");
+        g_gemm_forced = e ? atoi(e) : 0;
+    }
+    if (g_gemm_forced == 1 || g_gemm_forced == 2) return g_gemm_forced;
+    return (M >= 1024 && N >= 256) ? 2 : 1;
+}
+
 }  // namespace
+
+// 0 = choose by shape (default), 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel
+extern "C" int showo_gemm_set_impl(int impl) {
+    g_gemm_forced = (impl == 1 || impl == 2) ? impl : 0;
+    return 0;
+}
 
 extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
                                void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue,
@@ -300,6 +511,11 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     LinearLoader ld;
     ld.A = A; ld.lda = lda; ld.M = M;
     ProfScope prof(PROF_GEMM, 2.0 * M * N * K, (hipStream_t)stream);
+    if (gemm_impl_choice(M, N) == 2) {
+        LinearPtr lp;
+        lp.A = A; lp.lda = lda; lp.M = M;
+        return dispatch2(g, lp, epilogue, (hipStream_t)stream);
+    }
     return dispatch(g, ld, epilogue, (hipStream_t)stream);
 }
 
@@ -322,5 +538,10 @@ extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const fl
     ld.c = c; ld.M = g.M;
     // algorithmic flops of the convolution: real (unpadded) taps x channels
     ProfScope prof(PROF_CONV, 2.0 * g.M * Cout * 9.0 * Cin, (hipStream_t)stream);
+    if (gemm_impl_choice(g.M, Cout) == 2) {
+        ConvPtr cp;
+        cp.c = c; cp.M = g.M;
+        return dispatch2(g, cp, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
+    }
     return dispatch(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
 }

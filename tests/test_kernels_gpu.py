@@ -88,7 +88,7 @@ def test_layernorm(rows, H):
 def _gemm(A, W, bias, epi, resid=None, per_row=False, ldo=None):
     M, K = A.shape
     N = W.shape[0]
-    Ad, Wd = to_bf16_bits(A).cuda().contiguous(), to_bf16_bits(W).cuda().contiguous()
+    Ad, Wd = dev(to_bf16_bits(A)), dev(to_bf16_bits(W))
     bd = None if bias is None else dev(bias)
     ldo = ldo or N
     f32 = epi in (2, 3)
@@ -129,7 +129,7 @@ def test_gemm_inplace_residual_and_errors():
     torch.manual_seed(1)
     M, N, K = 130, 256, 128
     A, W, bias, x = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N), torch.randn(M, N)
-    Ad, Wd = to_bf16_bits(A).cuda(), to_bf16_bits(W).cuda()
+    Ad, Wd = dev(to_bf16_bits(A)), dev(to_bf16_bits(W))
     xd = dev(x)
     L().call("showo_gemm_bf16", L().ptr(Ad), K, L().ptr(Wd), K, L().ptr(dev(bias)), 0, L().ptr(xd), N, L().ptr(xd), N, M, N, K, 3, S())
     ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double() + x.double()
@@ -150,7 +150,7 @@ def _prep(qkv, qw, qb, kw, kb, B, Lq, nH, pos0=0, Lcap=None, Lp=None, Kbuf=None,
     Q = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
     K = Kbuf if Kbuf is not None else torch.zeros((B, nH, Lcap, 64), dtype=torch.int16, device="cuda")
     Vt = Vbuf if Vbuf is not None else torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda")
-    L().call("showo_qk_prep", L().ptr(to_bf16_bits(qkv).cuda().contiguous()), L().ptr(dev(qw)), L().ptr(dev(qb)), L().ptr(dev(kw)),
+    L().call("showo_qk_prep", L().ptr(dev(to_bf16_bits(qkv))), L().ptr(dev(qw)), L().ptr(dev(qb)), L().ptr(dev(kw)),
              L().ptr(dev(kb)), L().ptr(dev(cos)), L().ptr(dev(sin)), L().ptr(Q), L().ptr(K), L().ptr(Vt), B, Lq, nH, 32, 1e-5,
              pos0, Lcap, Lp, S())
     sync()
@@ -286,7 +286,7 @@ def test_attention_online_softmax_rescale_branch():
     Q, K, Vt = _prep(qkv, *p, 1, Lq, nH)
     Qf, Kf = from_bf16_bits(Q), from_bf16_bits(K)
     Kf[0, 0, 170] = Qf[0, 0, 180] * 8 * 6.0  # q180 . k170 is huge -> max jumps at key tile 160..191
-    K2 = to_bf16_bits(Kf.cpu()).cuda().contiguous()
+    K2 = dev(to_bf16_bits(Kf.cpu()))
     mask = torch.zeros(1, 1, Lq, Lq)
     got, _ = _attn(Q, K2, Vt, 1, nH, Lq, Lq, mask)
     want = _attn_oracle(Q, K2, Vt, mask, Lq, Lq)
@@ -407,7 +407,7 @@ def test_groupnorm_and_conv():
     a = from_bf16_bits(y).cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
     wgt = torch.randn(Cout, Cin, 3, 3) * 0.03
     bias = torch.randn(Cout)
-    wp = to_bf16_bits(wgt.permute(0, 2, 3, 1).contiguous()).cuda()
+    wp = dev(to_bf16_bits(wgt.permute(0, 2, 3, 1).contiguous()))
     wr = bf16_round(wgt)
     for mode, (Ho, Wo) in ((0, (H, W)), (1, (2 * H, 2 * W)), (2, (H // 2, W // 2))):
         out = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
@@ -425,7 +425,7 @@ def test_groupnorm_and_conv():
     # thin output (Cout = 3, like decoder.conv_out)
     w3 = torch.randn(3, Cin, 3, 3) * 0.03
     out = torch.empty((B, H * W, 3), dtype=torch.float32, device="cuda")
-    L().call("showo_conv3x3_bf16", L().ptr(y), L().ptr(to_bf16_bits(w3.permute(0, 2, 3, 1).contiguous()).cuda()), None, None, L().ptr(out), B, H, W,
+    L().call("showo_conv3x3_bf16", L().ptr(y), L().ptr(dev(to_bf16_bits(w3.permute(0, 2, 3, 1).contiguous()))), None, None, L().ptr(out), B, H, W,
              Cin, 3, 0, S())
     ref = F.conv2d(a, bf16_round(w3), None, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 3)
     assert (out.cpu() - ref).abs().max() < 1e-3 * float(ref.abs().max())
@@ -447,3 +447,25 @@ def test_softmax_rows_and_small_conv():
              13, 13, 1, S())
     ref = F.conv2d(z, wq, bq).permute(0, 2, 3, 1).reshape(2, 20, 13)
     assert (out.cpu() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_gemm_both_tile_kernels(impl):
+    """the 128^2 register-staged kernel and the 256^2 global_load_lds kernel give the same result on shapes
+    with ragged M/N edges (rows/cols beyond the edge are clamped on load and predicated on store)"""
+    L().call("showo_gemm_set_impl", impl)
+    try:
+        torch.manual_seed(impl)
+        for (M, N, K) in [(1100, 520, 192), (6192 // 4, 2048, 256), (300, 256, 64)]:
+            A, W, bias = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N)
+            ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double()
+            got = _gemm(A, W, bias, 2)
+            assert (got.double() - ref).abs().max() < 1e-3 * float(ref.abs().max()), (impl, M, N, K)
+            resid = torch.randn(M, N)
+            got = _gemm(A, W, bias, 3, resid=resid)
+            assert (got.double() - (ref + resid.double())).abs().max() < 1e-3 * float(ref.abs().max())
+            got = _gemm(A, W, bias, 1)
+            want = O.gelu_new(ref.float()).double()
+            assert (got.double() - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-3 * float(ref.abs().max())
+    finally:
+        L().call("showo_gemm_set_impl", 0)

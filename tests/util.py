@@ -29,11 +29,22 @@ def lib():
     return pkg()._lib
 
 
+_KEEP = []  # device tensors created by dev() stay alive until the end of the test: the C ABI takes raw pointers,
+            # and a temporary freed before the launch could be recycled by the caching allocator
+
+
 def dev(x, dtype=None):
     t = torch.as_tensor(x)
     if dtype is not None:
         t = t.to(dtype)
-    return t.cuda().contiguous()
+    t = t.cuda().contiguous()
+    _KEEP.append(t)
+    return t
+
+
+def release():
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    _KEEP.clear()
 
 
 def to_bf16_bits(t):
@@ -68,11 +79,13 @@ def tiny_state(seed=11):
 def build_showo(d, sd_np, max_batch=8, max_seq=128):
     """drop-in Showo on the GPU with the given (numpy) state dict"""
     S = pkg().Showo
-    m = S(w_clip_vit=d.w_clip_vit, vocab_size=d.vocab, llm_vocab_size=d.llm_vocab, codebook_size=d.codebook,
-          num_vq_tokens=d.num_vq_tokens, hidden_size=d.hidden, intermediate_size=d.ffn, num_hidden_layers=d.layers,
-          num_attention_heads=d.heads, max_position_embeddings=d.max_pos, max_batch=max_batch, max_seq=max_seq)
+    with torch.device("meta"):  # parameters are materialised directly on the GPU (no CPU init of 1.45 B values)
+        m = S(w_clip_vit=d.w_clip_vit, vocab_size=d.vocab, llm_vocab_size=d.llm_vocab, codebook_size=d.codebook,
+              num_vq_tokens=d.num_vq_tokens, hidden_size=d.hidden, intermediate_size=d.ffn, num_hidden_layers=d.layers,
+              num_attention_heads=d.heads, max_position_embeddings=d.max_pos, max_batch=max_batch, max_seq=max_seq)
+    m = m.to_empty(device="cuda")
     m.load_state_dict(O.to_torch(sd_np), strict=True)
-    return m.cuda().eval()
+    return m.eval()
 
 
 def gen_config(d):
