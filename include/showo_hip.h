@@ -65,6 +65,16 @@ int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, cons
 /* kernel selection for tests/benchmarks: 0 = by shape (default), 1 = 128x128 register-staged, 2 = 256x256 global_load_lds */
 int showo_gemm_set_impl(int impl);
 
+/* Split-precision forms (VQGAN path): every operand is a (hi, lo) bf16 pair, x = hi + lo to ~2^-17; the MFMA
+ * accumulates hi*hi + hi*lo + lo*hi in fp32.  fp32 output, optional residual.  Same layouts as the plain calls. */
+int showo_gemm_bf16x3(const uint16_t* A, const uint16_t* Alo, int lda, const uint16_t* W, const uint16_t* Wlo, int ldw,
+                      const float* bias, int bias_per_row, float* out, int ldo, const float* resid, int ldr, int M, int N,
+                      int K, void* stream);
+int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
+                         const float* resid, float* out, int B, int Hin, int Win, int Cin, int Cout, int mode, void* stream);
+/* fp32 -> (hi, lo) bf16 pair */
+int showo_split_f32_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
+
 /* fp32 -> bf16 cast (weight packing) */
 int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
@@ -119,10 +129,14 @@ int showo_mask_by_topk(const float* sel_prob, const int64_t* sampled, int64_t* c
 /* ---------------------------------------------------------------------------------------------
  * VQGAN building blocks (reference models/common_modules.py, channel-last activations)
  * ------------------------------------------------------------------------------------------- */
-/* GroupNorm(32, eps) statistics over x fp32 NHWC [B, HW, C]: stats double [B, 32, 2] = (sum, sumsq); zeroed inside. */
+/* GroupNorm(32, eps) statistics over x fp32 NHWC [B, HW, C]: stats double [B, 32, 2] = (sum, sumsq).
+ * Deterministic two-pass reduction (no atomics): `stats` must provide showo_gn_stats_doubles(B, HW) doubles
+ * ([B,32,2] result followed by per-block partials). */
+int showo_gn_stats_doubles(int B, int HW);
 int showo_gn_stats(const float* x, double* stats, int B, int HW, int C, void* stream);
-/* y bf16 NHWC = act((x - mean) * rstd * gamma + beta); act = swish if do_swish (common_modules.py:16-24). */
-int showo_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, uint16_t* y,
+/* y bf16 NHWC = act((x - mean) * rstd * gamma + beta); act = swish if do_swish (common_modules.py:16-24).
+ * ylo (optional): low half for split precision, ylo = bf16(value - float(y)). */
+int showo_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, uint16_t* y, uint16_t* ylo,
                    int B, int HW, int C, float eps, int do_swish, void* stream);
 /* 3x3 convolution as implicit GEMM on MFMA.  x bf16 NHWC [B,Hin,Win,Cin]; w bf16 [Cout][3][3][Cin];
  * out fp32 NHWC [B,Hout,Wout,Cout] = conv + bias (+ resid).  mode: 0 = stride 1 pad 1;
@@ -135,9 +149,9 @@ int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
 int showo_conv_small_f32(const float* x, const float* w, const float* bias, float* out, int B, int H, int W,
                          int Cin, int Cout, int ksize, void* stream);
 /* row softmax with scale: x fp32 [rows, n] -> y bf16 [rows, ldy] = softmax(x * scale) (AttnBlock, common_modules.py:199-201) */
-int showo_softmax_rows_bf16(const float* x, uint16_t* y, int rows, int n, int ldy, float scale, void* stream);
+int showo_softmax_rows_bf16(const float* x, uint16_t* y, uint16_t* ylo, int rows, int n, int ldy, float scale, void* stream);
 /* fp32 [P, C] -> bf16 [P, Cpad] with zero-padded channels (feeds the MFMA conv for the 3-/13-channel inputs) */
-int showo_pad_cast_bf16(const float* x, uint16_t* y, int64_t P, int C, int Cpad, void* stream);
+int showo_pad_cast_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t P, int C, int Cpad, void* stream);
 /* ids int64 [B, hw] -> z_q fp32 [B, hw, C] (channel-last form of get_codebook_entry) */
 int showo_lfq_unpack_nhwc(const int64_t* ids, float* zq, int B, int C, int hw, void* stream);
 /* layout changes at the image / latent boundary */
@@ -199,6 +213,7 @@ typedef struct {
     int enc_ch_mult[8], enc_blocks[8], enc_levels;
     int dec_ch_mult[8], dec_blocks[8], dec_levels;
     int max_batch, max_res; /* workspace sizing */
+    int precision;          /* 0 = bf16 operands; 1 = split (hi+lo) bf16 operands, fp32-class accuracy (default of MAGVITv2) */
 } showo_vq_config;
 int showo_vq_create(const showo_vq_config* cfg, showo_vq** out);
 void showo_vq_destroy(showo_vq* v);

@@ -66,38 +66,43 @@ TINY = dict(hidden=128, layers=2, heads=2, ffn=256, vocab=439, llm_vocab=300, co
             num_vq_tokens=16, max_text_len=8, max_pos=2048)
 
 
-def make_showo_state(d: ShowoDims, seed: int = 0, dtype=np.float32):
-    rs = np.random.RandomState(seed)
-    sd = OrderedDict()
-
-    def nrm(shape, std, mean=0.0):
-        return (rs.standard_normal(size=shape) * std + mean).astype(dtype)
-
+def showo_state_spec(d: ShowoDims):
+    """state-dict key -> (shape, std, mean) in the reference's parameter order (the RandomState draw order of
+    make_showo_state; the golden fixtures depend on it)."""
+    sp = OrderedDict()
     H, F = d.hidden, d.ffn
-    sd["showo.model.embed_tokens.weight"] = nrm((d.vocab, H), 0.02)
+    sp["showo.model.embed_tokens.weight"] = ((d.vocab, H), 0.02, 0.0)
     for i in range(d.layers):
         p = f"showo.model.layers.{i}."
         for n in ("q_proj", "k_proj", "v_proj", "dense"):
-            sd[p + f"self_attn.{n}.weight"] = nrm((H, H), 0.02)
-            sd[p + f"self_attn.{n}.bias"] = nrm((H,), 0.02)
+            sp[p + f"self_attn.{n}.weight"] = ((H, H), 0.02, 0.0)
+            sp[p + f"self_attn.{n}.bias"] = ((H,), 0.02, 0.0)
         for n in ("q_layernorm", "k_layernorm"):
-            sd[p + f"self_attn.{n}.weight"] = nrm((d.head_dim,), 0.1, 1.0)
-            sd[p + f"self_attn.{n}.bias"] = nrm((d.head_dim,), 0.05)
-        sd[p + "mlp.fc1.weight"] = nrm((F, H), 0.02)
-        sd[p + "mlp.fc1.bias"] = nrm((F,), 0.02)
-        sd[p + "mlp.fc2.weight"] = nrm((H, F), 0.02)
-        sd[p + "mlp.fc2.bias"] = nrm((H,), 0.02)
-        sd[p + "input_layernorm.weight"] = nrm((H,), 0.1, 1.0)
-        sd[p + "input_layernorm.bias"] = nrm((H,), 0.05)
-    sd["showo.model.final_layernorm.weight"] = nrm((H,), 0.1, 1.0)
-    sd["showo.model.final_layernorm.bias"] = nrm((H,), 0.05)
-    sd["showo.lm_head.weight"] = nrm((d.vocab, H), 0.02)
-    sd["showo.lm_head.bias"] = nrm((d.vocab,), 0.02)
+            sp[p + f"self_attn.{n}.weight"] = ((d.head_dim,), 0.1, 1.0)
+            sp[p + f"self_attn.{n}.bias"] = ((d.head_dim,), 0.05, 0.0)
+        sp[p + "mlp.fc1.weight"] = ((F, H), 0.02, 0.0)
+        sp[p + "mlp.fc1.bias"] = ((F,), 0.02, 0.0)
+        sp[p + "mlp.fc2.weight"] = ((H, F), 0.02, 0.0)
+        sp[p + "mlp.fc2.bias"] = ((H,), 0.02, 0.0)
+        sp[p + "input_layernorm.weight"] = ((H,), 0.1, 1.0)
+        sp[p + "input_layernorm.bias"] = ((H,), 0.05, 0.0)
+    sp["showo.model.final_layernorm.weight"] = ((H,), 0.1, 1.0)
+    sp["showo.model.final_layernorm.bias"] = ((H,), 0.05, 0.0)
+    sp["showo.lm_head.weight"] = ((d.vocab, H), 0.02, 0.0)
+    sp["showo.lm_head.bias"] = ((d.vocab,), 0.02, 0.0)
     if d.w_clip_vit:
-        sd["mm_projector.0.weight"] = nrm((2048, 1024), 0.02)
-        sd["mm_projector.0.bias"] = nrm((2048,), 0.02)
-        sd["mm_projector.2.weight"] = nrm((H, 2048), 0.02)
-        sd["mm_projector.2.bias"] = nrm((H,), 0.02)
+        sp["mm_projector.0.weight"] = ((2048, 1024), 0.02, 0.0)
+        sp["mm_projector.0.bias"] = ((2048,), 0.02, 0.0)
+        sp["mm_projector.2.weight"] = ((H, 2048), 0.02, 0.0)
+        sp["mm_projector.2.bias"] = ((H,), 0.02, 0.0)
+    return sp
+
+
+def make_showo_state(d: ShowoDims, seed: int = 0, dtype=np.float32):
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for k, (shape, std, mean) in showo_state_spec(d).items():
+        sd[k] = (rs.standard_normal(size=shape) * std + mean).astype(dtype)
     return sd
 
 

@@ -32,6 +32,9 @@ _PROTOS = {
     "showo_layernorm_f32_bf16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "showo_gemm_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_set_impl": [c_i],
+    "showo_gemm_bf16x3": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "showo_conv3x3_bf16x3": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "showo_cast_f32_bf16": [c_p, c_p, c_i64, c_p],
     "showo_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
@@ -40,11 +43,12 @@ _PROTOS = {
     "showo_cfg_softmax_sample": [c_p, c_p, c_i, c_f, c_p, c_i64, c_p, c_u64, c_u32, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_mask_by_topk": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_f, c_f, c_p, c_u64, c_u32, c_p, c_i, c_i, c_p],
     "showo_gn_stats": [c_p, c_p, c_i, c_i, c_i, c_p],
-    "showo_gn_apply": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
+    "showo_gn_stats_doubles": [c_i, c_i],
+    "showo_gn_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
     "showo_conv3x3_bf16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_conv_small_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
-    "showo_softmax_rows_bf16": [c_p, c_p, c_i, c_i, c_i, c_f, c_p],
-    "showo_pad_cast_bf16": [c_p, c_p, c_i64, c_i, c_i, c_p],
+    "showo_softmax_rows_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "showo_pad_cast_bf16": [c_p, c_p, c_p, c_i64, c_i, c_i, c_p],
     "showo_nchw_to_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_nhwc_to_nchw_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_argmax_f32": [c_p, c_i, c_p, c_p],
@@ -82,7 +86,7 @@ class VQConfig(C.Structure):
     _fields_ = [("ch", c_i), ("z_channels", c_i),
                 ("enc_ch_mult", c_i * 8), ("enc_blocks", c_i * 8), ("enc_levels", c_i),
                 ("dec_ch_mult", c_i * 8), ("dec_blocks", c_i * 8), ("dec_levels", c_i),
-                ("max_batch", c_i), ("max_res", c_i)]
+                ("max_batch", c_i), ("max_res", c_i), ("precision", c_i)]
 
 
 def build(force=False):

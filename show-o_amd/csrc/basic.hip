@@ -143,6 +143,26 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __rest
         d[j] = f2bf(s[j]);
     }
 }
+// split: x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+__global__ void split_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = s[i];
+        bf16_t h = f2bf(v);
+        hi[i] = h;
+        lo[i] = f2bf(v - bf2f(h));
+    }
+}
+extern "C" int showo_split_f32_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    split_f32_bf16_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, hi, lo, n);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
     if (n <= 0) return 0;
     if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 7)) return set_error_msg(1, "cast: src must be 16B and dst 8B aligned");
@@ -182,7 +202,8 @@ extern "C" int showo_embed_f32(const int64_t* ids, const float* table, float* x,
 }
 
 // row softmax (VQGAN AttnBlock): one wave per row; n <= a few thousand.
-__global__ void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int rows, int n, int ldy, float scale) {
+__global__ void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ ylo, int rows, int n,
+                                    int ldy, float scale) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
@@ -191,15 +212,24 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restr
     for (int i = lane; i < n; i += 64) m = fmaxf(m, xr[i] * scale);
     m = wave_max(m);
     float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += __expf(xr[i] * scale - m);
+    for (int i = lane; i < n; i += 64) s += expf(xr[i] * scale - m);
     s = wave_sum(s);
     float inv = 1.0f / s;
-    for (int i = lane; i < n; i += 64) y[(int64_t)r * ldy + i] = f2bf(__expf(xr[i] * scale - m) * inv);
-    for (int i = n + lane; i < ldy; i += 64) y[(int64_t)r * ldy + i] = 0;
+    for (int i = lane; i < n; i += 64) {
+        float p = expf(xr[i] * scale - m) * inv;
+        bf16_t h = f2bf(p);
+        y[(int64_t)r * ldy + i] = h;
+        if (ylo) ylo[(int64_t)r * ldy + i] = f2bf(p - bf2f(h));
+    }
+    for (int i = n + lane; i < ldy; i += 64) {
+        y[(int64_t)r * ldy + i] = 0;
+        if (ylo) ylo[(int64_t)r * ldy + i] = 0;
+    }
 }
-extern "C" int showo_softmax_rows_bf16(const float* x, uint16_t* y, int rows, int n, int ldy, float scale, void* stream) {
+extern "C" int showo_softmax_rows_bf16(const float* x, uint16_t* y, uint16_t* ylo, int rows, int n, int ldy, float scale,
+                                       void* stream) {
     if (rows <= 0) return 0;
-    softmax_rows_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, y, rows, n, ldy, scale);
+    softmax_rows_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, y, ylo, rows, n, ldy, scale);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

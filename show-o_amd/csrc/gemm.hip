@@ -29,6 +29,7 @@ constexpr int LDS_TILE = 128 * 64;  // bf16 elements per operand tile
 struct GemmArgs {
     const bf16_t* A; int lda;
     const bf16_t* W; int ldw;
+    const bf16_t* Wlo;  // split-precision mode: low halves of the weights (same layout as W)
     const float* bias; int bias_per_row;
     void* out; int ldo;
     const float* resid; int ldr;
@@ -38,19 +39,24 @@ struct GemmArgs {
 
 struct ConvArgs {
     const bf16_t* X;   // NHWC bf16 input
+    const bf16_t* Xlo; // split-precision mode: low halves (same layout)
     int B, Hin, Win, Cin, Hout, Wout, mode;
 };
 
 // ---- activation-operand loaders: setup(i, m) once per staged row, load(i, k) per k-tile -> 16-B chunk
 struct LinearLoader {
     const bf16_t* A; int lda; int M;
+    const bf16_t* Alo;
     const bf16_t* rowp[4];
+    int64_t lo_delta;  // element offset from the hi to the lo operand (same layout)
     __device__ inline void setup(int i, int m) {
         int mm = m < M ? m : M - 1;
         rowp[i] = A + (int64_t)mm * lda;
+        lo_delta = Alo ? (Alo - A) : 0;
     }
     __device__ inline void tile(int) {}
     __device__ inline uint4 load(int i, int k) const { return *reinterpret_cast<const uint4*>(rowp[i] + k); }
+    __device__ inline uint4 load_lo(int i, int k) const { return *reinterpret_cast<const uint4*>(rowp[i] + lo_delta + k); }
 };
 
 struct ConvLoader {
@@ -74,7 +80,8 @@ struct ConvLoader {
         ky = tap / 3;
         kx = tap - ky * 3;
     }
-    __device__ inline uint4 load(int i, int k) const {
+    template <bool LO>
+    __device__ inline uint4 load_t(int i, int k) const {
         int iy, ix;
         bool ok;
         if (c.mode == 2) {  // pad (0,1,0,1) then stride 2 (common_modules.py:83-88)
@@ -90,8 +97,10 @@ struct ConvLoader {
         }
         if (!ok) return make_uint4(0, 0, 0, 0);
         // k & 63 = this thread's chunk offset inside the tile
-        return *reinterpret_cast<const uint4*>(img[i] + ((int64_t)iy * c.Win + ix) * c.Cin + cbase + (k & 63));
+        return *reinterpret_cast<const uint4*>(img[i] + (LO ? (c.Xlo - c.X) : 0) + ((int64_t)iy * c.Win + ix) * c.Cin + cbase + (k & 63));
     }
+    __device__ inline uint4 load(int i, int k) const { return load_t<false>(i, k); }
+    __device__ inline uint4 load_lo(int i, int k) const { return load_t<true>(i, k); }
 };
 
 __device__ inline float gelu_new_fast(float x) {
@@ -157,12 +166,17 @@ __device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, int m, in
     }
 }
 
-template <int EPI, class Loader>
+// SPLIT: both operands come as (hi, lo) bf16 pairs with x = hi + lo to ~2^-17; the product is accumulated as
+// hi*hi + hi*lo + lo*hi in the fp32 MFMA accumulators (3 MFMAs per tile pair, ~fp32-class accuracy at 3/16 of the
+// fp32-MFMA cost).  Used by the VQGAN path, whose token ids must track the fp32 reference (SURVEY.md §7 hard parts).
+template <int EPI, class Loader, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
     Loader ld = ld_in;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);          // [2][128*64]
     bf16_t* sA = sW + 2 * LDS_TILE;                              // [2][128*64]
+    bf16_t* sWl = sA + 2 * LDS_TILE;                             // SPLIT only
+    bf16_t* sAl = sWl + 2 * LDS_TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
@@ -177,8 +191,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
 
     // staging assignment: thread -> chunk c (16 B) of rows r0 + 32*i
     const int sc = tid & 7, sr0 = tid >> 3;
-    uint4 ra[4], rw[4];
+    uint4 ra[4], rw[4], ral[SPLIT ? 4 : 1], rwl[SPLIT ? 4 : 1];
     const int nk = g.K / BK;
+    const int64_t wlo_delta = SPLIT ? (g.Wlo - g.W) : 0;
 
     const bf16_t* wrow[4];
 #pragma unroll
@@ -196,6 +211,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
         for (int i = 0; i < 4; ++i) {
             rw[i] = *reinterpret_cast<const uint4*>(wrow[i] + k);
             ra[i] = ld.load(i, k);
+            if (SPLIT) {
+                rwl[i] = *reinterpret_cast<const uint4*>(wrow[i] + wlo_delta + k);
+                ral[i] = ld.load_lo(i, k);
+            }
         }
     };
     auto swrite = [&](int buf) {
@@ -205,6 +224,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
             int off = row * 64 + ((sc ^ (row & 7)) << 3);
             *reinterpret_cast<uint4*>(sW + buf * LDS_TILE + off) = rw[i];
             *reinterpret_cast<uint4*>(sA + buf * LDS_TILE + off) = ra[i];
+            if (SPLIT) {
+                *reinterpret_cast<uint4*>(sWl + buf * LDS_TILE + off) = rwl[i];
+                *reinterpret_cast<uint4*>(sAl + buf * LDS_TILE + off) = ral[i];
+            }
         }
     };
 
@@ -245,6 +268,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            if (SPLIT) {
+                const bf16_t* bWl = sWl + cur * LDS_TILE;
+                const bf16_t* bAl = sAl + cur * LDS_TILE;
+                bf16x8 lf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // hi(W) * lo(A)
+                    int row = wm * 64 + j * 16 + fr;
+                    lf[j] = *reinterpret_cast<const bf16x8*>(bAl + row * 64 + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], lf[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // lo(W) * hi(A)
+                    int row = wn * 64 + i * 16 + fr;
+                    lf[i] = *reinterpret_cast<const bf16x8*>(bWl + row * 64 + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf[i], af[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (kt + 1 < nk) swrite(cur ^ 1);
         __syncthreads();
@@ -263,17 +311,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
 
 constexpr int SMEM_BYTES = 4 * LDS_TILE * 2;  // 64 KiB
 
-template <int EPI, class Loader>
+template <int EPI, class Loader, bool SPLIT = false>
 int launch(const GemmArgs& g, const Loader& ld, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm_kernel<EPI, Loader>;
+    auto kfn = gemm_kernel<EPI, Loader, SPLIT>;
+    const int smem = SPLIT ? 2 * SMEM_BYTES : SMEM_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm)", __FILE__, __LINE__);
         attr_set = true;
     }
     int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    kfn<<<dim3(tilesM * tilesN), dim3(256), SMEM_BYTES, s>>>(g, ld);
+    kfn<<<dim3(tilesM * tilesN), dim3(256), smem, s>>>(g, ld);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "gemm launch", __FILE__, __LINE__);
     return 0;
@@ -288,6 +337,15 @@ int dispatch(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) {
         case SHOWO_EPI_RESID_F32: return launch<SHOWO_EPI_RESID_F32>(g, ld, s);
     }
     return set_error_msg(1, "gemm: unknown epilogue");
+}
+
+template <class Loader>
+int dispatch_split(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case SHOWO_EPI_F32: return launch<SHOWO_EPI_F32, Loader, true>(g, ld, s);
+        case SHOWO_EPI_RESID_F32: return launch<SHOWO_EPI_RESID_F32, Loader, true>(g, ld, s);
+    }
+    return set_error_msg(1, "gemm x3: only fp32 epilogues (2, 3) are supported");
 }
 
 
@@ -502,14 +560,14 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
         return set_error_msg(1, "gemm: A/W must be 16B aligned with lda,ldw multiples of 8");
     if (epilogue == SHOWO_EPI_RESID_F32 && !resid) return set_error_msg(1, "gemm: resid required");
     GemmArgs g;
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.bias_per_row = bias_per_row;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.Wlo = nullptr; g.bias = bias; g.bias_per_row = bias_per_row;
     g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
     bool f32 = (epilogue == SHOWO_EPI_F32 || epilogue == SHOWO_EPI_RESID_F32);
     uintptr_t align = f32 ? 15 : 7;
     g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & align) == 0);
     if (epilogue == SHOWO_EPI_RESID_F32) g.vec_out = g.vec_out && ((ldr % 4) == 0) && ((((uintptr_t)resid) & 15) == 0);
     LinearLoader ld;
-    ld.A = A; ld.lda = lda; ld.M = M;
+    ld.A = A; ld.lda = lda; ld.M = M; ld.Alo = nullptr;
     ProfScope prof(PROF_GEMM, 2.0 * M * N * K, (hipStream_t)stream);
     if (gemm_impl_choice(M, N) == 2) {
         LinearPtr lp;
@@ -525,12 +583,12 @@ extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const fl
     if (Cin % 64) return set_error_msg(1, "conv3x3: Cin % 64 == 0 required (pad thin inputs to 64 channels)");
     if (mode < 0 || mode > 2) return set_error_msg(1, "conv3x3: bad mode");
     ConvArgs c;
-    c.X = x; c.B = B; c.Hin = Hin; c.Win = Win; c.Cin = Cin; c.mode = mode;
+    c.X = x; c.Xlo = nullptr; c.B = B; c.Hin = Hin; c.Win = Win; c.Cin = Cin; c.mode = mode;
     if (mode == 1) { c.Hout = Hin * 2; c.Wout = Win * 2; }
     else if (mode == 2) { c.Hout = Hin / 2; c.Wout = Win / 2; }
     else { c.Hout = Hin; c.Wout = Win; }
     GemmArgs g;
-    g.A = nullptr; g.lda = 0; g.W = w; g.ldw = 9 * Cin; g.bias = bias; g.bias_per_row = 0;
+    g.A = nullptr; g.lda = 0; g.W = w; g.ldw = 9 * Cin; g.Wlo = nullptr; g.bias = bias; g.bias_per_row = 0;
     g.out = out; g.ldo = Cout; g.resid = resid; g.ldr = Cout;
     g.M = B * c.Hout * c.Wout; g.N = Cout; g.K = 9 * Cin;
     g.vec_out = ((Cout % 4) == 0) && ((((uintptr_t)out) & 15) == 0) && (!resid || (((uintptr_t)resid) & 15) == 0);
@@ -544,4 +602,47 @@ extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const fl
         return dispatch2(g, cp, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
     }
     return dispatch(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
+}
+
+// ---- split-precision entry points (operands as hi/lo bf16 pairs, fp32 output) -----------------------------
+extern "C" int showo_gemm_bf16x3(const uint16_t* A, const uint16_t* Alo, int lda, const uint16_t* W, const uint16_t* Wlo, int ldw,
+                                 const float* bias, int bias_per_row, float* out, int ldo, const float* resid, int ldr, int M,
+                                 int N, int K, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K % BK) != 0) return set_error_msg(1, "gemm x3: K must be a positive multiple of 64");
+    if (!Alo || !Wlo) return set_error_msg(1, "gemm x3: lo operands required");
+    if ((lda % 8) || (ldw % 8) || (((uintptr_t)A) & 15) || (((uintptr_t)W) & 15) || (((uintptr_t)Alo) & 15) || (((uintptr_t)Wlo) & 15))
+        return set_error_msg(1, "gemm x3: operands must be 16B aligned with lda,ldw multiples of 8");
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.Wlo = Wlo; g.bias = bias; g.bias_per_row = bias_per_row;
+    g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+    g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & 15) == 0);
+    if (resid) g.vec_out = g.vec_out && ((ldr % 4) == 0) && ((((uintptr_t)resid) & 15) == 0);
+    LinearLoader ld;
+    ld.A = A; ld.lda = lda; ld.M = M; ld.Alo = Alo;
+    ProfScope prof(PROF_GEMM, 6.0 * M * N * K, (hipStream_t)stream);
+    return dispatch_split(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
+}
+
+extern "C" int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
+                                    const float* resid, float* out, int B, int Hin, int Win, int Cin, int Cout, int mode,
+                                    void* stream) {
+    if (B <= 0) return 0;
+    if (Cin % 64) return set_error_msg(1, "conv3x3 x3: Cin % 64 == 0 required");
+    if (mode < 0 || mode > 2) return set_error_msg(1, "conv3x3 x3: bad mode");
+    if (!xlo || !wlo) return set_error_msg(1, "conv3x3 x3: lo operands required");
+    ConvArgs c;
+    c.X = x; c.Xlo = xlo; c.B = B; c.Hin = Hin; c.Win = Win; c.Cin = Cin; c.mode = mode;
+    if (mode == 1) { c.Hout = Hin * 2; c.Wout = Win * 2; }
+    else if (mode == 2) { c.Hout = Hin / 2; c.Wout = Win / 2; }
+    else { c.Hout = Hin; c.Wout = Win; }
+    GemmArgs g;
+    g.A = nullptr; g.lda = 0; g.W = w; g.ldw = 9 * Cin; g.Wlo = wlo; g.bias = bias; g.bias_per_row = 0;
+    g.out = out; g.ldo = Cout; g.resid = resid; g.ldr = Cout;
+    g.M = B * c.Hout * c.Wout; g.N = Cout; g.K = 9 * Cin;
+    g.vec_out = ((Cout % 4) == 0) && ((((uintptr_t)out) & 15) == 0) && (!resid || (((uintptr_t)resid) & 15) == 0);
+    ConvLoader ld;
+    ld.c = c; ld.M = g.M;
+    ProfScope prof(PROF_CONV, 2.0 * g.M * Cout * 9.0 * Cin, (hipStream_t)stream);
+    return dispatch_split(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
 }

@@ -16,8 +16,9 @@
 
 using namespace showo;
 
-extern "C" int showo_pad_cast_bf16(const float* x, uint16_t* y, int64_t P, int C, int Cpad, void* stream);
-extern "C" int showo_lfq_unpack_nhwc(const int64_t* ids, float* zq, int B, int C, int hw, void* stream);
+// Precision (showo_vq_config.precision): 0 = bf16 MFMA operands; 1 (the default of the Python class) = every MFMA
+// operand is a (hi, lo) bf16 pair and each product is hi*hi + hi*lo + lo*hi in the fp32 accumulators, which tracks
+// the reference's fp32 convolutions to ~1e-5 so that the sign-test token ids agree with it.
 
 namespace {
 
@@ -27,12 +28,13 @@ struct Tensor {
     Kind kind;
     int cout = 0, cin = 0, cin_pad = 0, ks = 1;
     void* data = nullptr;  // bf16 for CONV3/CONV1, fp32 otherwise
+    bf16_t* lo = nullptr;  // split precision: low halves of a CONV3/CONV1 weight
     bool loaded = false;
 };
 
 // src fp32 [Cout, Cin, ks, ks] -> dst bf16 [Cout][ks][ks][Cin_pad]
-__global__ void repack_conv_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int Cout, int Cin, int Cpad, int ks,
-                                   int64_t total) {
+__global__ void repack_conv_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, bf16_t* __restrict__ dlo, int Cout,
+                                   int Cin, int Cpad, int ks, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int ci = (int)(i % Cpad);
@@ -41,7 +43,10 @@ __global__ void repack_conv_kernel(const float* __restrict__ src, bf16_t* __rest
     t /= ks;
     int ky = (int)(t % ks);
     int co = (int)(t / ks);
-    dst[i] = (ci < Cin) ? f2bf(src[(((int64_t)co * Cin + ci) * ks + ky) * ks + kx]) : (bf16_t)0;
+    float v = (ci < Cin) ? src[(((int64_t)co * Cin + ci) * ks + ky) * ks + kx] : 0.f;
+    bf16_t h = f2bf(v);
+    dst[i] = h;
+    if (dlo) dlo[i] = f2bf(v - bf2f(h));
 }
 // src fp32 [Cout, Cin, ks, ks] -> dst fp32 [Cout][ks][ks][Cin]
 __global__ void repack_small_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int ks, int64_t total) {
@@ -70,10 +75,12 @@ struct showo_vq {
     std::vector<void*> allocs;
     int64_t act_elems = 0;  // capacity of each activation buffer (elements)
     float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;
-    bf16_t *b0 = nullptr, *b1 = nullptr;
+    bf16_t *b0 = nullptr, *b1 = nullptr, *b0l = nullptr, *b1l = nullptr;  // *l: low halves (split precision only)
     double* stats = nullptr;
+    bool split = false;
     // attention scratch
     bf16_t *aq = nullptr, *ak = nullptr, *avt = nullptr, *ap = nullptr, *ao = nullptr;
+    bf16_t *aql = nullptr, *akl = nullptr, *avtl = nullptr, *apl = nullptr, *aol = nullptr;
     float* as = nullptr;
     int attn_hw = 0;
     float *zbuf = nullptr, *zbuf2 = nullptr;
@@ -116,6 +123,7 @@ struct showo_vq {
         for (const char* n : {"q", "k", "v", "proj_out"}) add_conv(p + "." + n, c, c, 1);
     }
     const bf16_t* W(const std::string& k) { return (const bf16_t*)t[k + ".weight"].data; }
+    const bf16_t* Wl(const std::string& k) { return t[k + ".weight"].lo; }
     const float* Wf(const std::string& k) { return (const float*)t[k + ".weight"].data; }
     const float* Bv(const std::string& k) { return (const float*)t[k + ".bias"].data; }
     bool has(const std::string& k) { return t.count(k) != 0; }
@@ -124,8 +132,10 @@ struct showo_vq {
 extern "C" int showo_vq_create(const showo_vq_config* c, showo_vq** out) {
     if (!c || !out) return set_error_msg(1, "vq_create: null argument");
     if (c->ch % 128) return set_error_msg(1, "vq: ch must be a multiple of 128 (GroupNorm/MFMA tiling)");
+    if (c->precision != 0 && c->precision != 1) return set_error_msg(1, "vq: precision must be 0 (bf16) or 1 (split bf16)");
     showo_vq* v = new showo_vq();
     v->cfg = *c;
+    v->split = c->precision == 1;
     const int ch = c->ch, zc = c->z_channels;
     // ---- encoder tensors (reference modeling_magvitv2.py:62-139)
     v->add_conv("encoder.conv_in", ch, 3, 3);
@@ -171,6 +181,7 @@ extern "C" int showo_vq_create(const showo_vq_config* c, showo_vq** out) {
             bf16_t* p = nullptr;
             rc |= v->alloc(&p, (int64_t)w.cout * w.ks * w.ks * w.cin_pad);
             w.data = p;
+            if (v->split) rc |= v->alloc(&w.lo, (int64_t)w.cout * w.ks * w.ks * w.cin_pad);
         } else if (w.kind == K_SMALL) {
             float* p = nullptr;
             rc |= v->alloc(&p, (int64_t)w.cout * w.ks * w.ks * w.cin);
@@ -187,7 +198,8 @@ extern "C" int showo_vq_create(const showo_vq_config* c, showo_vq** out) {
     v->act_elems = (int64_t)c->max_batch * R * R * top;
     rc |= v->alloc(&v->f0, v->act_elems); rc |= v->alloc(&v->f1, v->act_elems); rc |= v->alloc(&v->f2, v->act_elems);
     rc |= v->alloc(&v->b0, v->act_elems); rc |= v->alloc(&v->b1, v->act_elems);
-    rc |= v->alloc(&v->stats, (int64_t)c->max_batch * 64);
+    if (v->split) { rc |= v->alloc(&v->b0l, v->act_elems); rc |= v->alloc(&v->b1l, v->act_elems); }
+    rc |= v->alloc(&v->stats, (int64_t)showo_gn_stats_doubles(c->max_batch, (int)(R * R)));
     int levels = c->enc_levels > c->dec_levels ? c->enc_levels : c->dec_levels;
     int lat = (int)(R >> (levels - 1));
     int hw = lat * lat, hwp = ((hw + 63) / 64) * 64;
@@ -197,8 +209,12 @@ extern "C" int showo_vq_create(const showo_vq_config* c, showo_vq** out) {
     rc |= v->alloc(&v->avt, (int64_t)max_c * hwp); rc |= v->alloc(&v->ap, (int64_t)hw * hwp);
     rc |= v->alloc(&v->as, (int64_t)hw * hw);
     rc |= v->alloc(&v->zbuf, BP * 64); rc |= v->alloc(&v->zbuf2, BP * 64);
+    if (v->split) {
+        rc |= v->alloc(&v->aql, BP * max_c); rc |= v->alloc(&v->akl, BP * max_c); rc |= v->alloc(&v->aol, BP * max_c);
+        rc |= v->alloc(&v->avtl, (int64_t)max_c * hwp); rc |= v->alloc(&v->apl, (int64_t)hw * hwp);
+    }
     if (rc) { showo_vq_destroy(v); return rc; }
-    hipMemset(v->avt, 0, (size_t)max_c * hwp * sizeof(bf16_t));
+    if ((int64_t)max_c * hwp > v->act_elems) { showo_vq_destroy(v); return set_error_msg(5, "vq: workspace too small for the attention block"); }
     *out = v;
     return 0;
 }
@@ -234,7 +250,7 @@ extern "C" int showo_vq_load(showo_vq* v, const char* key, const float* src, int
             repack_small_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(src, (float*)w.data, w.cout, w.cin, w.ks, total);
         } else {
             int64_t total = (int64_t)w.cout * w.ks * w.ks * w.cin_pad;
-            repack_conv_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(src, (bf16_t*)w.data, w.cout, w.cin,
+            repack_conv_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(src, (bf16_t*)w.data, w.lo, w.cout, w.cin,
                                                                                            w.cin_pad, w.ks, total);
         }
         SHOWO_CHECK_HIP(hipGetLastError());
@@ -253,52 +269,83 @@ struct Ctx {
     float *cur, *t1, *t2;  // fp32 activation buffers (cur holds the running activation)
 };
 
-int gn(Ctx& c, const float* x, const std::string& name, bf16_t* y, int HW, int C, int swish) {
+// fp32 -> MFMA operand image: bf16, or the (hi, lo) pair in split precision
+int to_operand(Ctx& c, const float* src, bf16_t* hi, bf16_t* lo, int64_t n) {
+    if (c.v->split) return showo_split_f32_bf16(src, hi, lo, n, c.s);
+    return showo_cast_f32_bf16(src, hi, n, c.s);
+}
+
+int gn(Ctx& c, const float* x, const std::string& name, bf16_t* y, bf16_t* ylo, int HW, int C, int swish) {
     TRY(showo_gn_stats(x, c.v->stats, c.B, HW, C, c.s));
-    return showo_gn_apply(x, c.v->stats, c.v->Wf(name), c.v->Bv(name), y, c.B, HW, C, 1e-6f, swish, c.s);
+    return showo_gn_apply(x, c.v->stats, c.v->Wf(name), c.v->Bv(name), y, c.v->split ? ylo : nullptr, c.B, HW, C, 1e-6f, swish,
+                          c.s);
+}
+
+// 3x3 conv `name` on the operand image (x, xlo): out fp32 = conv + bias (+ resid)
+int conv3(Ctx& c, const bf16_t* x, const bf16_t* xlo, const std::string& name, const float* resid, float* out, int H, int W, int cin,
+          int cout, int mode) {
+    showo_vq* v = c.v;
+    if (v->split)
+        return showo_conv3x3_bf16x3(x, xlo, v->W(name), v->Wl(name), v->Bv(name), resid, out, c.B, H, W, cin, cout, mode, c.s);
+    return showo_conv3x3_bf16(x, v->W(name), v->Bv(name), resid, out, c.B, H, W, cin, cout, mode, c.s);
+}
+
+// out fp32 [M,N] (ldo) = A[M,K] * W[N,K]^T (+ bias) (+ resid); operands as images (hi, lo)
+int gemm32(Ctx& c, const bf16_t* A, const bf16_t* Alo, int lda, const bf16_t* W, const bf16_t* Wlo, int ldw, const float* bias,
+           int bias_per_row, float* out, int ldo, const float* resid, int M, int N, int K) {
+    if (c.v->split) return showo_gemm_bf16x3(A, Alo, lda, W, Wlo, ldw, bias, bias_per_row, out, ldo, resid, ldo, M, N, K, c.s);
+    return showo_gemm_bf16(A, lda, W, ldw, bias, bias_per_row, out, ldo, resid, ldo, M, N, K,
+                           resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, c.s);
 }
 
 // ResnetBlock.forward, temb=None (common_modules.py:337-357)
 int resblock(Ctx& c, const std::string& p, int cin, int cout, int H, int W) {
     showo_vq* v = c.v;
     const int HW = H * W;
-    TRY(gn(c, c.cur, p + ".norm1", v->b0, HW, cin, 1));
-    TRY(showo_conv3x3_bf16(v->b0, v->W(p + ".conv1"), v->Bv(p + ".conv1"), nullptr, c.t1, c.B, H, W, cin, cout, 0, c.s));
-    TRY(gn(c, c.t1, p + ".norm2", v->b0, HW, cout, 1));
+    TRY(gn(c, c.cur, p + ".norm1", v->b0, v->b0l, HW, cin, 1));
+    TRY(conv3(c, v->b0, v->b0l, p + ".conv1", nullptr, c.t1, H, W, cin, cout, 0));
+    TRY(gn(c, c.t1, p + ".norm2", v->b0, v->b0l, HW, cout, 1));
     if (cin != cout) {
-        TRY(showo_cast_f32_bf16(c.cur, v->b1, (int64_t)c.B * HW * cin, c.s));
-        TRY(showo_gemm_bf16(v->b1, cin, v->W(p + ".nin_shortcut"), cin, v->Bv(p + ".nin_shortcut"), 0, c.t2, cout, nullptr, 0,
-                            c.B * HW, cout, cin, SHOWO_EPI_F32, c.s));
-        TRY(showo_conv3x3_bf16(v->b0, v->W(p + ".conv2"), v->Bv(p + ".conv2"), c.t2, c.t2, c.B, H, W, cout, cout, 0, c.s));
+        TRY(to_operand(c, c.cur, v->b1, v->b1l, (int64_t)c.B * HW * cin));
+        TRY(gemm32(c, v->b1, v->b1l, cin, v->W(p + ".nin_shortcut"), v->Wl(p + ".nin_shortcut"), cin, v->Bv(p + ".nin_shortcut"), 0,
+                   c.t2, cout, nullptr, c.B * HW, cout, cin));
+        TRY(conv3(c, v->b0, v->b0l, p + ".conv2", c.t2, c.t2, H, W, cout, cout, 0));
         std::swap(c.cur, c.t2);
     } else {
-        TRY(showo_conv3x3_bf16(v->b0, v->W(p + ".conv2"), v->Bv(p + ".conv2"), c.cur, c.cur, c.B, H, W, cout, cout, 0, c.s));
+        TRY(conv3(c, v->b0, v->b0l, p + ".conv2", c.cur, c.cur, H, W, cout, cout, 0));
     }
     return 0;
 }
 
-// AttnBlock.forward (common_modules.py:187-211): single head over H*W positions, scale C^-0.5
+// AttnBlock.forward (common_modules.py:187-211): single head over H*W positions, scale C^-0.5.
+// Every product goes through the fp32-output GEMM and is re-imaged as an MFMA operand (the block runs at the
+// 16x16 / 32x32 latent resolution, so the extra passes are noise).
 int attnblock(Ctx& c, const std::string& p, int C, int H, int W) {
     showo_vq* v = c.v;
     const int hw = H * W, hwp = ((hw + 63) / 64) * 64;
     if (hw > v->attn_hw) return set_error_msg(5, "vq: attention resolution exceeds the configured workspace");
     const int BP = c.B * hw;
-    TRY(gn(c, c.cur, p + ".norm", v->b0, hw, C, 0));
-    TRY(showo_gemm_bf16(v->b0, C, v->W(p + ".q"), C, v->Bv(p + ".q"), 0, v->aq, C, nullptr, 0, BP, C, C, SHOWO_EPI_BF16, c.s));
-    TRY(showo_gemm_bf16(v->b0, C, v->W(p + ".k"), C, v->Bv(p + ".k"), 0, v->ak, C, nullptr, 0, BP, C, C, SHOWO_EPI_BF16, c.s));
+    TRY(gn(c, c.cur, p + ".norm", v->b0, v->b0l, hw, C, 0));
+    TRY(gemm32(c, v->b0, v->b0l, C, v->W(p + ".q"), v->Wl(p + ".q"), C, v->Bv(p + ".q"), 0, c.t1, C, nullptr, BP, C, C));
+    TRY(to_operand(c, c.t1, v->aq, v->aql, (int64_t)BP * C));
+    TRY(gemm32(c, v->b0, v->b0l, C, v->W(p + ".k"), v->Wl(p + ".k"), C, v->Bv(p + ".k"), 0, c.t1, C, nullptr, BP, C, C));
+    TRY(to_operand(c, c.t1, v->ak, v->akl, (int64_t)BP * C));
     const float scale = 1.0f / sqrtf((float)C);
     for (int b = 0; b < c.B; ++b) {
-        const bf16_t* hb = v->b0 + (int64_t)b * hw * C;
+        const int64_t ob = (int64_t)b * hw * C;
         // v^T[c][p] = sum_ci Wv[c][ci] h[p][ci] + bv[c]  (the GEMM "activation" is the weight matrix here)
-        TRY(showo_gemm_bf16(v->W(p + ".v"), C, hb, C, v->Bv(p + ".v"), 1, v->avt, hwp, nullptr, 0, C, hw, C, SHOWO_EPI_BF16, c.s));
-        TRY(showo_gemm_bf16(v->aq + (int64_t)b * hw * C, C, v->ak + (int64_t)b * hw * C, C, nullptr, 0, v->as, hw, nullptr, 0, hw,
-                            hw, C, SHOWO_EPI_F32, c.s));
-        TRY(showo_softmax_rows_bf16(v->as, v->ap, hw, hw, hwp, scale, c.s));
-        TRY(showo_gemm_bf16(v->ap, hwp, v->avt, hwp, nullptr, 0, v->ao + (int64_t)b * hw * C, C, nullptr, 0, hw, C, hwp,
-                            SHOWO_EPI_BF16, c.s));
+        SHOWO_CHECK_HIP(hipMemsetAsync(c.t1, 0, (size_t)C * hwp * sizeof(float), c.s));  // key padding columns stay 0
+        TRY(gemm32(c, v->W(p + ".v"), v->Wl(p + ".v"), C, v->b0 + ob, v->split ? v->b0l + ob : nullptr, C, v->Bv(p + ".v"), 1, c.t1,
+                   hwp, nullptr, C, hw, C));
+        TRY(to_operand(c, c.t1, v->avt, v->avtl, (int64_t)C * hwp));
+        TRY(gemm32(c, v->aq + ob, v->split ? v->aql + ob : nullptr, C, v->ak + ob, v->split ? v->akl + ob : nullptr, C, nullptr, 0,
+                   v->as, hw, nullptr, hw, hw, C));
+        TRY(showo_softmax_rows_bf16(v->as, v->ap, v->split ? v->apl : nullptr, hw, hw, hwp, scale, c.s));
+        TRY(gemm32(c, v->ap, v->apl, hwp, v->avt, v->avtl, hwp, nullptr, 0, c.t2, C, nullptr, hw, C, hwp));
+        TRY(to_operand(c, c.t2, v->ao + ob, v->split ? v->aol + ob : nullptr, (int64_t)hw * C));
     }
-    return showo_gemm_bf16(v->ao, C, v->W(p + ".proj_out"), C, v->Bv(p + ".proj_out"), 0, c.cur, C, c.cur, C, BP, C, C,
-                           SHOWO_EPI_RESID_F32, c.s);
+    return gemm32(c, v->ao, v->aol, C, v->W(p + ".proj_out"), v->Wl(p + ".proj_out"), C, v->Bv(p + ".proj_out"), 0, c.cur, C, c.cur,
+                  BP, C, C);
 }
 
 int check_vq(showo_vq* v, int B, int H, int W) {
@@ -313,6 +360,7 @@ int check_vq(showo_vq* v, int B, int H, int W) {
 
 extern "C" int showo_vq_decode_code(showo_vq* v, const int64_t* ids, int B, int h, int w, float* image, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (!v) return set_error_msg(1, "vq: null handle");
     const showo_vq_config& cf = v->cfg;
     const int up = 1 << (cf.dec_levels - 1);
     TRY(check_vq(v, B, h * up, w * up));
@@ -322,9 +370,9 @@ extern "C" int showo_vq_decode_code(showo_vq* v, const int64_t* ids, int B, int 
     // get_codebook_entry -> post_quant_conv (1x1, fp32) -> conv_in (modeling_magvitv2.py:208-221, 371-374)
     TRY(showo_lfq_unpack_nhwc(ids, v->zbuf, B, zc, h * w, s));
     TRY(showo_conv_small_f32(v->zbuf, v->Wf("decoder.post_quant_conv"), v->Bv("decoder.post_quant_conv"), v->zbuf2, B, H, W, zc, zc, 1, s));
-    TRY(showo_pad_cast_bf16(v->zbuf2, v->b0, (int64_t)B * H * W, zc, 64, s));
+    TRY(showo_pad_cast_bf16(v->zbuf2, v->b0, v->split ? v->b0l : nullptr, (int64_t)B * H * W, zc, 64, s));
     int block_in = ch * cf.dec_ch_mult[cf.dec_levels - 1];
-    TRY(showo_conv3x3_bf16(v->b0, v->W("decoder.conv_in"), v->Bv("decoder.conv_in"), nullptr, c.cur, B, H, W, 64, block_in, 0, s));
+    TRY(conv3(c, v->b0, v->b0l, "decoder.conv_in", nullptr, c.cur, H, W, 64, block_in, 0));
     TRY(resblock(c, "decoder.mid.block_1", block_in, block_in, H, W));
     TRY(attnblock(c, "decoder.mid.attn_1", block_in, H, W));
     TRY(resblock(c, "decoder.mid.block_2", block_in, block_in, H, W));
@@ -336,19 +384,20 @@ extern "C" int showo_vq_decode_code(showo_vq* v, const int64_t* ids, int B, int 
         }
         if (l != 0) {  // nearest 2x + conv (common_modules.py:36-40), fused into the conv's gather
             std::string n = "decoder.up." + std::to_string(l) + ".upsample.conv";
-            TRY(showo_cast_f32_bf16(c.cur, v->b1, (int64_t)B * H * W * block_in, s));
-            TRY(showo_conv3x3_bf16(v->b1, v->W(n), v->Bv(n), nullptr, c.t1, B, H, W, block_in, block_in, 1, s));
+            TRY(to_operand(c, c.cur, v->b1, v->b1l, (int64_t)B * H * W * block_in));
+            TRY(conv3(c, v->b1, v->b1l, n, nullptr, c.t1, H, W, block_in, block_in, 1));
             std::swap(c.cur, c.t1);
             H *= 2; W *= 2;
         }
     }
-    TRY(gn(c, c.cur, "decoder.norm_out", v->b0, H * W, block_in, 1));
-    TRY(showo_conv3x3_bf16(v->b0, v->W("decoder.conv_out"), v->Bv("decoder.conv_out"), nullptr, c.t1, B, H, W, block_in, 3, 0, s));
+    TRY(gn(c, c.cur, "decoder.norm_out", v->b0, v->b0l, H * W, block_in, 1));
+    TRY(conv3(c, v->b0, v->b0l, "decoder.conv_out", nullptr, c.t1, H, W, block_in, 3, 0));
     return showo_nhwc_to_nchw_f32(c.t1, image, B, 3, H * W, s);
 }
 
 extern "C" int showo_vq_get_code(showo_vq* v, const float* pixels, int B, int Hi, int Wi, int64_t* ids, float* z_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (!v) return set_error_msg(1, "vq: null handle");
     const showo_vq_config& cf = v->cfg;
     TRY(check_vq(v, B, Hi, Wi));
     const int down = 1 << (cf.enc_levels - 1);
@@ -357,8 +406,8 @@ extern "C" int showo_vq_get_code(showo_vq* v, const float* pixels, int B, int Hi
     Ctx c{v, s, B, v->f0, v->f1, v->f2};
     int H = Hi, W = Wi;
     TRY(showo_nchw_to_nhwc_f32(pixels, c.t1, B, 3, H * W, s));
-    TRY(showo_pad_cast_bf16(c.t1, v->b0, (int64_t)B * H * W, 3, 64, s));
-    TRY(showo_conv3x3_bf16(v->b0, v->W("encoder.conv_in"), v->Bv("encoder.conv_in"), nullptr, c.cur, B, H, W, 64, ch, 0, s));
+    TRY(showo_pad_cast_bf16(c.t1, v->b0, v->split ? v->b0l : nullptr, (int64_t)B * H * W, 3, 64, s));
+    TRY(conv3(c, v->b0, v->b0l, "encoder.conv_in", nullptr, c.cur, H, W, 64, ch, 0));
     int block_in = ch;
     for (int l = 0; l < cf.enc_levels; ++l) {
         int block_out = ch * cf.enc_ch_mult[l];
@@ -368,8 +417,8 @@ extern "C" int showo_vq_get_code(showo_vq* v, const float* pixels, int B, int Hi
         }
         if (l != cf.enc_levels - 1) {  // pad (0,1,0,1) + stride-2 conv (common_modules.py:83-88), fused into the gather
             std::string n = "encoder.down." + std::to_string(l) + ".downsample.conv";
-            TRY(showo_cast_f32_bf16(c.cur, v->b1, (int64_t)B * H * W * block_in, s));
-            TRY(showo_conv3x3_bf16(v->b1, v->W(n), v->Bv(n), nullptr, c.t1, B, H, W, block_in, block_in, 2, s));
+            TRY(to_operand(c, c.cur, v->b1, v->b1l, (int64_t)B * H * W * block_in));
+            TRY(conv3(c, v->b1, v->b1l, n, nullptr, c.t1, H, W, block_in, block_in, 2));
             std::swap(c.cur, c.t1);
             H /= 2; W /= 2;
         }
@@ -377,8 +426,8 @@ extern "C" int showo_vq_get_code(showo_vq* v, const float* pixels, int B, int Hi
     TRY(resblock(c, "encoder.mid.block_1", block_in, block_in, H, W));
     TRY(attnblock(c, "encoder.mid.attn_1", block_in, H, W));
     TRY(resblock(c, "encoder.mid.block_2", block_in, block_in, H, W));
-    TRY(gn(c, c.cur, "encoder.norm_out", v->b0, H * W, block_in, 1));
-    TRY(showo_conv3x3_bf16(v->b0, v->W("encoder.conv_out"), v->Bv("encoder.conv_out"), nullptr, v->zbuf, B, H, W, block_in, zc, 0, s));
+    TRY(gn(c, c.cur, "encoder.norm_out", v->b0, v->b0l, H * W, block_in, 1));
+    TRY(conv3(c, v->b0, v->b0l, "encoder.conv_out", nullptr, v->zbuf, H, W, block_in, zc, 0));
     TRY(showo_conv_small_f32(v->zbuf, v->Wf("encoder.quant_conv"), v->Bv("encoder.quant_conv"), v->zbuf2, B, H, W, zc, zc, 1, s));
     // LFQuantizer sign-pack (modeling_magvitv2.py:201-206, 239-241)
     TRY(showo_lfq_pack_nhwc(v->zbuf2, ids, B, zc, H * W, zc, s));

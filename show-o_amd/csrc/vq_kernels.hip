@@ -12,37 +12,52 @@ namespace {
 constexpr int GN_GROUPS = 32;
 constexpr int GN_PIX_PER_BLOCK = 512;
 
-// stats[b][g] = (sum, sumsq) in double.  Thread t owns channel quad f = t % (C/4) for all of its pixels,
-// so its partial sums belong to exactly one group (C % 128 == 0  =>  channels-per-group % 4 == 0).
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C) {
-    __shared__ float ssum[GN_GROUPS], ssq[GN_GROUPS];
-    const int tid = threadIdx.x, b = blockIdx.y;
-    if (tid < GN_GROUPS) { ssum[tid] = 0.f; ssq[tid] = 0.f; }
-    __syncthreads();
+// Deterministic GroupNorm statistics (no atomics: the same input gives the same bits on every run, which the
+// sign-test quantizer downstream needs).  Pass 1: block (blk, b) reduces GN_PIX_PER_BLOCK pixels to 32 (sum, sumsq)
+// pairs in double and writes them to part[b][blk][g][2].  Thread t owns channel quad f = t % (C/4) for all of its
+// pixels, so its partial sums belong to exactly one group (C % 128 == 0  =>  channels-per-group % 4 == 0); every
+// group is owned by exactly 8 threads of the block.  Pass 2 adds the per-block partials in block order.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int HW, int C) {
+    __shared__ double ssum[256], ssq[256];
+    const int tid = threadIdx.x, b = blockIdx.y, nblk = gridDim.x;
     const int quads = C >> 2, ppp = 256 / quads;  // pixels per pass
     const int f = tid % quads, pl = tid / quads;
     const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
     const int pend = min(p0 + GN_PIX_PER_BLOCK, HW);
     const float* xb = x + (int64_t)b * HW * C;
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;
     for (int p = p0 + pl; p < pend; p += ppp) {
         float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C + f * 4);
-        s += (v.x + v.y) + (v.z + v.w);
-        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     }
-    const int g = (f * 4) / (C / GN_GROUPS);
-    atomicAdd(&ssum[g], s);
-    atomicAdd(&ssq[g], q);
+    // slot layout: group-major, 8 owners per group in (pixel-lane, quad-in-group) order
+    const int qpg = quads / GN_GROUPS;  // quads per group
+    const int g = f / qpg;
+    const int slot = g * 8 + pl * qpg + (f - g * qpg);
+    ssum[slot] = s;
+    ssq[slot] = q;
     __syncthreads();
     if (tid < GN_GROUPS) {
-        atomicAdd(&stats[((int64_t)b * GN_GROUPS + tid) * 2 + 0], (double)ssum[tid]);
-        atomicAdd(&stats[((int64_t)b * GN_GROUPS + tid) * 2 + 1], (double)ssq[tid]);
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += ssum[tid * 8 + i]; c += ssq[tid * 8 + i]; }
+        double* o = part + (((int64_t)b * nblk + blockIdx.x) * GN_GROUPS + tid) * 2;
+        o[0] = a;
+        o[1] = c;
     }
+}
+__global__ void gn_finalize_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+    const int b = blockIdx.x, t = threadIdx.x;  // t = g*2 + which
+    double a = 0.0;
+    for (int k = 0; k < nblk; ++k) a += part[((int64_t)b * nblk + k) * (GN_GROUPS * 2) + t];
+    stats[(int64_t)b * GN_GROUPS * 2 + t] = a;
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16_t* __restrict__ y, int HW, int C, float eps, int do_swish) {
+                                                       bf16_t* __restrict__ y, bf16_t* __restrict__ ylo, int HW, int C, float eps,
+                                                       int do_swish) {
     __shared__ float smean[GN_GROUPS], srstd[GN_GROUPS];
     const int tid = threadIdx.x, b = blockIdx.y;
     if (tid < GN_GROUPS) {
@@ -64,6 +79,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int pend = min(p0 + GN_PIX_PER_BLOCK, HW);
     const float* xb = x + (int64_t)b * HW * C;
     bf16_t* yb = y + (int64_t)b * HW * C;
+    bf16_t* ylb = ylo ? ylo + (int64_t)b * HW * C : nullptr;
     for (int p = p0 + pl; p < pend; p += ppp) {
         float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C + f * 4);
         float o[4] = {(v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y,
@@ -76,6 +92,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         pk.x = pack_bf2(o[0], o[1]);
         pk.y = pack_bf2(o[2], o[3]);
         *reinterpret_cast<uint2*>(yb + (int64_t)p * C + f * 4) = pk;
+        if (ylb) {  // split precision: lo = bf16(x - float(hi))
+            uint2 pl2;
+            pl2.x = pack_bf2(o[0] - bf2f((bf16_t)(pk.x & 0xffff)), o[1] - bf2f((bf16_t)(pk.x >> 16)));
+            pl2.y = pack_bf2(o[2] - bf2f((bf16_t)(pk.y & 0xffff)), o[3] - bf2f((bf16_t)(pk.y >> 16)));
+            *reinterpret_cast<uint2*>(ylb + (int64_t)p * C + f * 4) = pl2;
+        }
     }
 }
 
@@ -107,12 +129,16 @@ __global__ void conv_small_kernel(const float* __restrict__ x, const float* __re
 }
 
 // fp32 [P, C] -> bf16 [P, Cpad] (zero padded channels)
-__global__ void pad_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int C, int Cpad, int64_t total) {
+__global__ void pad_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ ylo, int C, int Cpad,
+                                int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int c = (int)(i % Cpad);
     int64_t p = i / Cpad;
-    y[i] = (c < C) ? f2bf(x[p * C + c]) : (bf16_t)0;
+    float v = (c < C) ? x[p * C + c] : 0.f;
+    bf16_t h = f2bf(v);
+    y[i] = h;
+    if (ylo) ylo[i] = f2bf(v - bf2f(h));
 }
 
 __global__ void lfq_unpack_nhwc_kernel(const int64_t* __restrict__ ids, float* __restrict__ zq, int C, int64_t total) {
@@ -125,21 +151,28 @@ __global__ void lfq_unpack_nhwc_kernel(const int64_t* __restrict__ ids, float* _
 
 }  // namespace
 
+extern "C" int showo_gn_stats_doubles(int B, int HW) {
+    int nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
+    return B * GN_GROUPS * 2 * (1 + nblk);
+}
+
 extern "C" int showo_gn_stats(const float* x, double* stats, int B, int HW, int C, void* stream) {
     if (B <= 0 || HW <= 0) return 0;
     if ((C % 128) || C > 1024) return set_error_msg(1, "gn_stats: C must be a multiple of 128 and <= 1024");
-    SHOWO_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * GN_GROUPS * B, (hipStream_t)stream));
-    gn_stats_kernel<<<dim3((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK, B), dim3(256), 0, (hipStream_t)stream>>>(x, stats, HW, C);
+    const int nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
+    double* part = stats + (int64_t)B * GN_GROUPS * 2;  // per-block partials live behind the [B,32,2] result
+    gn_partial_kernel<<<dim3(nblk, B), dim3(256), 0, (hipStream_t)stream>>>(x, part, HW, C);
+    gn_finalize_kernel<<<dim3(B), dim3(GN_GROUPS * 2), 0, (hipStream_t)stream>>>(part, stats, nblk);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int showo_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, uint16_t* y,
-                              int B, int HW, int C, float eps, int do_swish, void* stream) {
+                              uint16_t* ylo, int B, int HW, int C, float eps, int do_swish, void* stream) {
     if (B <= 0 || HW <= 0) return 0;
     if ((C % 128) || C > 1024) return set_error_msg(1, "gn_apply: C must be a multiple of 128 and <= 1024");
     gn_apply_kernel<<<dim3((HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK, B), dim3(256), 0, (hipStream_t)stream>>>(
-        x, stats, gamma, beta, y, HW, C, eps, do_swish);
+        x, stats, gamma, beta, y, ylo, HW, C, eps, do_swish);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -155,10 +188,10 @@ extern "C" int showo_conv_small_f32(const float* x, const float* w, const float*
     return 0;
 }
 
-extern "C" int showo_pad_cast_bf16(const float* x, uint16_t* y, int64_t P, int C, int Cpad, void* stream) {
+extern "C" int showo_pad_cast_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t P, int C, int Cpad, void* stream) {
     int64_t total = P * Cpad;
     if (total <= 0) return 0;
-    pad_cast_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, C, Cpad, total);
+    pad_cast_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(x, y, ylo, C, Cpad, total);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

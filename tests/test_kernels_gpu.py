@@ -395,13 +395,23 @@ def test_groupnorm_and_conv():
     x = torch.randn(B, Cin, H, W) * 2 + 0.3
     gam, bet = torch.randn(Cin) * .1 + 1, torch.randn(Cin) * .05
     xn = dev(x.permute(0, 2, 3, 1))
-    stats = torch.zeros((B, 32, 2), dtype=torch.float64, device="cuda")
+    stats = torch.zeros((L().load().showo_gn_stats_doubles(B, H * W),), dtype=torch.float64, device="cuda")
     y = torch.empty((B, H * W, Cin), dtype=torch.int16, device="cuda")
+    ylo = torch.empty_like(y)
     L().call("showo_gn_stats", L().ptr(xn), L().ptr(stats), B, H * W, Cin, S())
-    L().call("showo_gn_apply", L().ptr(xn), L().ptr(stats), L().ptr(dev(gam)), L().ptr(dev(bet)), L().ptr(y), B, H * W, Cin, 1e-6, 1, S())
+    st = stats[:B * 64].reshape(B, 32, 2).cpu()
+    xg = x.double().reshape(B, 32, -1)
+    assert torch.allclose(st[..., 0], xg.sum(-1), rtol=1e-12, atol=1e-9) and torch.allclose(st[..., 1], (xg * xg).sum(-1), rtol=1e-12)
+    stats2 = torch.zeros_like(stats)
+    L().call("showo_gn_stats", L().ptr(xn), L().ptr(stats2), B, H * W, Cin, S())
+    assert torch.equal(stats[:B * 64], stats2[:B * 64])  # deterministic: no atomics
+    L().call("showo_gn_apply", L().ptr(xn), L().ptr(stats), L().ptr(dev(gam)), L().ptr(dev(bet)), L().ptr(y), L().ptr(ylo), B, H * W, Cin,
+             1e-6, 1, S())
     want = O.swish(O.group_norm(x, gam, bet)).permute(0, 2, 3, 1).reshape(B, H * W, Cin)
     got = from_bf16_bits(y).cpu()
     assert (got - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-5
+    got2 = got + from_bf16_bits(ylo).cpu()  # split precision: hi + lo carries ~16 mantissa bits
+    assert (got2 - want).abs().max() < 3e-5 * float(want.abs().max())
     # conv modes on the bf16 image, vs F.conv2d on the same rounded operands
     import torch.nn.functional as F
     a = from_bf16_bits(y).cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
@@ -435,10 +445,13 @@ def test_softmax_rows_and_small_conv():
     torch.manual_seed(1)
     x = torch.randn(40, 100) * 3
     y = torch.full((40, 128), 7, dtype=torch.int16, device="cuda")
-    L().call("showo_softmax_rows_bf16", L().ptr(dev(x)), L().ptr(y), 40, 100, 128, 0.5, S())
+    ylo = torch.full((40, 128), 7, dtype=torch.int16, device="cuda")
+    L().call("showo_softmax_rows_bf16", L().ptr(dev(x)), L().ptr(y), L().ptr(ylo), 40, 100, 128, 0.5, S())
     got = from_bf16_bits(y).cpu()
     assert (got[:, :100] - torch.softmax(x * 0.5, -1)).abs().max() < 2 ** -8
     assert (got[:, 100:] == 0).all()
+    got2 = got + from_bf16_bits(ylo).cpu()
+    assert (got2[:, :100] - torch.softmax(x * 0.5, -1)).abs().max() < 2e-6 and (from_bf16_bits(ylo).cpu()[:, 100:] == 0).all()
     import torch.nn.functional as F
     z = torch.randn(2, 13, 5, 4)
     wq, bq = torch.randn(13, 13, 1, 1), torch.randn(13)
@@ -469,3 +482,54 @@ def test_gemm_both_tile_kernels(impl):
             assert (got.double() - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-3 * float(ref.abs().max())
     finally:
         L().call("showo_gemm_set_impl", 0)
+
+
+# ------------------------------------------------------------------------------------ split-precision (bf16 x3) kernels
+def _split(t):
+    """(hi, lo) bf16 bit tensors on the device with t ~= hi + lo"""
+    hi = torch.empty(t.shape, dtype=torch.int16, device="cuda")
+    lo = torch.empty_like(hi)
+    L().call("showo_split_f32_bf16", L().ptr(dev(t)), L().ptr(hi), L().ptr(lo), t.numel(), S())
+    util._KEEP.extend([hi, lo])
+    return hi, lo
+
+
+def test_split_gemm_and_conv_track_fp32():
+    """x3 kernels: operands as (hi, lo) bf16 pairs, product = hi*hi + hi*lo + lo*hi accumulated in fp32.  Compared
+    with an fp64 product of the ORIGINAL fp32 operands: bound 3e-5 of the output scale (vs 4e-3 for plain bf16)."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    t = torch.randn(1000) * 3
+    hi, lo = _split(t)
+    rec = from_bf16_bits(hi).cpu() + from_bf16_bits(lo).cpu()
+    assert torch.equal(from_bf16_bits(hi).cpu(), bf16_round(t)) and (rec - t).abs().max() <= 2 ** -16 * float(t.abs().max())
+    for (M, N, K) in [(300, 200, 128), (129, 512, 512), (16, 16, 64)]:
+        A, W, bias, resid = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N), torch.randn(M, N)
+        ah, al = _split(A)
+        wh, wl = _split(W)
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        L().call("showo_gemm_bf16x3", L().ptr(ah), L().ptr(al), K, L().ptr(wh), L().ptr(wl), K, L().ptr(dev(bias)), 0, L().ptr(out), N,
+                 L().ptr(dev(resid)), N, M, N, K, S())
+        ref = A.double() @ W.double().T + bias.double() + resid.double()
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < 3e-5, (M, N, K, err)
+    B, H, Wd, Cin, Cout = 2, 9, 7, 128, 128
+    x = torch.randn(B, Cin, H, Wd)
+    wgt = torch.randn(Cout, Cin, 3, 3) * 0.03
+    bias = torch.randn(Cout)
+    xh, xl = _split(x.permute(0, 2, 3, 1).contiguous())
+    wh, wl = _split(wgt.permute(0, 2, 3, 1).contiguous())
+    for mode, (Ho, Wo) in ((0, (H, Wd)), (1, (2 * H, 2 * Wd)), (2, (H // 2, Wd // 2))):
+        out = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        L().call("showo_conv3x3_bf16x3", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), None, L().ptr(out), B, H, Wd,
+                 Cin, Cout, mode, S())
+        xd, wd_, bd = x.double(), wgt.double(), bias.double()
+        if mode == 0:
+            ref = F.conv2d(xd, wd_, bd, padding=1)
+        elif mode == 1:
+            ref = F.conv2d(xd.repeat_interleave(2, 2).repeat_interleave(2, 3), wd_, bd, padding=1)
+        else:
+            ref = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wd_, bd, stride=2)
+        ref = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < 3e-5, (mode, err)
