@@ -62,8 +62,13 @@ enum {
 int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
                     void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, void* stream);
 
-/* kernel selection for tests/benchmarks: 0 = by shape (default), 1 = 128x128 register-staged, 2 = 256x256 global_load_lds */
+/* kernel selection for tests/benchmarks: 0 = by shape (default), 1 = 128x128 register-staged, 2 = 256x256 global_load_lds,
+ * 3 = 256x256 phase-split (4 phases per k-tile), 4 = 256x256 phase-split (2 phases per k-tile; default for M >= 1024) */
 int showo_gemm_set_impl(int impl);
+/* development knobs of the 256^2 phase-split kernel (impl 3), used by tools/gemm_bench.cpp: gn = weight panels per
+ * tile group of the block->tile map, flags bit0 = run the two wave groups without the one-barrier stagger,
+ * dbg = device buffer of 512 uint64 for per-barrier timestamps (NULL = off). */
+int showo_gemm_tune(int gn, int flags, unsigned long long* dbg);
 
 /* Split-precision forms (VQGAN path): every operand is a (hi, lo) bf16 pair, x = hi + lo to ~2^-17; the MFMA
  * accumulates hi*hi + hi*lo + lo*hi in fp32.  fp32 output, optional residual.  Same layouts as the plain calls. */

@@ -13,7 +13,7 @@ timeout 600 python bench.py --steps 3 --warmup 1 > gpurun_out/bench_$TAG.log 2>&
 tail -4 gpurun_out/bench_$TAG.log
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o prof -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o prof -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
 echo "rocprof rc=$?" >> $R/gpurun_out/prof_$TAG.log
 cd $R
 find gpurun_out/prof_$TAG -name "*kernel_stats*" | head

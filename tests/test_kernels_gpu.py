@@ -462,7 +462,7 @@ def test_softmax_rows_and_small_conv():
     assert (out.cpu() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4])
 def test_gemm_both_tile_kernels(impl):
     """the 128^2 register-staged kernel and the 256^2 global_load_lds kernel give the same result on shapes
     with ragged M/N edges (rows/cols beyond the edge are clamped on load and predicated on store)"""

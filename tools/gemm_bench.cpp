@@ -1,0 +1,144 @@
+// Standalone GEMM A/B harness (no torch): drives libshowo_hip.so through its C ABI.
+//   build: hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -o tools/gemm_bench -Lshow-o_amd -lshowo_hip -Wl,-rpath,'$ORIGIN/../show-o_amd'
+//   run:   tools/gemm_bench [impl list, e.g. 2,3]
+// For every shape: each implementation is checked against implementation 1 (the 128^2 kernel, itself checked against
+// the oracle by tests/test_kernels_gpu.py) on the full output, 3 repeats (race screen), then timed on rotating weight
+// buffers (weights stream from HBM like in the 24-layer stack), random normal operands.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "../include/showo_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+#define RC(x) do { int r_ = (x); if (r_) { printf("showo error %d: %s (line %d)\n", r_, showo_last_error(), __LINE__); exit(3); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t v) { uint32_t u = ((uint32_t)v) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+__global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed; x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+        uint32_t y = x * 1664525u + 1013904223u; y ^= y >> 15;
+        float u1 = ((x >> 8) + 0.5f) / 16777216.f, u2 = ((y >> 8) + 0.5f) / 16777216.f;
+        float v = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2) * scale;  // N(0, scale)
+        uint32_t b = __float_as_uint(v); b += 0x7fffu + ((b >> 16) & 1u);
+        p[i] = (uint16_t)(b >> 16);
+    }
+}
+
+struct Shape { int M, N, K, epi; const char* name; };
+
+int main(int argc, char** argv) {
+    // variants: "impl[:gn[:flags]]" separated by ','  e.g.  2,3:1,3:4,3:8,3:4:1
+    struct Var { int impl, gn, flags; };
+    std::vector<Var> impls = {{2, 1, 0}, {3, 4, 0}};
+    if (argc > 1) {
+        impls.clear();
+        for (char* t = strtok(argv[1], ","); t; t = strtok(nullptr, ",")) {
+            Var v{0, 4, 0};
+            sscanf(t, "%d:%d:%d", &v.impl, &v.gn, &v.flags);
+            impls.push_back(v);
+        }
+    }
+    int quick = argc > 2 ? atoi(argv[2]) : 0;
+    int dbg = argc > 3 ? atoi(argv[3]) : 0;
+    unsigned long long* dbgbuf = nullptr;
+    if (dbg) CK(hipMalloc(&dbgbuf, 512 * 8));
+    std::vector<Shape> shapes = {
+        {300, 256, 64, 2, "edge-small"}, {1100, 520, 192, 2, "edge-ragged"}, {1548, 2048, 256, 3, "ragged-resid"},
+        {6192, 6144, 2048, 0, "qkv"}, {6192, 2048, 2048, 3, "dense"}, {6192, 8192, 2048, 1, "fc1+gelu"},
+        {6192, 2048, 8192, 3, "fc2"}, {4096, 8192, 2048, 2, "lm_head rows"}, {6192, 14336, 2048, 0, "qkv|fc1 fused"},
+        {6192, 2048, 10240, 3, "dense|fc2 fused"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
+    };
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Shape& s : shapes) {
+        if (quick && (size_t)s.M * s.N * s.K > (size_t)6192 * 14336 * 2048) continue;
+        const size_t nA = (size_t)s.M * s.K, nW = (size_t)s.N * s.K, nO = (size_t)s.M * s.N;
+        int R = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)1 << 30) / (nW * 2)));
+        uint16_t *A, *W; float *bias, *resid; void *out_ref, *out;
+        const bool f32 = s.epi >= 2;
+        CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&W, nW * 2 * R)); CK(hipMalloc(&bias, s.N * 4)); CK(hipMalloc(&resid, nO * 4));
+        CK(hipMalloc(&out_ref, nO * 4)); CK(hipMalloc(&out, nO * 4));
+        fill_kernel<<<1024, 256, 0, st>>>(A, nA, 1u, 1.0f);
+        fill_kernel<<<1024, 256, 0, st>>>(W, nW * R, 2u, 0.02f);
+        {   // bias / resid: reuse the generator through a bf16 temp is overkill; small host fill
+            std::vector<float> hb(s.N); for (int i = 0; i < s.N; ++i) hb[i] = 0.01f * ((i * 37) % 101 - 50);
+            CK(hipMemcpy(bias, hb.data(), s.N * 4, hipMemcpyHostToDevice));
+            CK(hipMemsetAsync(resid, 0, nO * 4, st));
+        }
+        CK(hipStreamSynchronize(st));
+        auto run = [&](Var v, void* o, int r) {
+            RC(showo_gemm_set_impl(v.impl));
+            RC(showo_gemm_tune(v.gn, v.flags, nullptr));
+            // in-place residual like the engine when epi == 3: resid := o would accumulate across repeats, so use `resid`
+            RC(showo_gemm_bf16(A, s.K, W + (size_t)r * nW, s.K, bias, 0, o, s.N, s.epi == 3 ? resid : nullptr, s.N, s.M, s.N, s.K, s.epi, st));
+        };
+        run(Var{1, 1, 0}, out_ref, 0);
+        CK(hipStreamSynchronize(st));
+        std::vector<float> href(f32 ? nO : 0); std::vector<uint16_t> hrefb(f32 ? 0 : nO);
+        if (f32) CK(hipMemcpy(href.data(), out_ref, nO * 4, hipMemcpyDeviceToHost)); else CK(hipMemcpy(hrefb.data(), out_ref, nO * 2, hipMemcpyDeviceToHost));
+        printf("%-18s M=%5d N=%5d K=%5d epi=%d  tiles256=%4d |", s.name, s.M, s.N, s.K, s.epi, ((s.M + 255) / 256) * ((s.N + 255) / 256));
+        for (Var impl : impls) {
+            double maxd = 0, maxr = 0; size_t bad = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemsetAsync(out, 0xff, nO * (f32 ? 4 : 2), st));
+                run(impl, out, 0);
+                CK(hipStreamSynchronize(st));
+                if (f32) {
+                    std::vector<float> h(nO); CK(hipMemcpy(h.data(), out, nO * 4, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < nO; ++i) { double d = fabs((double)h[i] - href[i]); if (!(d <= 1e-3 * (1 + fabs(href[i])))) bad++; if (d > maxd) maxd = d; if (fabs(href[i]) > maxr) maxr = fabs(href[i]); }
+                } else {
+                    std::vector<uint16_t> h(nO); CK(hipMemcpy(h.data(), out, nO * 2, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < nO; ++i) { double a = bf2f(h[i]), b = bf2f(hrefb[i]); double d = fabs(a - b); if (!(d <= 1.6e-2 * (fabs(b) + 1e-2))) bad++; if (d > maxd) maxd = d; if (fabs(b) > maxr) maxr = fabs(b); }
+                }
+            }
+            // timing
+            const int iters = (size_t)s.M * s.N * s.K > ((size_t)1 << 36) ? 6 : 16;
+            for (int i = 0; i < 3; ++i) run(impl, out, i % R);
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) run(impl, out, i % R);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            double tf = 2.0 * s.M * s.N * s.K * iters / (ms * 1e-3) / 1e12;
+            printf(" v%d:%d:%d %7.1f TF %6.3f ms %s|", impl.impl, impl.gn, impl.flags, tf, ms / iters, bad ? "**MISMATCH** " : "");
+            (void)maxd; (void)maxr;
+            fflush(stdout);
+        }
+        printf("\n");
+        if (dbg && s.epi == 0 && s.M == 4096 && s.K == 4096) {
+            for (Var v : impls) {
+                if (v.impl < 3 || (v.flags >> 4)) continue;
+                RC(showo_gemm_set_impl(v.impl));
+                RC(showo_gemm_tune(v.gn, v.flags, dbgbuf));
+                CK(hipMemsetAsync(dbgbuf, 0, 512 * 8, st));
+                RC(showo_gemm_bf16(A, s.K, W, s.K, bias, 0, out, s.N, nullptr, s.N, s.M, s.N, s.K, 0, st));
+                CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> h(512);
+                CK(hipMemcpy(h.data(), dbgbuf, 512 * 8, hipMemcpyDeviceToHost));
+                printf("  timestamps (cycles since first, per barrier exit; k-tiles 8,9) gn=%d flags=%d\n", v.gn, v.flags);
+                unsigned long long t0 = h[0];
+                for (int w = 0; w < 8; w += 4) {
+                    printf("   wave %d:", w);
+                    for (int i = 0; i < 16; ++i) printf(" %5lld", (long long)(h[w * 64 + i] - t0));
+                    printf("\n   delta :     ");
+                    for (int i = 1; i < 16; ++i) printf(" %5lld", (long long)(h[w * 64 + i] - h[w * 64 + i - 1]));
+                    printf("\n");
+                }
+                RC(showo_gemm_tune(v.gn, v.flags, nullptr));
+            }
+        }
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(resid)); CK(hipFree(out_ref)); CK(hipFree(out));
+    }
+    RC(showo_gemm_set_impl(0));
+    return 0;
+}
