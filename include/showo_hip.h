@@ -107,6 +107,10 @@ int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag, int B, in
  * iv/flag from showo_mask_compress; dense_mask may be NULL iff *flag is known to be 0.
  * Lq query rows (row r attends with mask row r); Lk keys; K holds Lcap rows per head, Vt rows are Lp long.
  * iv == NULL and flag == NULL: causal (query r sees keys <= r + Lk - Lq). */
+/* kernel selection for tests/benchmarks: 0 = by shape (default: LDS-tiled for Lq >= 64), 1 = gather form (one wave
+ * per 32 query rows, operands straight from L2), 2 = LDS-tiled form (4 waves share 64-key K / V^T tiles staged by
+ * global_load_lds; 4 waves/SIMD), 3 = the same at 3 waves/SIMD (no register spill) */
+int showo_attn_set_impl(int impl);
 int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                    void* stream);

@@ -33,6 +33,7 @@ _PROTOS = {
     "showo_gemm_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_set_impl": [c_i],
     "showo_gemm_tune": [c_i, c_i, c_p],
+    "showo_attn_set_impl": [c_i],
     "showo_gemm_bf16x3": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "showo_conv3x3_bf16x3": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],

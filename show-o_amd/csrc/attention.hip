@@ -17,6 +17,7 @@
 #include "../../include/showo_hip.h"
 #include "prof.h"
 #include <cfloat>
+#include <cstdlib>
 
 using namespace showo;
 
@@ -274,6 +275,212 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled form (prefill / t2i): block = 4 waves = 128 query rows of one (b, head); K and V^T are streamed
+// through LDS in 64-key tiles shared by the 4 waves (coalesced 16-B global loads, register-staged,
+// double-buffered: the loads of tile t+1 are in flight under the MFMAs of tile t; one barrier per tile).
+// The per-wave math is that of attn_fwd_kernel.  The gather form above spends its time in the texture
+// addresser (every lane of a V^T load touches its own 128-B line); here a tile costs 16 fully coalesced
+// wave-loads per block.
+// LDS image of both tiles: [64 rows][8 chunks of 16 B], chunk c of row r stored at c ^ ((r >> 1) & 7): a
+// ds_read_b128 of 32 consecutive rows at one logical chunk (the 32x32x16 operand fetch) is conflict-free.
+// K rows = keys in the order pi (key blocks 4-7 and 8-11 of every 16 swapped), so that the 16 scores a lane holds
+// after the swapped QK^T (C-layout rows (r&3) + 8(r>>2) + 4hh) are the keys 16(r>>3) + 8hh + (r&7): its two
+// P fragments then multiply 8 CONSECUTIVE keys each, one 16-B chunk of the natural-order V^T rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int AT_TILE = 64 * 64;  // bf16 elements of one K (or V^T) tile
+constexpr float AT_DEFER = 8.0f;   // deferred-rescale threshold (natural-log units of the score)
+
+// hardware RNE f32 -> packed bf16 (same rounding as f2bf on finite values)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <bool DENSE>
+__device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int* s_hull) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qblk = blockIdx.x * 4 + wave;
+    const bool wactive = qblk * 32 < a.Lq;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qi = lane & 31, hh = lane >> 5;
+    const int qrow_raw = qblk * 32 + qi;
+    const int qrow = qrow_raw < a.Lq ? qrow_raw : a.Lq - 1;
+    const int64_t bh = (int64_t)b * a.nH + head;
+
+    bf16x8 qf[4];
+    {
+        const bf16_t* Qp = a.Q + (bh * a.Lq + qrow) * 64 + 8 * hh;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const bf16x8*>(Qp + 16 * m);
+    }
+    constexpr bool dense = DENSE;
+    int lo1, hi1, lo2, hi2;
+    if (dense) {
+        lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0;
+    } else if (a.iv) {
+        int4 v = *reinterpret_cast<const int4*>(a.iv + ((int64_t)b * a.Lq + qrow) * 4);
+        lo1 = v.x; hi1 = v.y; lo2 = v.z; hi2 = v.w;
+    } else {
+        lo1 = 0; hi1 = qrow + 1 + (a.Lk - a.Lq); lo2 = 0; hi2 = 0;
+    }
+    hi1 = min(hi1, a.Lk);
+    hi2 = min(hi2, a.Lk);
+    if (!wactive) { lo1 = hi1 = lo2 = hi2 = 0; }
+    // key hull of the wave and of the block
+    const int wmin = wave_min_i(min(lo1 < hi1 ? lo1 : 0x7fffffff, lo2 < hi2 ? lo2 : 0x7fffffff));
+    const int wmax = wave_max_i(max(lo1 < hi1 ? hi1 : 0, lo2 < hi2 ? hi2 : 0));
+    if (lane == 0) { s_hull[wave] = wmin; s_hull[4 + wave] = wmax; }
+    __syncthreads();
+    const int bmin = min(min(s_hull[0], s_hull[1]), min(s_hull[2], s_hull[3]));
+    const int bmax = max(max(s_hull[4], s_hull[5]), max(s_hull[6], s_hull[7]));
+    const float* drow = dense ? a.dense + ((int64_t)b * a.Lq + qrow) * a.Lk : nullptr;
+
+    // ---- staging by DMA (global_load_lds, 16 B/lane, no VGPR round trip).  One wave-instruction fills 8 rows x 128 B
+    // (lane-linear LDS image, so the chunk swizzle is applied to the SOURCE address); wave w issues pieces w and w + 4
+    // of both tiles.  LDS row i of the K tile holds key pi(i) = (i & ~15) + 4 * {0,2,1,3}[(i >> 2) & 3] + (i & 3).
+    const int prow = lane >> 3;
+    const bf16_t* Kg = a.K + bh * a.Lcap * 64;
+    const bf16_t* Vg = a.Vt + bh * 64 * a.Lp;
+    int pik[2], kch[2];
+    int64_t voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (wave + 4 * i) + prow;
+        const int f = (r >> 1) & 7;
+        const int blk = (r >> 2) & 3;
+        pik[i] = (r & ~15) + 4 * (((blk & 1) << 1) | (blk >> 1)) + (r & 3);
+        kch[i] = ((lane & 7) ^ f) << 3;
+        voff[i] = (int64_t)r * a.Lp + kch[i];
+    }
+#define AT_STAGE(KT, BUF)                                                                              \
+    do {                                                                                               \
+        bf16_t* sK_ = sm + (BUF) * 2 * AT_TILE;                                                        \
+        bf16_t* sV_ = sK_ + AT_TILE;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+            int key_ = (KT) + pik[i];                                                                  \
+            key_ = key_ < a.Lk ? key_ : a.Lk - 1; /* clamped rows are masked out below */              \
+            glds16(Kg + (int64_t)key_ * 64 + kch[i], sK_ + (wave + 4 * i) * 512);                      \
+            glds16(Vg + voff[i] + (KT), sV_ + (wave + 4 * i) * 512);                                   \
+        }                                                                                              \
+    } while (0)
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+
+    const int fsw = (qi >> 1) & 7;  // swizzle of the fragment rows qi and 32 + qi (same (r >> 1) & 7)
+    const int kt0 = bmin >= 0x7fffffff ? 0 : (bmin & ~63);
+    if (kt0 < bmax) AT_STAGE(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt0; kt < bmax; kt += 64, buf ^= 1) {
+        const bool more = kt + 64 < bmax;
+        if (more) AT_STAGE(kt + 64, buf ^ 1);  // lands under this tile's MFMAs
+        const bf16_t* sK = sm + buf * 2 * AT_TILE;
+        const bf16_t* sV = sK + AT_TILE;
+#pragma unroll 1
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ks = kt + 32 * sub;
+            if (ks >= wmax || ks + 32 <= wmin) continue;  // wave-uniform: nothing visible to this wave here
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * sub + qi) * 64 + (((2 * m + hh) ^ fsw) << 3));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m], s, 0, 0, 0);
+            }
+            // interior sub-tile: every row of the wave sees all 32 keys -> no per-element mask work
+            const bool inner = !dense && __all(((lo1 <= ks) & (ks + 32 <= hi1)) | ((lo2 <= ks) & (ks + 32 <= hi2)));
+            float sv[16];
+            float mx = -INFINITY;
+            if (inner) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sv[r] = s[r]; mx = fmaxf(mx, sv[r]); }
+            } else {
+                const unsigned len1 = (unsigned)max(hi1 - lo1, 0), len2 = (unsigned)max(hi2 - lo2, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = ks + 16 * (r >> 3) + 8 * hh + (r & 7);  // K rows are stored in pi order
+                    const bool vis = ((unsigned)(key - lo1) < len1) | ((unsigned)(key - lo2) < len2);
+                    float x = s[r];
+                    if (dense) x += (key < a.Lk) ? drow[key] : 0.f;
+                    sv[r] = vis ? x : -INFINITY;
+                    mx = fmaxf(mx, sv[r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // deferred rescale: the running max is only advanced (and O, l rescaled) when some row's tile max exceeds
+            // it by more than AT_DEFER; otherwise P = exp(S - m_old) <= e^AT_DEFER, still exact in the final ratio
+            if (__any(mx > m_run + AT_DEFER)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - ((m_new == -INFINITY) ? 0.f : m_new)) * LOG2E);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
+            const float mb = ((m_run == -INFINITY) ? 0.f : m_run) * LOG2E;
+            float p[16];
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -mb));
+                ps += p[r];
+            }
+            l_run += ps;
+            bf16x8 pb0, pb1;
+            {
+                uint4 u0, u1;
+                u0.x = cvt_pk_bf16(p[0], p[1]); u0.y = cvt_pk_bf16(p[2], p[3]); u0.z = cvt_pk_bf16(p[4], p[5]); u0.w = cvt_pk_bf16(p[6], p[7]);
+                u1.x = cvt_pk_bf16(p[8], p[9]); u1.y = cvt_pk_bf16(p[10], p[11]); u1.z = cvt_pk_bf16(p[12], p[13]); u1.w = cvt_pk_bf16(p[14], p[15]);
+                pb0 = __builtin_bit_cast(bf16x8, u0);
+                pb1 = __builtin_bit_cast(bf16x8, u1);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = ((4 * sub + 2 * kk + hh) ^ fsw) << 3;
+                bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(sV + qi * 64 + c);
+                bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(sV + (32 + qi) * 64 + c);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pb1 : pb0, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pb1 : pb0, o1, 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (!wactive) return;
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float inv = 1.0f / l_tot;
+    if (qrow_raw < a.Lq) {
+        bf16_t* op = a.O + ((int64_t)b * a.Lq + qrow_raw) * a.ldo + head * 64 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w0, w1;
+            w0.x = cvt_pk_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = cvt_pk_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = cvt_pk_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = cvt_pk_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 8 * g) = w0;
+            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
+        }
+    }
+}
+
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t sm[4 * AT_TILE];  // [buf][K | Vt]
+    __shared__ int s_hull[8];
+    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);  // block-uniform
+    if (dense) attn_lds_body<true>(a, sm, s_hull);
+    else attn_lds_body<false>(a, sm, s_hull);
+}
+
 }  // namespace
 
 extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
@@ -300,6 +507,11 @@ extern "C" int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
+static int g_attn_forced = -1;
+extern "C" int showo_attn_set_impl(int impl) {
+    g_attn_forced = (impl >= 1 && impl <= 3) ? impl : 0;
+    return 0;
+}
 
 extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv,
                               const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
@@ -311,7 +523,12 @@ extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16
     a.B = B; a.nH = nH; a.Lq = Lq; a.Lk = Lk; a.Lcap = Lcap; a.Lp = Lp; a.ldo = ldo;
     int qblocks = (Lq + 31) / 32;
     ProfScope prof(PROF_ATTN, 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // dense QK^T + PV flops
-    attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    if (g_attn_forced < 0) { const char* e = getenv("SHOWO_ATTN_IMPL"); g_attn_forced = e ? atoi(e) : 0; }
+    const int forced = g_attn_forced;  // 1 = gather form, 2 = LDS-tiled form, else by shape
+    const bool tiled = forced >= 2 || (forced != 1 && Lq >= 64);  // decode steps (a few query rows) keep the gather form
+    if (tiled && forced == 3) attn_fwd_lds_kernel<3><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    else if (tiled) attn_fwd_lds_kernel<4><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    else attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

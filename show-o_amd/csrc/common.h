@@ -54,6 +54,12 @@ __device__ inline int wave_max_i(int v) {
     return v;
 }
 
+// direct HBM -> LDS copy, 16 B per lane; the LDS destination is wave-uniform base + lane * 16 (lane-linear image)
+__device__ inline void glds16(const bf16_t* src, bf16_t* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
 // Philox4x32-10 counter RNG (Salmon et al. 2011) — the on-device noise source of the sampler.
 struct Philox {
     uint32_t k0, k1;

@@ -415,10 +415,6 @@ struct ConvPtr {
     }
 };
 
-__device__ inline void glds16(const bf16_t* src, bf16_t* lds_dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
-}
 
 template <int EPI, class Loader>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, Loader ld_in) {

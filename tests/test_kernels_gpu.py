@@ -225,8 +225,16 @@ def _mask_cases(d, Lq):
     yield "lm_causal", O.mask_t2i(torch.full((2, Lq), 5), d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False)
 
 
+@pytest.fixture(params=[1, 2], ids=["gather", "lds-tiled"])
+def attn_impl(request):
+    """run the attention tests on both kernels: 1 = gather form (also the decode kernel), 2 = LDS-tiled form"""
+    L().call("showo_attn_set_impl", request.param)
+    yield request.param
+    L().call("showo_attn_set_impl", 0)
+
+
 @pytest.mark.parametrize("Lq,nH", [(27, 2), (387, 2), (1155, 1)])
-def test_attention_mask_families(Lq, nH):
+def test_attention_mask_families(Lq, nH, attn_impl):
     d = util.tiny_dims()
     torch.manual_seed(Lq)
     for name, mask in _mask_cases(d, Lq):
@@ -247,7 +255,7 @@ def test_attention_mask_families(Lq, nH):
         assert err < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3, (name, float(err))
 
 
-def test_attention_mmu_vit_and_dense_fallback():
+def test_attention_mmu_vit_and_dense_fallback(attn_impl):
     torch.manual_seed(3)
     nH, Lq = 2, 700
     mask = O.mask_mmu_vit(1, Lq, system_prompt_len=28)  # causal + columns [30,606) visible: two intervals
@@ -277,7 +285,7 @@ def test_attention_mmu_vit_and_dense_fallback():
     assert (got - want).abs().max() < 2.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
 
 
-def test_attention_online_softmax_rescale_branch():
+def test_attention_online_softmax_rescale_branch(attn_impl):
     """force the running-max rescale: one key in a late tile dominates one query row (CDNA playbook rule 26)"""
     torch.manual_seed(5)
     nH, Lq = 1, 200
