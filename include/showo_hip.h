@@ -95,6 +95,15 @@ int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, c
                   const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                   int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream);
 
+/* The same result as showo_gemm_bf16(h, Wqkv) + showo_qk_prep in ONE kernel: the QKV projection whose epilogue applies
+ * bias, the per-head LayerNorm(64) of q and k, the partial rotary embedding (rot must be 32) and writes Q (pre-scaled),
+ * K and V^T head-major -- the fp32 accumulators are normalised directly (no bf16 round trip of qkv).
+ * A bf16 [B*L, lda] (LayerNorm output h), Wqkv bf16 [3*nH*64, ldw] rows q|k|v, bias fp32 [3*nH*64]. */
+int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias, const float* qln_w,
+                        const float* qln_b, const float* kln_w, const float* kln_b, const float* cos_tab,
+                        const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot,
+                        float eps, int pos0, int Lcap, int Lp, void* stream);
+
 /* Compress an additive attention mask [B,1,Lq,Lk] fp32 (values 0 / very negative, as built by
  * training/prompting_utils.py:466-511, 591-624) into per-row visibility intervals
  * iv int32 [B, Lq, 4] = (lo1, hi1, lo2, hi2): key c is visible iff lo1<=c<hi1 or lo2<=c<hi2.

@@ -224,9 +224,15 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, bool use_cache, c
         bf16_t* Kd = use_cache ? e->kcache + (int64_t)li * nH * e->cache_cap * 64 : e->K;
         bf16_t* Vd = use_cache ? e->vtcache + (int64_t)li * nH * 64 * e->cache_cap : e->Vt;
         TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
-        TRY(showo_gemm_bf16(e->h, H, l.wqkv, H, l.bqkv, 0, e->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
-        TRY(showo_qk_prep(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd, B, L, nH,
-                          e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+        if (T >= 256 && e->cfg.rotary_dim == 32) {
+            // prefill / t2i: one kernel (the projection's epilogue normalises, rotates and relayouts the fp32 accumulators)
+            TRY(showo_gemm_qkv_bf16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
+                                    B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+        } else {
+            TRY(showo_gemm_bf16(e->h, H, l.wqkv, H, l.bqkv, 0, e->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
+            TRY(showo_qk_prep(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd, B, L, nH,
+                              e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+        }
         TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
         TRY(showo_gemm_bf16(e->attn, H, l.wd, H, l.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
         TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, s));

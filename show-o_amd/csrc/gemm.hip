@@ -38,7 +38,14 @@ struct GemmArgs {
     int gn;       // v3: n-panels per tile group (L2 locality of the block -> tile map)
     int flags;    // v3 experiments: bit0 = no group stagger
     unsigned long long* dbg;  // v3 debug build: per-barrier timestamps of block 0
+    // fused q/k LayerNorm + RoPE + head-major relayout epilogue (EPI_QKV): out is unused
+    const float *qw, *qb, *kw, *kb, *cosT, *sinT;
+    bf16_t *Q, *Kd, *Vt;
+    int L, nH, pos0, Lcap, Lp;
+    float eps;
 };
+
+constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
 
 struct ConvArgs {
     const bf16_t* X;   // NHWC bf16 input
@@ -797,13 +804,100 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs g) {
         if (blockIdx.x == 0 && g.dbg) g.dbg[tid] = dbgl[lane];
     }
 
+    if constexpr (EPI == EPI_QKV) {
+        // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
+        // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
+        // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
+        const int nbase = n0 + wn * 64;
+        if (nbase < g.N) {
+            const int Hq = g.nH * 64;
+            const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)
+            const int head = (nbase - which * Hq) >> 6;
+            float bn[4][4], lw[4][4], lb[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + fg * 4;
-        float bn[4];
-        load_bias4(g, n, bn);
+            for (int i = 0; i < 4; ++i) {
+                load_bias4(g, nbase + i * 16 + fg * 4, bn[i]);
+                if (which < 2) {
+                    const float4 w4 = *reinterpret_cast<const float4*>((which ? g.kw : g.qw) + i * 16 + fg * 4);
+                    const float4 b4 = *reinterpret_cast<const float4*>((which ? g.kb : g.qb) + i * 16 + fg * 4);
+                    lw[i][0] = w4.x; lw[i][1] = w4.y; lw[i][2] = w4.z; lw[i][3] = w4.w;
+                    lb[i][0] = b4.x; lb[i][1] = b4.y; lb[i][2] = b4.z; lb[i][3] = b4.w;
+                }
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) store_frag<EPI>(g, acc[i][j], m0 + wm * 128 + j * 16 + fr, n, bn);
+            for (int j = 0; j < 8; ++j) {
+                const int m = m0 + wm * 128 + j * 16 + fr;
+                const bool valid = m < g.M;
+                const int mm = valid ? m : g.M - 1;
+                const int b = mm / g.L, l = mm - b * g.L, pos = g.pos0 + l;
+                const int64_t bh = (int64_t)b * g.nH + head;
+                float x[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
+                if (which == 2) {  // V^T[bh][d][pos]
+                    if (valid) {
+                        bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = f2bf(x[i][r]);
+                    }
+                    continue;
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.0f / 64.0f);
+                float sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[i][r] = x[i][r] * rstd * lw[i][r] + lb[i][r];
+                // partial rotary over dims [0, 32): rotate_half pairs d with d + 16 = fragments i = 0 and 1 of this lane
+                const float4 c0 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + fg * 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + fg * 4);
+                const float4 c1 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + 16 + fg * 4);
+                const float4 s1 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + 16 + fg * 4);
+                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, ss0[4] = {s0.x, s0.y, s0.z, s0.w};
+                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = x[0][r], y1 = x[1][r];
+                    x[0][r] = y0 * cc0[r] - y1 * ss0[r];
+                    x[1][r] = y1 * cc1[r] + y0 * ss1[r];
+                }
+                if (!valid) continue;
+                const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact in bf16)
+                bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + pos) * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint2 pk;
+                    pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
+                    pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
+                    *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) store_frag<EPI>(g, acc[i][j], m0 + wm * 128 + j * 16 + fr, n, bn);
+        }
     }
 #undef bar_raw
 #undef P3_TILE
@@ -919,6 +1013,29 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
         return dispatch2(g, lp, epilogue, (hipStream_t)stream);
     }
     return dispatch(g, ld, epilogue, (hipStream_t)stream);
+}
+
+// fused QKV projection: Q/K/V^T = relayout(rope(layernorm(A Wqkv^T + b)))  (reference models/phi.py:657-694)
+extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias,
+                                   const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                   const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B,
+                                   int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream) {
+    const int M = B * L, N = 3 * nH * 64, Kd = nH * 64;
+    if (M <= 0) return 0;
+    if (rot != 32) return set_error_msg(1, "gemm_qkv: the fused epilogue implements rotary_dim 32 (use showo_gemm_bf16 + showo_qk_prep)");
+    if ((Lp % 64) || Lp < pos0 + L || Lcap < pos0 + L) return set_error_msg(1, "gemm_qkv: bad Lp/Lcap");
+    if ((lda % 8) || (ldw % 8) || (((uintptr_t)A) & 15) || (((uintptr_t)Wqkv) & 15))
+        return set_error_msg(1, "gemm_qkv: A/W must be 16B aligned with lda,ldw multiples of 8");
+    if ((int64_t)M * lda * 2 >= ((int64_t)1 << 32) || (int64_t)N * ldw * 2 >= ((int64_t)1 << 32))
+        return set_error_msg(1, "gemm_qkv: operand larger than 4 GiB");
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = Wqkv; g.ldw = ldw; g.Wlo = nullptr; g.bias = bias; g.bias_per_row = 0;
+    g.out = nullptr; g.ldo = 0; g.resid = nullptr; g.ldr = 0; g.M = M; g.N = N; g.K = Kd; g.vec_out = 1;
+    g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1; g.flags = 0; g.dbg = nullptr;
+    g.qw = qln_w; g.qb = qln_b; g.kw = kln_w; g.kb = kln_b; g.cosT = cos_tab; g.sinT = sin_tab;
+    g.Q = Q; g.Kd = K; g.Vt = Vt; g.L = L; g.nH = nH; g.pos0 = pos0; g.Lcap = Lcap; g.Lp = Lp; g.eps = eps;
+    ProfScope prof(PROF_GEMM, 2.0 * M * N * Kd, (hipStream_t)stream);
+    return launch3<EPI_QKV, 2>(g, (hipStream_t)stream);
 }
 
 extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, const float* resid, float* out,

@@ -181,6 +181,41 @@ def test_qk_prep(B, Lq, nH):
     assert (vt[..., Lq:] == 0).all()  # pad keys are zero (finite) by contract
 
 
+@pytest.mark.parametrize("B,Lq,nH,pos0", [(2, 27, 2, 0), (3, 387, 4, 0), (1, 300, 3, 0), (2, 5, 2, 40)])
+def test_fused_qkv_projection(B, Lq, nH, pos0):
+    """showo_gemm_qkv_bf16 = QKV GEMM whose epilogue does bias + q/k LayerNorm + partial RoPE + relayout.  Checked
+    against the oracle evaluated on the fp32 product of the bf16-rounded operands (one output rounding: 2^-8)."""
+    torch.manual_seed(B * 1000 + Lq)
+    H = nH * 64
+    h = torch.randn(B * Lq, H)
+    W = torch.randn(3 * H, H) * 0.05
+    bias = torch.randn(3 * H) * 0.1
+    qw, qb, kw, kb = torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05
+    cos, sin = _rope_tables()
+    Lcap = pos0 + Lq + 3
+    Lp = ((pos0 + Lq + 63) // 64) * 64
+    Q = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
+    K = torch.zeros((B, nH, Lcap, 64), dtype=torch.int16, device="cuda")
+    Vt = torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda")
+    L().call("showo_gemm_qkv_bf16", L().ptr(dev(to_bf16_bits(h))), H, L().ptr(dev(to_bf16_bits(W))), H, L().ptr(dev(bias)),
+             L().ptr(dev(qw)), L().ptr(dev(qb)), L().ptr(dev(kw)), L().ptr(dev(kb)), L().ptr(dev(cos)), L().ptr(dev(sin)),
+             L().ptr(Q), L().ptr(K), L().ptr(Vt), B, Lq, nH, 32, 1e-5, pos0, Lcap, Lp, S())
+    sync()
+    qkv = (bf16_round(h).double() @ bf16_round(W).double().T + bias.double()).float()
+    x = qkv.view(B, Lq, 3, nH, 64)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    cs, sn = cos[pos0:pos0 + Lq], sin[pos0:pos0 + Lq]
+    q = O.apply_partial_rope(O.layer_norm(q, qw, qb, 1e-5), cs, sn, 32) * 0.125
+    k = O.apply_partial_rope(O.layer_norm(k, kw, kb, 1e-5), cs, sn, 32)
+    assert (from_bf16_bits(Q).cpu() - q).abs().max() < 2 ** -8 * float(q.abs().max()) + 1e-5
+    Kc = from_bf16_bits(K).cpu()
+    assert (Kc[:, :, pos0:pos0 + Lq] - k).abs().max() < 2 ** -8 * float(k.abs().max()) + 1e-5
+    assert (Kc[:, :, :pos0] == 0).all() and (Kc[:, :, pos0 + Lq:] == 0).all()  # only the new rows are written
+    vt = from_bf16_bits(Vt).cpu()
+    assert (vt[..., pos0:pos0 + Lq] - v.transpose(2, 3)).abs().max() < 2 ** -8 * float(v.abs().max()) + 1e-5
+    assert (vt[..., :pos0] == 0).all() and (vt[..., pos0 + Lq:] == 0).all()
+
+
 def _attn(Q, K, Vt, B, nH, Lq, Lk, mask=None, causal=False, Lcap=None):
     Lp = Vt.shape[-1]
     Lcap = Lcap or K.shape[2]
