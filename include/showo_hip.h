@@ -63,7 +63,8 @@ int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, cons
                     void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, void* stream);
 
 /* kernel selection for tests/benchmarks: 0 = by shape (default), 1 = 128x128 register-staged, 2 = 256x256 global_load_lds,
- * 3 = 256x256 phase-split (4 phases per k-tile), 4 = 256x256 phase-split (2 phases per k-tile; default for M >= 1024) */
+ * 3 = 256x256 phase-split (4 phases per k-tile), 4 = 256x256 phase-split (2 phases per k-tile),
+ * 5 = production 2-phase kernel with a per-launch tile height (256 / 208 rows; default for M >= 1024) */
 int showo_gemm_set_impl(int impl);
 /* development knobs of the 256^2 phase-split kernel (impl 3), used by tools/gemm_bench.cpp: gn = weight panels per
  * tile group of the block->tile map, flags bit0 = run the two wave groups without the one-barrier stagger,

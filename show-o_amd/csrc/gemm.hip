@@ -565,6 +565,107 @@ __device__ __forceinline__ void bar_raw_fn() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
+// the wave's m range, n0 + wn*64 = its first column.
+template <int EPI, int MF>
+__device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg) {
+    if constexpr (EPI == EPI_QKV) {
+        // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
+        // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
+        // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
+        const int nbase = n0 + wn * 64;
+        if (nbase < g.N) {
+            const int Hq = g.nH * 64;
+            const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)
+            const int head = (nbase - which * Hq) >> 6;
+            float bn[4][4], lw[4][4], lb[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                load_bias4(g, nbase + i * 16 + fg * 4, bn[i]);
+                if (which < 2) {
+                    const float4 w4 = *reinterpret_cast<const float4*>((which ? g.kw : g.qw) + i * 16 + fg * 4);
+                    const float4 b4 = *reinterpret_cast<const float4*>((which ? g.kb : g.qb) + i * 16 + fg * 4);
+                    lw[i][0] = w4.x; lw[i][1] = w4.y; lw[i][2] = w4.z; lw[i][3] = w4.w;
+                    lb[i][0] = b4.x; lb[i][1] = b4.y; lb[i][2] = b4.z; lb[i][3] = b4.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = mrow0 + j * 16 + fr;
+                const bool valid = m < g.M;
+                const int mm = valid ? m : g.M - 1;
+                const int b = mm / g.L, l = mm - b * g.L, pos = g.pos0 + l;
+                const int64_t bh = (int64_t)b * g.nH + head;
+                float x[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
+                if (which == 2) {  // V^T[bh][d][pos]
+                    if (valid) {
+                        bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = f2bf(x[i][r]);
+                    }
+                    continue;
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.0f / 64.0f);
+                float sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[i][r] = x[i][r] * rstd * lw[i][r] + lb[i][r];
+                // partial rotary over dims [0, 32): rotate_half pairs d with d + 16 = fragments i = 0 and 1 of this lane
+                const float4 c0 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + fg * 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + fg * 4);
+                const float4 c1 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + 16 + fg * 4);
+                const float4 s1 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + 16 + fg * 4);
+                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, ss0[4] = {s0.x, s0.y, s0.z, s0.w};
+                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = x[0][r], y1 = x[1][r];
+                    x[0][r] = y0 * cc0[r] - y1 * ss0[r];
+                    x[1][r] = y1 * cc1[r] + y0 * ss1[r];
+                }
+                if (!valid) continue;
+                const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact in bf16)
+                bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + pos) * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint2 pk;
+                    pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
+                    pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
+                    *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) store_frag<EPI>(g, acc[i][j], mrow0 + j * 16 + fr, n, bn);
+        }
+    }
+}
+
 // ABL (timing ablations, results are garbage): bit0 = no ds_read in the loop, bit1 = no DMA in the loop, bit2 = no barriers
 template <int EPI, int PH, bool DBG, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs g) {
@@ -804,101 +905,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs g) {
         if (blockIdx.x == 0 && g.dbg) g.dbg[tid] = dbgl[lane];
     }
 
-    if constexpr (EPI == EPI_QKV) {
-        // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
-        // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
-        // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
-        const int nbase = n0 + wn * 64;
-        if (nbase < g.N) {
-            const int Hq = g.nH * 64;
-            const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)
-            const int head = (nbase - which * Hq) >> 6;
-            float bn[4][4], lw[4][4], lb[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                load_bias4(g, nbase + i * 16 + fg * 4, bn[i]);
-                if (which < 2) {
-                    const float4 w4 = *reinterpret_cast<const float4*>((which ? g.kw : g.qw) + i * 16 + fg * 4);
-                    const float4 b4 = *reinterpret_cast<const float4*>((which ? g.kb : g.qb) + i * 16 + fg * 4);
-                    lw[i][0] = w4.x; lw[i][1] = w4.y; lw[i][2] = w4.z; lw[i][3] = w4.w;
-                    lb[i][0] = b4.x; lb[i][1] = b4.y; lb[i][2] = b4.z; lb[i][3] = b4.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = m0 + wm * 128 + j * 16 + fr;
-                const bool valid = m < g.M;
-                const int mm = valid ? m : g.M - 1;
-                const int b = mm / g.L, l = mm - b * g.L, pos = g.pos0 + l;
-                const int64_t bh = (int64_t)b * g.nH + head;
-                float x[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
-                if (which == 2) {  // V^T[bh][d][pos]
-                    if (valid) {
-                        bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = f2bf(x[i][r]);
-                    }
-                    continue;
-                }
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
-                const float mean = sum * (1.0f / 64.0f);
-                float sq = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
-                const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[i][r] = x[i][r] * rstd * lw[i][r] + lb[i][r];
-                // partial rotary over dims [0, 32): rotate_half pairs d with d + 16 = fragments i = 0 and 1 of this lane
-                const float4 c0 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + fg * 4);
-                const float4 s0 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + fg * 4);
-                const float4 c1 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + 16 + fg * 4);
-                const float4 s1 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + 16 + fg * 4);
-                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, ss0[4] = {s0.x, s0.y, s0.z, s0.w};
-                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float y0 = x[0][r], y1 = x[1][r];
-                    x[0][r] = y0 * cc0[r] - y1 * ss0[r];
-                    x[1][r] = y1 * cc1[r] + y0 * ss1[r];
-                }
-                if (!valid) continue;
-                const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact in bf16)
-                bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + pos) * 64;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint2 pk;
-                    pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
-                    pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
-                    *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fg * 4;
-            float bn[4];
-            load_bias4(g, n, bn);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) store_frag<EPI>(g, acc[i][j], m0 + wm * 128 + j * 16 + fr, n, bn);
-        }
-    }
+    epilogue8p<EPI, 8>(g, acc, n0, wn, m0 + wm * 128, fr, fg);
 #undef bar_raw
 #undef P3_TILE
 #undef P2_TILE
@@ -957,6 +964,237 @@ int dispatch3(GemmArgs g, int epilogue, hipStream_t s) {
     return set_error_msg(1, "gemm: unknown epilogue");
 }
 
+// =====================================================================================================
+// Production form of the 2-phase kernel with a selectable tile HEIGHT: the two wave groups own MF0 and MF1 16-row
+// m-fragments (tile = 16 (MF0 + MF1) rows x 256 columns; 8+8 = 256, 7+6 = 208, 5+5 = 160).  A launch is
+// rounds x tile-time long, rounds = ceil(tiles / 256 CUs): at M = 6192 the 256-row tile leaves 22 % of the chip idle
+// in the last round of every projection (200, 600, 800 tiles), the 208-row tile gives 240 / 720 / 960.
+//   tile rows: group 0 = [0, 16 MF0), group 1 = [16 MF0, 16 (MF0 + MF1)).
+//   "lo" rows of a group = its first 4 fragments (ph0), "hi" rows = the rest (ph1).
+//   DMA pieces (8 rows each): W 32 (4 per wave), A-lo 16 (2 per wave), A-hi 2 (MF0 + MF1 - 8) <= 16: every wave issues two
+//   hi pieces (index wave and wave + 8, wrapped onto an existing piece when there are fewer), so the vmcnt counts are
+//   the same for all waves.
+// Schedule, hazards and LDS image: see the phase-split kernel above (PH = 2 form).
+// =====================================================================================================
+template <int EPI, int MF0, int MF1>
+__global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
+    static_assert(MF0 >= 5 && MF0 <= 8 && MF1 >= 5 && MF1 <= 8, "each group needs 4 lo fragments and 1..4 hi fragments");
+    constexpr int BMT = 16 * (MF0 + MF1);
+    constexpr int NHI = 2 * (MF0 - 4) + 2 * (MF1 - 4);  // hi pieces
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int tn, tm;
+    {
+        const int per = g.gn * tilesM;
+        const int grp = bid / per, rem = bid - grp * per;
+        const int first = grp * g.gn;
+        const int gsz = min(tilesN - first, g.gn);
+        tm = rem / gsz;
+        tn = first + (rem - tm * gsz);
+    }
+    const int m0 = tm * BMT, n0 = tn * B2;
+    const int nk = g.K / BK;
+    const int wn = wave & 3, wm = wave >> 2;
+    const int gbase = wm * 16 * MF0;  // first tile row of this wave's group
+
+    // ---- DMA roles (byte offsets from the operand base; LDS destinations are wave-uniform)
+    const int srow = lane >> 3;
+    const int coff = ((lane & 7) ^ srow) << 3;
+    uint32_t woff[2][2], alo[2], ahi[2];
+    int hirow[2];  // tile row base of this wave's two hi pieces
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int n = n0 + h * 128 + i * 64 + wave * 8 + srow;
+            n = n < g.N ? n : g.N - 1;
+            woff[h][i] = (uint32_t)(((int64_t)n * g.ldw + coff) * 2);
+        }
+        int m = m0 + h * 16 * MF0 + wave * 8 + srow;  // lo piece `wave` of group h
+        m = m < g.M ? m : g.M - 1;
+        alo[h] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
+        int p = wave + 8 * h;
+        p = p < NHI ? p : p % NHI;
+        hirow[h] = p < 2 * (MF0 - 4) ? 64 + 8 * p : 16 * MF0 + 64 + 8 * (p - 2 * (MF0 - 4));
+        m = m0 + hirow[h] + srow;
+        m = m < g.M ? m : g.M - 1;
+        ahi[h] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
+    }
+    const char* wbase = reinterpret_cast<const char*>(g.W);
+    const char* abase = reinterpret_cast<const char*>(g.A);
+    constexpr int AOFF = 2 * 256 * 64;  // LDS (elements): W[buf][256][64] at 0, A[buf][256][64] behind it
+#define Q2_DMA_W(BUF, K0)                                                                                         \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                          \
+            glds16(reinterpret_cast<const bf16_t*>(wbase + (size_t)(K0) * 2 + (size_t)woff[h_][i_]),              \
+                   smem + (BUF) * 256 * 64 + (h_ * 128 + i_ * 64 + wave * 8) * 64)
+#define Q2_DMA_ALO(BUF, K0)                                                                                       \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                              \
+        glds16(reinterpret_cast<const bf16_t*>(abase + (size_t)(K0) * 2 + (size_t)alo[h_]),                       \
+               smem + AOFF + (BUF) * 256 * 64 + (h_ * 16 * MF0 + wave * 8) * 64)
+#define Q2_DMA_AHI(BUF, K0)                                                                                       \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                              \
+        glds16(reinterpret_cast<const bf16_t*>(abase + (size_t)(K0) * 2 + (size_t)ahi[h_]),                       \
+               smem + AOFF + (BUF) * 256 * 64 + hirow[h_] * 64)
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int lsw0 = fr * 64 + ((fg ^ (fr & 7)) << 3);
+    const int lsw1 = fr * 64 + (((fg + 4) ^ (fr & 7)) << 3);
+    const bf16_t* ldsW = smem + (wn * 64) * 64;
+    const bf16_t* ldsA = smem + AOFF + gbase * 64;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[2][4], af[2][4];
+
+#define Q2_READ_W(BUF)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        wf[0][i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * 256 * 64 + i * 16 * 64 + lsw0);                \
+        wf[1][i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * 256 * 64 + i * 16 * 64 + lsw1);                \
+    }
+#define Q2_READ_A(BUF, MB, CNT)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < (CNT); ++j) {                                                           \
+        af[0][j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * 256 * 64 + ((MB) + j) * 16 * 64 + lsw0);       \
+        af[1][j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * 256 * 64 + ((MB) + j) * 16 * 64 + lsw1);       \
+    }
+#define Q2_MFMA(MB, CNT)                                                                                          \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < (CNT); ++j)                                                 \
+                    acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[kk][j], acc[i][(MB) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+#define Q2_TILE(BUF, T)                                                                                           \
+    do {                                                                                                          \
+        const int kN = ((T) + 1) * BK;                                                                            \
+        const bool has1 = (T) + 1 < nk;                                                                           \
+        /* ph0: all W fragments + the 4 lo A fragments */                                                         \
+        Q2_READ_W(BUF)                                                                                            \
+        Q2_READ_A(BUF, 0, 4)                                                                                      \
+        if (has1) {                                                                                               \
+            Q2_DMA_W((BUF) ^ 1, kN);                                                                              \
+            Q2_DMA_ALO((BUF) ^ 1, kN);                                                                            \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); /* retires the hi pieces of this tile */             \
+        } else {                                                                                                  \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        }                                                                                                         \
+        bar_raw_fn();                                                                                             \
+        Q2_MFMA(0, 4);                                                                                            \
+        bar_raw_fn();                                                                                             \
+        /* ph1: the hi A fragments of this group */                                                               \
+        if (MF0 == MF1 || wm == 0) { Q2_READ_A(BUF, 4, MF0 - 4) } else { Q2_READ_A(BUF, 4, MF1 - 4) }             \
+        if (has1) {                                                                                               \
+            Q2_DMA_AHI((BUF) ^ 1, kN);                                                                            \
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); /* retires W + A-lo of tile T+1 */                   \
+        } else {                                                                                                  \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        }                                                                                                         \
+        bar_raw_fn();                                                                                             \
+        if (MF0 == MF1 || wm == 0) Q2_MFMA(4, MF0 - 4); else Q2_MFMA(4, MF1 - 4);                                 \
+        bar_raw_fn();                                                                                             \
+    } while (0)
+
+    // ---- prologue: all of tile 0
+    Q2_DMA_W(0, 0);
+    Q2_DMA_ALO(0, 0);
+    Q2_DMA_AHI(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar_raw_fn();
+    if (wm == 1) bar_raw_fn();  // group 1 runs one barrier behind group 0
+
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        Q2_TILE(0, t);
+        Q2_TILE(1, t + 1);
+    }
+    if (t < nk) Q2_TILE(0, t);
+    if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
+
+    if (MF0 == MF1 || wm == 0) epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg);
+    else epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg);
+#undef Q2_TILE
+#undef Q2_MFMA
+#undef Q2_READ_A
+#undef Q2_READ_W
+#undef Q2_DMA_AHI
+#undef Q2_DMA_ALO
+#undef Q2_DMA_W
+}
+
+template <int EPI, int MF0, int MF1>
+int launch2p(const GemmArgs& g, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = gemm2p_kernel<EPI, MF0, MF1>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_BYTES);
+        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm2p)", __FILE__, __LINE__);
+        attr_set = true;
+    }
+    constexpr int BMT = 16 * (MF0 + MF1);
+    int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
+    kfn<<<dim3(tilesM * tilesN), dim3(512), SMEM3_BYTES, s>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "gemm2p launch", __FILE__, __LINE__);
+    return 0;
+}
+
+int g_gemm_bm = 0;  // 0 = choose the tile height per launch; 256 / 208 / 160 = force
+// tile height that minimises rounds x height (rounds = ceil(tiles / CUs)); ties go to the taller tile
+int pick_bm(int M, int N) {
+    if (g_gemm_bm == 256 || g_gemm_bm == 208 || g_gemm_bm == 160) return g_gemm_bm;
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    const int cand[3] = {256, 208, 160};
+    const int tilesN = (N + B2 - 1) / B2;
+    int best = 256;
+    long bestc = -1;
+    for (int c : cand) {
+        long tiles = (long)((M + c - 1) / c) * tilesN;
+        long cost = ((tiles + cus - 1) / cus) * c;
+        if (bestc < 0 || cost < bestc) { bestc = cost; best = c; }
+    }
+    return best;
+}
+
+template <int EPI>
+int launch2p_bm(const GemmArgs& g, hipStream_t s) {
+    switch (pick_bm(g.M, g.N)) {
+        case 208: return launch2p<EPI, 7, 6>(g, s);
+        case 160: return launch2p<EPI, 5, 5>(g, s);
+    }
+    return launch2p<EPI, 8, 8>(g, s);
+}
+
+int dispatch2p(GemmArgs g, int epilogue, hipStream_t s) {
+    g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
+    g.flags = 0;
+    g.dbg = nullptr;
+    switch (epilogue) {
+        case SHOWO_EPI_BF16: return launch2p_bm<SHOWO_EPI_BF16>(g, s);
+        case SHOWO_EPI_GELU_BF16: return launch2p_bm<SHOWO_EPI_GELU_BF16>(g, s);
+        case SHOWO_EPI_F32: return launch2p_bm<SHOWO_EPI_F32>(g, s);
+        case SHOWO_EPI_RESID_F32: return launch2p_bm<SHOWO_EPI_RESID_F32>(g, s);
+    }
+    return set_error_msg(1, "gemm: unknown epilogue");
+}
+
 // 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel, 0 = pick by shape
 int g_gemm_forced = -1;
 int gemm_impl_choice(int M, int N) {
@@ -964,22 +1202,23 @@ int gemm_impl_choice(int M, int N) {
         const char* e = getenv("SHOWO_GEMM_IMPL");
         g_gemm_forced = e ? atoi(e) : 0;
     }
-    if (g_gemm_forced >= 1 && g_gemm_forced <= 4) return g_gemm_forced;
-    return (M >= 1024 && N >= 256) ? 4 : 1;
+    if (g_gemm_forced >= 1 && g_gemm_forced <= 5) return g_gemm_forced;
+    return (M >= 1024 && N >= 256) ? 5 : 1;
 }
 
 }  // namespace
 
 // 0 = choose by shape (default), 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel
 extern "C" int showo_gemm_set_impl(int impl) {
-    g_gemm_forced = (impl >= 1 && impl <= 4) ? impl : 0;
+    g_gemm_forced = (impl >= 1 && impl <= 5) ? impl : 0;
     return 0;
 }
 
 // experiment knobs of the v3 kernel (tools/gemm_bench.cpp): gn = n-panels per tile group, flags bit0 = no stagger,
 // dbg = device buffer of 512 uint64 receiving block 0's per-barrier timestamps of k-tiles 8 and 9 (bf16 epilogue only)
 extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
-    g_gemm_gn = gn; g_gemm_flags = flags; g_gemm_dbg = dbg;
+    g_gemm_gn = gn; g_gemm_flags = flags & 0xff; g_gemm_dbg = dbg;
+    g_gemm_bm = flags >> 8;  // impl 5: tile height 256 / 208 / 160 (0 = automatic)
     return 0;
 }
 
@@ -1007,6 +1246,7 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     if (impl >= 3 && ((int64_t)M * lda * 2 >= ((int64_t)1 << 32) || (int64_t)N * ldw * 2 >= ((int64_t)1 << 32))) impl = 2;
     if (impl == 3) return dispatch3<4>(g, epilogue, (hipStream_t)stream);
     if (impl == 4) return dispatch3<2>(g, epilogue, (hipStream_t)stream);
+    if (impl == 5) return dispatch2p(g, epilogue, (hipStream_t)stream);
     if (impl == 2) {
         LinearPtr lp;
         lp.A = A; lp.lda = lda; lp.M = M;
@@ -1035,7 +1275,7 @@ extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* W
     g.qw = qln_w; g.qb = qln_b; g.kw = kln_w; g.kb = kln_b; g.cosT = cos_tab; g.sinT = sin_tab;
     g.Q = Q; g.Kd = K; g.Vt = Vt; g.L = L; g.nH = nH; g.pos0 = pos0; g.Lcap = Lcap; g.Lp = Lp; g.eps = eps;
     ProfScope prof(PROF_GEMM, 2.0 * M * N * Kd, (hipStream_t)stream);
-    return launch3<EPI_QKV, 2>(g, (hipStream_t)stream);
+    return launch2p_bm<EPI_QKV>(g, (hipStream_t)stream);
 }
 
 extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, const float* resid, float* out,

@@ -505,13 +505,14 @@ def test_softmax_rows_and_small_conv():
     assert (out.cpu() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("impl", [1, 2, 3, 4])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5, 5 + (256 << 16), 5 + (208 << 16), 5 + (160 << 16)])
 def test_gemm_both_tile_kernels(impl):
     """the 128^2 register-staged kernel and the 256^2 global_load_lds kernel give the same result on shapes
     with ragged M/N edges (rows/cols beyond the edge are clamped on load and predicated on store)"""
-    L().call("showo_gemm_set_impl", impl)
+    L().call("showo_gemm_set_impl", impl & 0xffff)
+    L().call("showo_gemm_tune", 8, (impl >> 16) << 8, None)  # impl 5: forced tile height 256 / 208 / 160 (0 = automatic)
     try:
-        torch.manual_seed(impl)
+        torch.manual_seed(impl & 0xffff)
         for (M, N, K) in [(1100, 520, 192), (6192 // 4, 2048, 256), (300, 256, 64)]:
             A, W, bias = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N)
             ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double()
@@ -525,6 +526,7 @@ def test_gemm_both_tile_kernels(impl):
             assert (got.double() - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-3 * float(ref.abs().max())
     finally:
         L().call("showo_gemm_set_impl", 0)
+        L().call("showo_gemm_tune", 8, 0, None)
 
 
 # ------------------------------------------------------------------------------------ split-precision (bf16 x3) kernels

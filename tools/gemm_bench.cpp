@@ -38,13 +38,13 @@ struct Shape { int M, N, K, epi; const char* name; };
 
 int main(int argc, char** argv) {
     // variants: "impl[:gn[:flags]]" separated by ','  e.g.  2,3:1,3:4,3:8,3:4:1
-    struct Var { int impl, gn, flags; };
-    std::vector<Var> impls = {{2, 1, 0}, {3, 4, 0}};
+    struct Var { int impl, gn, flags, bm; };
+    std::vector<Var> impls = {{4, 8, 0, 0}, {5, 8, 0, 0}};
     if (argc > 1) {
         impls.clear();
         for (char* t = strtok(argv[1], ","); t; t = strtok(nullptr, ",")) {
-            Var v{0, 4, 0};
-            sscanf(t, "%d:%d:%d", &v.impl, &v.gn, &v.flags);
+            Var v{0, 8, 0, 0};
+            sscanf(t, "%d:%d:%d:%d", &v.impl, &v.gn, &v.flags, &v.bm);
             impls.push_back(v);
         }
     }
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
         {300, 256, 64, 2, "edge-small"}, {1100, 520, 192, 2, "edge-ragged"}, {1548, 2048, 256, 3, "ragged-resid"},
         {6192, 6144, 2048, 0, "qkv"}, {6192, 2048, 2048, 3, "dense"}, {6192, 8192, 2048, 1, "fc1+gelu"},
         {6192, 2048, 8192, 3, "fc2"}, {4096, 8192, 2048, 2, "lm_head rows"}, {6192, 14336, 2048, 0, "qkv|fc1 fused"},
-        {6192, 2048, 10240, 3, "dense|fc2 fused"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
+        {6192, 2048, 10240, 3, "dense|fc2 fused"}, {9240, 6144, 2048, 0, "qkv L1155"}, {9240, 2048, 8192, 3, "fc2 L1155"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
     };
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -78,11 +78,11 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         auto run = [&](Var v, void* o, int r) {
             RC(showo_gemm_set_impl(v.impl));
-            RC(showo_gemm_tune(v.gn, v.flags, nullptr));
+            RC(showo_gemm_tune(v.gn, v.flags | (v.bm << 8), nullptr));
             // in-place residual like the engine when epi == 3: resid := o would accumulate across repeats, so use `resid`
             RC(showo_gemm_bf16(A, s.K, W + (size_t)r * nW, s.K, bias, 0, o, s.N, s.epi == 3 ? resid : nullptr, s.N, s.M, s.N, s.K, s.epi, st));
         };
-        run(Var{1, 1, 0}, out_ref, 0);
+        run(Var{1, 1, 0, 0}, out_ref, 0);
         CK(hipStreamSynchronize(st));
         std::vector<float> href(f32 ? nO : 0); std::vector<uint16_t> hrefb(f32 ? 0 : nO);
         if (f32) CK(hipMemcpy(href.data(), out_ref, nO * 4, hipMemcpyDeviceToHost)); else CK(hipMemcpy(hrefb.data(), out_ref, nO * 2, hipMemcpyDeviceToHost));
@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             double tf = 2.0 * s.M * s.N * s.K * iters / (ms * 1e-3) / 1e12;
-            printf(" v%d:%d:%d %7.1f TF %6.3f ms %s|", impl.impl, impl.gn, impl.flags, tf, ms / iters, bad ? "**MISMATCH** " : "");
+            printf(" v%d:%d:%d:%d %7.1f TF %6.3f ms %s|", impl.impl, impl.gn, impl.flags, impl.bm, tf, ms / iters, bad ? "**MISMATCH** " : "");
             (void)maxd; (void)maxr;
             fflush(stdout);
         }
@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
             for (Var v : impls) {
                 if (v.impl < 3 || (v.flags >> 4)) continue;
                 RC(showo_gemm_set_impl(v.impl));
-                RC(showo_gemm_tune(v.gn, v.flags, dbgbuf));
+                RC(showo_gemm_tune(v.gn, v.flags | (v.bm << 8), dbgbuf));
                 CK(hipMemsetAsync(dbgbuf, 0, 512 * 8, st));
                 RC(showo_gemm_bf16(A, s.K, W, s.K, bias, 0, out, s.N, nullptr, s.N, s.M, s.N, s.K, 0, st));
                 CK(hipStreamSynchronize(st));
@@ -134,7 +134,7 @@ int main(int argc, char** argv) {
                     for (int i = 1; i < 16; ++i) printf(" %5lld", (long long)(h[w * 64 + i] - h[w * 64 + i - 1]));
                     printf("\n");
                 }
-                RC(showo_gemm_tune(v.gn, v.flags, nullptr));
+                RC(showo_gemm_tune(v.gn, v.flags | (v.bm << 8), nullptr));
             }
         }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(resid)); CK(hipFree(out_ref)); CK(hipFree(out));
