@@ -1154,6 +1154,10 @@ int launch2p(const GemmArgs& g, hipStream_t s) {
 int g_gemm_bm = 0;  // 0 = choose the tile height per launch; 256 / 208 / 160 = force
 // tile height that minimises rounds x height (rounds = ceil(tiles / CUs)); ties go to the taller tile
 int pick_bm(int M, int N) {
+    if (g_gemm_bm == 0) {  // SHOWO_GEMM_BM=256|208|160 forces a height (A/B runs of bench.py)
+        const char* e = getenv("SHOWO_GEMM_BM");
+        g_gemm_bm = e ? atoi(e) : -1;
+    }
     if (g_gemm_bm == 256 || g_gemm_bm == 208 || g_gemm_bm == 160) return g_gemm_bm;
     static int cus = 0;
     if (!cus) {
@@ -1218,7 +1222,7 @@ extern "C" int showo_gemm_set_impl(int impl) {
 // dbg = device buffer of 512 uint64 receiving block 0's per-barrier timestamps of k-tiles 8 and 9 (bf16 epilogue only)
 extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
     g_gemm_gn = gn; g_gemm_flags = flags & 0xff; g_gemm_dbg = dbg;
-    g_gemm_bm = flags >> 8;  // impl 5: tile height 256 / 208 / 160 (0 = automatic)
+    g_gemm_bm = (flags >> 8) ? (flags >> 8) : -1;  // impl 5: tile height 256 / 208 / 160 (0 = automatic)
     return 0;
 }
 
