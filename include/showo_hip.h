@@ -125,6 +125,28 @@ int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, con
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                    void* stream);
 
+/* Training forward: showo_attn_fwd that also writes lse fp32 [B, nH, Lq] = log sum_k exp(score) of every (masked) row. */
+int showo_attn_fwd_lse(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
+                       const float* dense_mask, uint16_t* O, float* lse, int B, int nH, int Lq, int Lk, int Lcap, int Lp,
+                       int ldo, void* stream);
+
+/* X rows [.., L, 64] (row r of (b, h) at x + b*batch_stride + h*head_stride + r*row_stride) -> XT bf16 [B, nH, 64, Lp]
+ * (columns >= L zero).  Makes the k-contiguous operand images (Q^T, K^T) of showo_attn_bwd. */
+int showo_head_transpose(const uint16_t* x, uint16_t* xt, int B, int nH, int L, int Lp, int64_t batch_stride,
+                         int64_t head_stride, int row_stride, void* stream);
+
+/* Backward of the fused attention (autograd of SDPA + mask, phi.py:715-722).  Self-attention, Lq = Lk = L, interval
+ * masks (iv from showo_mask_compress, NULL = causal; *flag must be 0).
+ * in : Q (pre-scaled), K bf16 [B,nH,L,64]; QT, KT bf16 [B,nH,64,Lp] (showo_head_transpose); V rows token-major (row
+ *      stride ldv, head h at column 64h: the v section of the raw qkv projection); O, dO bf16 token-major [B*L, lddo];
+ *      lse fp32 [B,nH,L] from showo_attn_fwd_lse.
+ * scratch: dOT bf16 [B,nH,64,Lp], D fp32 [B,nH,L].
+ * out: dQ (w.r.t. the pre-scaled Q), dK, dV bf16 token-major (row strides ldq/ldk/ldvo, head h at column 64h). */
+int showo_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* QT, const uint16_t* KT, const uint16_t* V, int ldv,
+                   const uint16_t* O, const uint16_t* dO, int lddo, uint16_t* dOT, const float* lse, float* D,
+                   const int32_t* iv, const int32_t* flag, uint16_t* dQ, int ldq, uint16_t* dK, int ldk, uint16_t* dV,
+                   int ldvo, int B, int nH, int L, int Lp, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * t2i sampler (reference models/modeling_showo.py:140-179, models/sampling.py:14-36)
  * ------------------------------------------------------------------------------------------- */

@@ -34,6 +34,10 @@ _PROTOS = {
     "showo_gemm_set_impl": [c_i],
     "showo_gemm_tune": [c_i, c_i, c_p],
     "showo_attn_set_impl": [c_i],
+    "showo_attn_fwd_lse": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_head_transpose": [c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_p],
+    "showo_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i,
+                       c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_bf16x3": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "showo_conv3x3_bf16x3": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],

@@ -155,6 +155,7 @@ struct AttnArgs {
     const float* dense;
     bf16_t* O;
     int B, nH, Lq, Lk, Lcap, Lp, ldo;
+    float* lse;  // optional (training): log-sum-exp of every score row, fp32 [B, nH, Lq]
 };
 
 __device__ inline bf16x8 pack8(const float* p) {
@@ -456,6 +457,7 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     if (!wactive) return;
     float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     float inv = 1.0f / l_tot;
+    if (a.lse && hh == 0 && qrow_raw < a.Lq) a.lse[bh * a.Lq + qrow_raw] = m_run + __logf(l_tot);
     if (qrow_raw < a.Lq) {
         bf16_t* op = a.O + ((int64_t)b * a.Lq + qrow_raw) * a.ldo + head * 64 + 4 * hh;
 #pragma unroll
@@ -513,22 +515,36 @@ extern "C" int showo_attn_set_impl(int impl) {
     return 0;
 }
 
-extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv,
-                              const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
-                              int Lcap, int Lp, int ldo, void* stream) {
+static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
+                         const float* dense_mask, uint16_t* O, float* lse, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
+                         void* stream) {
     if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
     if ((Lp % 64) || Lp < Lk || Lcap < Lk || (ldo % 4)) return set_error_msg(1, "attn: bad Lp/Lcap/ldo");
     AttnArgs a;
     a.Q = Q; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = flag; a.dense = dense_mask; a.O = O;
-    a.B = B; a.nH = nH; a.Lq = Lq; a.Lk = Lk; a.Lcap = Lcap; a.Lp = Lp; a.ldo = ldo;
+    a.B = B; a.nH = nH; a.Lq = Lq; a.Lk = Lk; a.Lcap = Lcap; a.Lp = Lp; a.ldo = ldo; a.lse = lse;
     int qblocks = (Lq + 31) / 32;
     ProfScope prof(PROF_ATTN, 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // dense QK^T + PV flops
     if (g_attn_forced < 0) { const char* e = getenv("SHOWO_ATTN_IMPL"); g_attn_forced = e ? atoi(e) : 0; }
     const int forced = g_attn_forced;  // 1 = gather form, 2 = LDS-tiled form, else by shape
-    const bool tiled = forced >= 2 || (forced != 1 && Lq >= 64);  // decode steps (a few query rows) keep the gather form
+    const bool tiled = lse != nullptr || forced >= 2 || (forced != 1 && Lq >= 64);  // only the tiled form writes lse  // decode steps (a few query rows) keep the gather form
     if (tiled && forced == 3) attn_fwd_lds_kernel<3><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     else if (tiled) attn_fwd_lds_kernel<4><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     else attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv,
+                              const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
+                              int Lcap, int Lp, int ldo, void* stream) {
+    return attn_fwd_impl(Q, K, Vt, iv, flag, dense_mask, O, nullptr, B, nH, Lq, Lk, Lcap, Lp, ldo, stream);
+}
+
+// training forward: additionally writes lse fp32 [B, nH, Lq] (natural-log sum of exp of the masked score row)
+extern "C" int showo_attn_fwd_lse(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv,
+                                  const int32_t* flag, const float* dense_mask, uint16_t* O, float* lse, int B, int nH, int Lq,
+                                  int Lk, int Lcap, int Lp, int ldo, void* stream) {
+    if (!lse) return set_error_msg(1, "attn_fwd_lse: lse is required");
+    return attn_fwd_impl(Q, K, Vt, iv, flag, dense_mask, O, lse, B, nH, Lq, Lk, Lcap, Lp, ldo, stream);
 }
