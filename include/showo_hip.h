@@ -148,6 +148,45 @@ int showo_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* QT, con
                    int ldvo, int B, int nH, int L, int Lp, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training kernels (autograd of the block + loss + optimizer; reference training/train.py:590-628).
+ * Every reduction is fixed-order (block partials + finalize): bit-reproducible gradients.
+ * ------------------------------------------------------------------------------------------- */
+/* X bf16 [T, C] (row stride ld) -> XT bf16 [C, Tp] (Tp % 64 == 0, columns >= T zero): the k-contiguous operand of the
+ * weight-gradient GEMMs dW = dY^T X.  mode 1 writes gelu_new(X)^T (the MLP activation from the saved pre-activation).
+ * colsum (optional, fp32 [C]): column sums of X = bias gradient (accumulate != 0 adds); colpart: scratch fp32 [Tp/64, C]. */
+int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int T, int C, int Tp, int mode, float* colpart, float* colsum,
+                         int accumulate, void* stream);
+/* LayerNorm backward fused with the residual add of the parallel block (phi.py:774-790): dx = dy + dLN(x)^T dh.
+ * x, dh, dy fp32 [T,H]; dx32 fp32 (may alias dy), dx16 bf16 copy (may be NULL); dgb fp32 [2,H] = (dgamma, dbeta);
+ * part: scratch fp32 [showo_ln_bwd_blocks(T), 2, H]. */
+int showo_ln_bwd(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16, float* part,
+                 float* dgb, int T, int H, float eps, void* stream);
+int showo_ln_bwd_blocks(int T);
+/* Backward of q/k LayerNorm(64) + partial rotary + the 1/8 fold (phi.py:661-694): dq, dk bf16 [T, ldg] (w.r.t. the stored Q,
+ * K), raw qkv bf16 [T, 3*nH*64] -> dqkv bf16 [T, 3*nH*64] (q and k sections), dparams fp32 [4,64] = (dq_ln_w, dq_ln_b,
+ * dk_ln_w, dk_ln_b); part: scratch fp32 [showo_qkln_rope_bwd_blocks(T, nH), 4, 64]. */
+int showo_qkln_rope_bwd(const uint16_t* dq, const uint16_t* dk, int ldg, const uint16_t* qkv, const float* qw, const float* kw,
+                        const float* cos_tab, const float* sin_tab, uint16_t* dqkv, float* part, float* dparams, int T, int L,
+                        int nH, int rot, float eps, void* stream);
+int showo_qkln_rope_bwd_blocks(int T, int nH);
+/* The three mean cross-entropies of Showo.forward (modeling_showo.py:80-98) and their gradient.
+ * logits fp32 [B*L, ldl]; labels int64 [B,L] (-100 = ignore).  losses fp32 [3] = (t2i, lm, mmu);
+ * dlogits (optional) bf16 [B*L, ldd] = d(g_t2i*loss_t2i + g_lm*loss_lm + g_mmu*loss_mmu)/dlogits, pad columns zero.
+ * scratch: rows_ws 12*B*L bytes, counts int[3], rowloss fp32 [2*B*L]. */
+int showo_ce_loss(const float* logits, int ldl, const int64_t* labels, int B, int L, int V, int b_t2i, int b_lm, int b_mmu,
+                  int max_seq_len, float g_t2i, float g_lm, float g_mmu, void* rows_ws, int* counts, float* rowloss,
+                  uint16_t* dlogits, int ldd, float* losses, void* stream);
+/* Embedding backward (deterministic): dE[ids[t]] = sum of dx[t] over equal ids, in position order.  dE must be
+ * zero-filled by the caller; order_ws: scratch int[2*T]. */
+int showo_embed_bwd(const int64_t* ids, const float* dx, float* dE, int* order_ws, int T, int H, int V, void* stream);
+/* torch.optim.AdamW step on fp32 tensors (step counts from 1). */
+int showo_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int step, void* stream);
+int showo_scale_f32(float* x, int64_t n, float s, void* stream);
+/* df = da * gelu_new'(f) (bf16, elementwise) */
+int showo_dgelu_bf16(const uint16_t* da, const uint16_t* f, uint16_t* df, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * t2i sampler (reference models/modeling_showo.py:140-179, models/sampling.py:14-36)
  * ------------------------------------------------------------------------------------------- */
 /* One categorical draw per image token from softmax((1+w)*cond - w*uncond) using the algorithm

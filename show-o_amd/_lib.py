@@ -34,6 +34,16 @@ _PROTOS = {
     "showo_gemm_set_impl": [c_i],
     "showo_gemm_tune": [c_i, c_i, c_p],
     "showo_attn_set_impl": [c_i],
+    "showo_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "showo_ln_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "showo_ln_bwd_blocks": [c_i],
+    "showo_qkln_rope_bwd": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "showo_qkln_rope_bwd_blocks": [c_i, c_i],
+    "showo_ce_loss": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "showo_embed_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "showo_adamw": [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
+    "showo_scale_f32": [c_p, c_i64, c_f, c_p],
+    "showo_dgelu_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "showo_attn_fwd_lse": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_head_transpose": [c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_p],
     "showo_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i,

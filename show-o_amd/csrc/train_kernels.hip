@@ -1,0 +1,529 @@
+// HBM-bound kernels of the training step for gfx950.
+// Replaces (reference): the autograd of LayerNorm / gelu_new / q,k LayerNorm + rotary / embedding / cross-entropy that
+// loss.backward() runs (training/train.py:612; forward definitions models/phi.py:208-212, 661-694, 774-790,
+// models/modeling_showo.py:80-98) and torch.optim.AdamW.step (training/train.py:225-231, 617).
+// All reductions are fixed-order (per-block partials + a finalize pass): the same inputs give the same bits.
+#include "common.h"
+#include "../../include/showo_hip.h"
+
+using namespace showo;
+
+namespace {
+
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+// d/dx [0.5 x (1 + tanh(u))],  u = c (x + 0.044715 x^3)
+__device__ __forceinline__ float gelu_new_grad(float x) {
+    const float c = 0.7978845608028654f;
+    const float u = c * (x + 0.044715f * x * x * x);
+    const float t = tanhf(u);
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// X bf16 [T, C] (row stride ld) -> XT bf16 [C, Tp] (columns >= T zero).  mode 1: XT = gelu_new(X)^T.
+// colpart (optional): fp32 [gridDim.y, C] per-row-block column sums of X (bias gradients), summed by colsum_finalize.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ xt, float* __restrict__ colpart,
+                                                        int T, int C, int ld, int Tp, int mode) {
+    __shared__ bf16_t t[64][66];
+    __shared__ float cs[4][64];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+    {
+        const int r = tid >> 2, cq = (tid & 3) * 16;  // row r, 16 columns
+        float v[16];
+        const bool rok = t0 + r < T;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (rok && c0 + cq + 8 * h < C) u = *reinterpret_cast<const uint4*>(x + (int64_t)(t0 + r) * ld + c0 + cq + 8 * h);
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[8 * h + j] = bf2f(e[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float w = v[j];
+            if (mode == 1) w = rok ? gelu_new_f(w) : 0.f;
+            t[r][cq + j] = f2bf(w);
+        }
+    }
+    __syncthreads();
+    if (colpart) {  // column sums of the (untransformed) tile, fixed order: 4 partial sums of 16 rows, then 4 -> 1
+        const int c = tid & 63, part = tid >> 6;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += bf2f(t[part * 16 + r][c]);
+        cs[part][c] = s;
+    }
+    {
+        const int c = tid >> 2, ts = (tid & 3) * 16;
+        if (c0 + c < C) {
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (uint32_t)t[ts + 2 * j][c] | ((uint32_t)t[ts + 2 * j + 1][c] << 16);
+            uint4* o = reinterpret_cast<uint4*>(xt + (int64_t)(c0 + c) * Tp + t0 + ts);
+            o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
+    if (colpart) {
+        __syncthreads();
+        if (tid < 64 && c0 + tid < C) colpart[(int64_t)blockIdx.y * C + c0 + tid] = (cs[0][tid] + cs[1][tid]) + (cs[2][tid] + cs[3][tid]);
+    }
+}
+// out[c] (+)= sum over blocks of part[blk][c], in block order
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part[(int64_t)k * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward fused with the residual add of the parallel block (y = x + f(LN(x)), phi.py:774-790):
+//   dx = dy + LN'(x)^T dh.   One wave per row; a block walks LNB_ROWS rows and keeps per-lane column partials of
+//   dgamma / dbeta, written as part[blk][2][H].  dx goes to dx32 (may alias dy) and, rounded, to dx16 (GEMM operand).
+// ------------------------------------------------------------------------------------------------
+constexpr int LNB_ROWS = 32;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dh, const float* dy, float* dx32,
+                                                     bf16_t* __restrict__ dx16, float* __restrict__ part, int T, int H, float eps) {
+    extern __shared__ float red[];  // [4][2][H] cross-wave reduction of the column partials
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = H / 256;  // float4 groups per lane (H % 256 == 0)
+    float ag[8][4], ab[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+    const int r0 = blockIdx.x * LNB_ROWS;
+    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+        const int r = r0 + rr;
+        if (r >= T) break;
+        const float* xr = x + (int64_t)r * H;
+        const float* gr = dh + (int64_t)r * H;
+        float4 xv[8], gv[8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nv) {
+                xv[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+                s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+            }
+        const float mean = wave_sum(s) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nv) {
+                xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+                q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+        float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dh * gamma
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 d = *reinterpret_cast<const float4*>(gr + c);
+                const float4 w = *reinterpret_cast<const float4*>(gamma + c);
+                xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;  // xhat
+                ag[i][0] += d.x * xv[i].x; ag[i][1] += d.y * xv[i].y; ag[i][2] += d.z * xv[i].z; ag[i][3] += d.w * xv[i].w;
+                ab[i][0] += d.x; ab[i][1] += d.y; ab[i][2] += d.z; ab[i][3] += d.w;
+                gv[i] = make_float4(d.x * w.x, d.y * w.y, d.z * w.z, d.w * w.w);
+                s1 += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+                s2 += (gv[i].x * xv[i].x + gv[i].y * xv[i].y) + (gv[i].z * xv[i].z + gv[i].w * xv[i].w);
+            }
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                float4 o = *reinterpret_cast<const float4*>(dy + (int64_t)r * H + c);
+                o.x += rstd * (gv[i].x - m1 - xv[i].x * m2);
+                o.y += rstd * (gv[i].y - m1 - xv[i].y * m2);
+                o.z += rstd * (gv[i].z - m1 - xv[i].z * m2);
+                o.w += rstd * (gv[i].w - m1 - xv[i].w * m2);
+                *reinterpret_cast<float4*>(dx32 + (int64_t)r * H + c) = o;
+                if (dx16) {
+                    uint2 pk;
+                    pk.x = pack_bf2(o.x, o.y);
+                    pk.y = pack_bf2(o.z, o.w);
+                    *reinterpret_cast<uint2*>(dx16 + (int64_t)r * H + c) = pk;
+                }
+            }
+    }
+    // block partials: red[wave][0|1][c]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[(wave * 2 + 0) * H + c + j] = ag[i][j];
+                red[(wave * 2 + 1) * H + c + j] = ab[i][j];
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 256) {
+        const int which = c / H, col = c - which * H;
+        const float v = (red[(0 * 2 + which) * H + col] + red[(1 * 2 + which) * H + col]) +
+                        (red[(2 * 2 + which) * H + col] + red[(3 * 2 + which) * H + col]);
+        part[((int64_t)blockIdx.x * 2 + which) * H + col] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of q/k LayerNorm(64) + partial rotary (rotary_dim 32) + the 1/8 fold of Q (phi.py:661-694).
+//   in : dq, dk bf16 token-major [T, ldg] (gradients w.r.t. the STORED Q (= rope(ln(q)) / 8) and K), raw qkv bf16 [T, 3H]
+//   out: dqkv bf16 [T, 3H] q and k sections (the v section is written by the attention backward);
+//        part[blk][4][64] = per-block partials of (dqln_w, dqln_b, dkln_w, dkln_b).
+//   One wave per (token, head) row, lane = head dim.
+// ------------------------------------------------------------------------------------------------
+constexpr int QKB_ROWS = 64;  // rows (token, head pairs) per wave per block
+__global__ __launch_bounds__(256) void qkln_rope_bwd_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, int ldg,
+                                                            const bf16_t* __restrict__ qkv, const float* __restrict__ qw,
+                                                            const float* __restrict__ kw, const float* __restrict__ cosT,
+                                                            const float* __restrict__ sinT, bf16_t* __restrict__ dqkv,
+                                                            float* __restrict__ part, int T, int L, int nH, float eps) {
+    __shared__ float red[4][4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int H = nH * 64;
+    const int64_t rows = (int64_t)T * nH;
+    float awq = 0.f, abq = 0.f, awk = 0.f, abk = 0.f;
+    const float wq = qw[lane], wk = kw[lane];
+    const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * QKB_ROWS;
+    for (int i = 0; i < QKB_ROWS; ++i) {
+        const int64_t row = base + i;
+        if (row >= rows) break;
+        const int tok = (int)(row / nH), head = (int)(row - (int64_t)tok * nH);
+        const int pos = tok % L;  // training sequences start at position 0 (phi.py:998-1003)
+        const float c = lane < 32 ? cosT[(int64_t)pos * 32 + lane] : 1.f;
+        const float sn = lane < 32 ? sinT[(int64_t)pos * 32 + lane] : 0.f;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const float g = bf2f((which ? dk : dq)[(int64_t)tok * ldg + head * 64 + lane]) * (which ? 1.0f : 0.125f);
+            // rope^T: y'[d] = y[d] c[d] + rot(y)[d] s[d], rot(y)[d] = -y[d+16] (d<16), +y[d-16] (16<=d<32)
+            //   => dy[d] = g[d] c[d] + (d < 16 ? g[d+16] s[d+16] : -g[d-16] s[d-16])
+            const float gs = g * sn;
+            const float other = __shfl_xor(gs, 16, 64);
+            float dy = g * c;
+            if (lane < 16) dy += other; else if (lane < 32) dy -= other;
+            const float x = bf2f(qkv[(int64_t)tok * 3 * H + which * H + head * 64 + lane]);
+            const float mean = wave_sum(x) * (1.0f / 64.0f);
+            const float xc = x - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum(xc * xc) * (1.0f / 64.0f) + eps);
+            const float xh = xc * rstd;
+            if (which) { awk += dy * xh; abk += dy; } else { awq += dy * xh; abq += dy; }
+            const float gg = dy * (which ? wk : wq);
+            const float m1 = wave_sum(gg) * (1.0f / 64.0f), m2 = wave_sum(gg * xh) * (1.0f / 64.0f);
+            dqkv[(int64_t)tok * 3 * H + which * H + head * 64 + lane] = f2bf(rstd * (gg - m1 - xh * m2));
+        }
+    }
+    red[wave][0][lane] = awq; red[wave][1][lane] = abq; red[wave][2][lane] = awk; red[wave][3][lane] = abk;
+    __syncthreads();
+    {
+        const int which = threadIdx.x >> 6;
+        part[((int64_t)blockIdx.x * 4 + which) * 64 + lane] =
+            (red[0][which][lane] + red[1][which][lane]) + (red[2][which][lane] + red[3][which][lane]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-entropy of Showo.forward (modeling_showo.py:80-98).  A logits row r = (b, l) can carry up to two targets:
+//   A = labels[b, l]     with weight wa  (mask-token prediction rows: b < b_t2i, l > max_seq_len)
+//   B = labels[b, l+1]   with weight wb  (next-token rows of the lm and mmu slices, l < L-1)
+// ce_rows_kernel builds (labA, labB, group bits) and the three valid-label counts; ce_kernel computes per row
+//   lse, ceA = lse - z[A], ceB = lse - z[B] and dlogits = (wa + wb) softmax - wa onehot(A) - wb onehot(B)  (bf16, ld Vp);
+// ce_finalize sums the row losses per group in row order (mean over valid labels, like F.cross_entropy).
+// ------------------------------------------------------------------------------------------------
+struct CeRow { int labA, labB, bits; };  // bits: 1 = t2i row, 2 = lm row, 4 = mmu row (valid label only)
+__global__ void ce_rows_kernel(const int64_t* __restrict__ labels, CeRow* __restrict__ rows, int* __restrict__ counts, int B, int L,
+                               int b_t2i, int b_lm, int b_mmu, int max_seq_len) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B * L) return;
+    const int b = r / L, l = r - b * L;
+    CeRow o;
+    o.labA = -100; o.labB = -100; o.bits = 0;
+    if (b < b_t2i && l >= max_seq_len + 1) {
+        const int64_t t = labels[r];
+        if (t != -100) { o.labA = (int)t; o.bits |= 1; atomicAdd(&counts[0], 1); }
+    }
+    if (l < L - 1) {
+        const int64_t t = labels[r + 1];
+        if (t != -100) {
+            const bool in_lm = b >= b_t2i && b < b_t2i + b_lm;
+            const bool in_mmu = b_mmu == 0 ? true : b >= B - b_mmu;  // logits[-0:] selects the whole batch (reference quirk)
+            if (in_lm) { o.bits |= 2; atomicAdd(&counts[1], 1); }
+            if (in_mmu) { o.bits |= 4; atomicAdd(&counts[2], 1); }
+            if (in_lm || in_mmu) o.labB = (int)t;
+        }
+    }
+    rows[r] = o;
+}
+
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int ldl, const CeRow* __restrict__ rows,
+                                                 const int* __restrict__ counts, float g_t2i, float g_lm, float g_mmu,
+                                                 bf16_t* __restrict__ dlogits, int ldd, float* __restrict__ rowloss, int V) {
+    __shared__ float sred[4];
+    __shared__ float sbc;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const CeRow cr = rows[r];
+    const float* z = logits + (int64_t)r * ldl;
+    bf16_t* dz = dlogits ? dlogits + (int64_t)r * ldd : nullptr;
+    float wa = 0.f, wb = 0.f;
+    if (cr.bits & 1) wa = g_t2i / (float)counts[0];
+    if (cr.bits & 2) wb += g_lm / (float)counts[1];
+    if (cr.bits & 4) wb += g_mmu / (float)counts[2];
+    if (cr.bits == 0) {  // no target: zero gradient row, no loss
+        if (dz)
+            for (int i = tid * 8; i < ldd; i += 256 * 8) *reinterpret_cast<uint4*>(dz + i) = make_uint4(0, 0, 0, 0);
+        if (tid == 0) { rowloss[2 * r] = 0.f; rowloss[2 * r + 1] = 0.f; }
+        return;
+    }
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, z[i]);
+    mx = wave_max(mx);
+    if (lane == 0) sred[wave] = mx;
+    __syncthreads();
+    if (tid == 0) sbc = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    mx = sbc;
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += expf(z[i] - mx);
+    s = wave_sum(s);
+    __syncthreads();
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    if (tid == 0) sbc = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    __syncthreads();
+    const float tot = sbc;
+    const float lse = mx + logf(tot);
+    if (tid == 0) {
+        rowloss[2 * r] = (cr.bits & 1) ? lse - z[cr.labA] : 0.f;
+        rowloss[2 * r + 1] = (cr.bits & 6) ? lse - z[cr.labB] : 0.f;
+    }
+    if (dz) {
+        const float w = wa + wb, inv = 1.0f / tot;
+        for (int i0 = tid * 8; i0 < ldd; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j;
+                float g = 0.f;
+                if (i < V) {
+                    g = w * expf(z[i] - mx) * inv;
+                    if (i == cr.labA) g -= wa;
+                    if (i == cr.labB) g -= wb;
+                }
+                v[j] = g;
+            }
+            uint4 u;
+            u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(dz + i0) = u;
+        }
+    }
+}
+// losses[g] = sum over rows of group g (row order) / count[g]
+__global__ void ce_finalize_kernel(const float* __restrict__ rowloss, const CeRow* __restrict__ rows, const int* __restrict__ counts,
+                                   float* __restrict__ losses, int R) {
+    const int g = threadIdx.x;
+    if (g >= 3) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int bits = rows[r].bits;
+        if (g == 0 && (bits & 1)) s += rowloss[2 * r];
+        if (g == 1 && (bits & 2)) s += rowloss[2 * r + 1];
+        if (g == 2 && (bits & 4)) s += rowloss[2 * r + 1];
+    }
+    losses[g] = (float)(s / (double)counts[g]);  // 0/0 -> nan like F.cross_entropy on an empty selection
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding backward, deterministic: tokens are ranked by (id, position) with a counting pass, then every run of equal
+// ids is summed in position order by one block (4 waves x 512 columns at H = 2048).
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_rank_kernel(const int64_t* __restrict__ ids, int* __restrict__ order, int* __restrict__ runstart, int T) {
+    // O(T^2 / threads) ranking; T <= ~16k tokens per step, ids small: cheap next to one GEMM
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int64_t id = ids[t];
+    int rank = 0, first = 1;
+    for (int u = 0; u < T; ++u) {
+        const int64_t o = ids[u];
+        rank += (o < id) || (o == id && u < t);
+        if (o == id && u < t) first = 0;
+    }
+    order[rank] = t;
+    runstart[rank] = first;
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const int* __restrict__ order,
+                                                        const int* __restrict__ runstart, const float* __restrict__ dx,
+                                                        float* __restrict__ dE, int T, int H) {
+    const int i = blockIdx.x;
+    if (!runstart[i]) return;
+    const int64_t id = ids[order[i]];
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = i; j < T && (j == i || !runstart[j]); ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(dx + (int64_t)order[j] * H + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dE + id * H + c) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics: decoupled decay, bias-corrected moments) on fp32 master weights.
+// ------------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float w = p[i];
+        const float gr = g[i];
+        w *= 1.0f - lr * wd;
+        const float mm = beta1 * m[i] + (1.0f - beta1) * gr;
+        const float vv = beta2 * v[i] + (1.0f - beta2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+        p[i] = w - (lr / bc1) * (mm / denom);
+    }
+}
+
+__global__ void scale_f32_kernel(float* __restrict__ x, int64_t n, float s) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) x[i] *= s;
+}
+
+// dgrad epilogue helper: d_f bf16 = d_a (bf16) * gelu_new'(f)   (elementwise, when not fused in a GEMM epilogue)
+__global__ void dgelu_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ f, bf16_t* __restrict__ df, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+    for (; i < n; i += stride) {
+        const uint4 a = *reinterpret_cast<const uint4*>(da + i);
+        const uint4 b = *reinterpret_cast<const uint4*>(f + i);
+        const bf16_t* ea = reinterpret_cast<const bf16_t*>(&a);
+        const bf16_t* eb = reinterpret_cast<const bf16_t*>(&b);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bf2f(ea[j]) * gelu_new_grad(bf2f(eb[j]));
+        uint4 u;
+        u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(df + i) = u;
+    }
+}
+
+}  // namespace
+
+extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int T, int C, int Tp, int mode, float* colpart,
+                                    float* colsum, int accumulate, void* stream) {
+    if (T <= 0 || C <= 0) return 0;
+    if ((Tp % 64) || Tp < T || (ld % 8) || (C % 8)) return set_error_msg(1, "transpose: Tp % 64 == 0, Tp >= T, ld % 8 == 0, C % 8 == 0 required");
+    if (colsum && !colpart) return set_error_msg(1, "transpose: column sums need the partial buffer [Tp/64, C]");
+    hipStream_t s = (hipStream_t)stream;
+    transpose_kernel<<<dim3((C + 63) / 64, Tp / 64), dim3(256), 0, s>>>(x, xt, colsum ? colpart : nullptr, T, C, ld, Tp, mode);
+    if (colsum) colsum_finalize_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(colpart, colsum, Tp / 64, C, accumulate);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16,
+                            float* part, float* dgb, int T, int H, float eps, void* stream) {
+    if (T <= 0) return 0;
+    if ((H % 256) || H > 2048) return set_error_msg(1, "ln_bwd: H must be a multiple of 256 and <= 2048");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (T + LNB_ROWS - 1) / LNB_ROWS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_set = true;
+    }
+    ln_bwd_kernel<<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, T, H, eps);
+    // part is [nblk][2][H]: reduce it as a [nblk, 2H] matrix -> dgb = (dgamma[H], dbeta[H])
+    colsum_finalize_kernel<<<dim3((2 * H + 255) / 256), dim3(256), 0, s>>>(part, dgb, nblk, 2 * H, 0);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int showo_ln_bwd_blocks(int T) { return (T + LNB_ROWS - 1) / LNB_ROWS; }
+
+extern "C" int showo_qkln_rope_bwd(const uint16_t* dq, const uint16_t* dk, int ldg, const uint16_t* qkv, const float* qw,
+                                   const float* kw, const float* cos_tab, const float* sin_tab, uint16_t* dqkv, float* part,
+                                   float* dparams, int T, int L, int nH, int rot, float eps, void* stream) {
+    if (T <= 0) return 0;
+    if (rot != 32) return set_error_msg(1, "qkln_rope_bwd: rotary_dim 32 only");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = (int64_t)T * nH;
+    const int nblk = (int)((rows + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS));
+    qkln_rope_bwd_kernel<<<dim3(nblk), dim3(256), 0, s>>>(dq, dk, ldg, qkv, qw, kw, cos_tab, sin_tab, dqkv, part, T, L, nH, eps);
+    colsum_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(part, dparams, nblk, 256, 0);  // (dqw, dqb, dkw, dkb) x 64
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int showo_qkln_rope_bwd_blocks(int T, int nH) { return (int)(((int64_t)T * nH + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS)); }
+
+extern "C" int showo_ce_loss(const float* logits, int ldl, const int64_t* labels, int B, int L, int V, int b_t2i, int b_lm,
+                             int b_mmu, int max_seq_len, float g_t2i, float g_lm, float g_mmu, void* rows_ws, int* counts,
+                             float* rowloss, uint16_t* dlogits, int ldd, float* losses, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if (dlogits && ((ldd % 8) || ldd < V)) return set_error_msg(1, "ce_loss: ldd must be a multiple of 8 and >= V");
+    hipStream_t s = (hipStream_t)stream;
+    const int R = B * L;
+    CeRow* rows = reinterpret_cast<CeRow*>(rows_ws);
+    SHOWO_CHECK_HIP(hipMemsetAsync(counts, 0, 3 * sizeof(int), s));
+    ce_rows_kernel<<<dim3((R + 255) / 256), dim3(256), 0, s>>>(labels, rows, counts, B, L, b_t2i, b_lm, b_mmu, max_seq_len);
+    ce_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, ldl, rows, counts, g_t2i, g_lm, g_mmu, dlogits, ldd, rowloss, V);
+    if (losses) ce_finalize_kernel<<<dim3(1), dim3(64), 0, s>>>(rowloss, rows, counts, losses, R);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_embed_bwd(const int64_t* ids, const float* dx, float* dE, int* order_ws, int T, int H, int V, void* stream) {
+    if (T <= 0) return 0;
+    if (H % 4) return set_error_msg(1, "embed_bwd: H % 4 == 0 required");
+    (void)V;
+    hipStream_t s = (hipStream_t)stream;
+    int* order = order_ws;
+    int* runstart = order_ws + T;
+    embed_rank_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ids, order, runstart, T);
+    embed_bwd_kernel<<<dim3(T), dim3(256), 0, s>>>(ids, order, runstart, dx, dE, T, H);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int step, void* stream) {
+    if (n <= 0) return 0;
+    if (step < 1) return set_error_msg(1, "adamw: step counts from 1");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    adamw_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_scale_f32(float* x, int64_t n, float s, void* stream) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    scale_f32_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(x, n, s);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_dgelu_bf16(const uint16_t* da, const uint16_t* f, uint16_t* df, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return set_error_msg(1, "dgelu: n % 8 == 0 required");
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    dgelu_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(da, f, df, n);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -93,3 +93,153 @@ def test_attention_backward_vs_autograd(B, nH, Lq, kind):
         rms = float((g - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
         print(f"[parity] attention bwd {kind} L={Lq} {name}: max err {err:.3e} / scale {scale:.3e}, rel rms {rms:.3e}")
         assert err < 2 ** -6 * scale + 1e-3 and rms < 1e-2, name
+
+
+def _rope_tables():
+    return O.rope_tables(32, 2048, 10000.0)
+
+
+def test_transpose_colsum_and_gelu_mode():
+    torch.manual_seed(0)
+    T, C, Tp = 150, 200, 192
+    x = bf16_round(torch.randn(T, C))
+    xt = torch.full((C, Tp), 7, dtype=torch.int16, device="cuda")
+    part = torch.zeros((Tp // 64, C), dtype=torch.float32, device="cuda")
+    cs = torch.zeros(C, dtype=torch.float32, device="cuda")
+    L().call("showo_transpose_bf16", L().ptr(_bits(x)), C, L().ptr(xt), T, C, Tp, 0, L().ptr(part), L().ptr(cs), 0, S())
+    got = from_bf16_bits(xt).cpu()
+    assert torch.equal(got[:, :T], x.T) and (got[:, T:] == 0).all()
+    assert (cs.cpu() - x.sum(0)).abs().max() < 1e-3
+    L().call("showo_transpose_bf16", L().ptr(_bits(x)), C, L().ptr(xt), T, C, Tp, 1, None, None, 0, S())
+    got = from_bf16_bits(xt).cpu()
+    assert (got[:, :T] - O.gelu_new(x).T).abs().max() < 2 ** -8 * 4 and (got[:, T:] == 0).all()
+
+
+@pytest.mark.parametrize("T,H", [(37, 256), (100, 2048)])
+def test_layernorm_backward(T, H):
+    torch.manual_seed(T)
+    x = (torch.randn(T, H) * 1.5 + 0.2).requires_grad_(True)
+    gamma = (torch.randn(H) * 0.1 + 1).requires_grad_(True)
+    beta = torch.zeros(H, requires_grad=True)
+    dh, dy = torch.randn(T, H), torch.randn(T, H)
+    h = O.layer_norm(x, gamma, beta, 1e-5)
+    (h * dh).sum().backward()
+    want_dx = x.grad + dy
+    nblk = L().load().showo_ln_bwd_blocks(T)
+    part = torch.zeros((nblk, 2, H), dtype=torch.float32, device="cuda")
+    dgb = torch.zeros((2, H), dtype=torch.float32, device="cuda")
+    dx32 = dev(dy.clone())
+    dx16 = torch.zeros((T, H), dtype=torch.int16, device="cuda")
+    L().call("showo_ln_bwd", L().ptr(dev(x.detach())), L().ptr(dev(gamma.detach())), L().ptr(dev(dh)), L().ptr(dx32), L().ptr(dx32), L().ptr(dx16),
+             L().ptr(part), L().ptr(dgb), T, H, 1e-5, S())
+    assert (dx32.cpu() - want_dx).abs().max() < 1e-4 * float(want_dx.abs().max())
+    assert torch.equal(from_bf16_bits(dx16).cpu(), bf16_round(dx32.cpu()))
+    assert (dgb[0].cpu() - gamma.grad).abs().max() < 1e-4 * float(gamma.grad.abs().max()) + 1e-5
+    assert (dgb[1].cpu() - beta.grad).abs().max() < 1e-4 * float(beta.grad.abs().max()) + 1e-5
+
+
+def test_qk_layernorm_rope_backward():
+    torch.manual_seed(4)
+    B, Lq, nH = 2, 37, 3
+    T, H = B * Lq, nH * 64
+    qkv = bf16_round(torch.randn(T, 3 * H))
+    qw = (torch.randn(64) * .1 + 1).requires_grad_(True)
+    qb = (torch.randn(64) * .05).requires_grad_(True)
+    kw = (torch.randn(64) * .1 + 1).requires_grad_(True)
+    kb = (torch.randn(64) * .05).requires_grad_(True)
+    dq, dk = bf16_round(torch.randn(T, H)), bf16_round(torch.randn(T, H))
+    cos, sin = _rope_tables()
+    x = qkv.clone().requires_grad_(True)
+    xv = x.view(B, Lq, 3, nH, 64)
+    q = O.apply_partial_rope(O.layer_norm(xv[:, :, 0].transpose(1, 2), qw, qb, 1e-5), cos[:Lq], sin[:Lq], 32) * 0.125
+    k = O.apply_partial_rope(O.layer_norm(xv[:, :, 1].transpose(1, 2), kw, kb, 1e-5), cos[:Lq], sin[:Lq], 32)
+    ((q.transpose(1, 2).reshape(T, H) * dq).sum() + (k.transpose(1, 2).reshape(T, H) * dk).sum()).backward()
+    nblk = L().load().showo_qkln_rope_bwd_blocks(T, nH)
+    part = torch.zeros((nblk, 4, 64), dtype=torch.float32, device="cuda")
+    dpar = torch.zeros((4, 64), dtype=torch.float32, device="cuda")
+    dqkv = torch.zeros((T, 3 * H), dtype=torch.int16, device="cuda")
+    L().call("showo_qkln_rope_bwd", L().ptr(_bits(dq)), L().ptr(_bits(dk)), H, L().ptr(_bits(qkv)), L().ptr(dev(qw.detach())), L().ptr(dev(kw.detach())),
+             L().ptr(dev(cos)), L().ptr(dev(sin)), L().ptr(dqkv), L().ptr(part), L().ptr(dpar), T, Lq, nH, 32, 1e-5, S())
+    got = from_bf16_bits(dqkv).cpu()
+    want = x.grad
+    assert (got[:, :2 * H] - want[:, :2 * H]).abs().max() < 2 ** -7 * float(want.abs().max())
+    assert (got[:, 2 * H:] == 0).all()  # the v section belongs to the attention backward
+    for i, p in enumerate((qw, qb, kw, kb)):
+        assert (dpar[i].cpu() - p.grad).abs().max() < 1e-3 * float(p.grad.abs().max()) + 1e-4, i
+
+
+@pytest.mark.parametrize("b_t2i,b_lm,b_mmu", [(2, 1, 2), (3, 0, 0), (0, 2, 3)])
+def test_cross_entropy_losses_and_gradient(b_t2i, b_lm, b_mmu):
+    """the three slices of Showo.forward (incl. the logits[-0:] quirk when batch_size_mmu == 0) vs the oracle + autograd"""
+    torch.manual_seed(b_t2i * 7 + b_mmu)
+    B, Lq, V, msl = max(b_t2i + b_lm + b_mmu, 3), 24, 439, 8
+    Vp = (V + 63) // 64 * 64
+    logits = (torch.randn(B, Lq, V) * 2).requires_grad_(True)
+    labels = torch.randint(0, V, (B, Lq))
+    labels[torch.rand(B, Lq) < 0.4] = -100
+    import torch.nn.functional as F
+    l1 = F.cross_entropy(logits[:b_t2i, msl + 1:].reshape(-1, V), labels[:b_t2i, msl + 1:].reshape(-1), ignore_index=-100)
+    l2 = F.cross_entropy(logits[b_t2i:b_t2i + b_lm, :-1].reshape(-1, V), labels[b_t2i:b_t2i + b_lm, 1:].reshape(-1), ignore_index=-100)
+    l3 = F.cross_entropy(logits[-b_mmu:, :-1].reshape(-1, V), labels[-b_mmu:, 1:].reshape(-1), ignore_index=-100)
+    g = (1.0, 0.1, 0.7)
+    tot = sum(c * l for c, l in zip(g, (l1, l2, l3)) if torch.isfinite(l))
+    tot.backward()
+    R = B * Lq
+    rows = torch.zeros(3 * R, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(4, dtype=torch.int32, device="cuda")
+    rowloss = torch.zeros(2 * R, dtype=torch.float32, device="cuda")
+    dl = torch.full((R, Vp), 7, dtype=torch.int16, device="cuda")
+    losses = torch.zeros(4, dtype=torch.float32, device="cuda")
+    L().call("showo_ce_loss", L().ptr(dev(logits.detach().reshape(R, V))), V, L().ptr(dev(labels)), B, Lq, V, b_t2i, b_lm, b_mmu, msl,
+             g[0], g[1], g[2], L().ptr(rows), L().ptr(counts), L().ptr(rowloss), L().ptr(dl), Vp, L().ptr(losses), S())
+    got = losses.cpu()
+    for i, l in enumerate((l1, l2, l3)):
+        if torch.isfinite(l):
+            assert abs(float(got[i]) - float(l)) < 1e-4 * abs(float(l)) + 1e-5, (i, float(got[i]), float(l))
+        else:
+            assert not torch.isfinite(got[i])  # empty selection -> nan, like F.cross_entropy
+    gd = from_bf16_bits(dl).cpu()
+    if all(torch.isfinite(l) for l in (l1, l2, l3)):
+        want = logits.grad.reshape(R, V)
+        assert (gd[:, :V] - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-6
+    assert (gd[:, V:] == 0).all()
+
+
+def test_embedding_backward_deterministic():
+    torch.manual_seed(2)
+    T, H, V = 300, 256, 50
+    ids = torch.randint(0, V, (T,))
+    ids[::3] = 7  # a heavily repeated id (the mask token in training)
+    dx = torch.randn(T, H)
+    want = torch.zeros(V, H).index_add_(0, ids, dx)
+    dE = torch.zeros((V, H), dtype=torch.float32, device="cuda")
+    ws = torch.zeros(2 * T, dtype=torch.int32, device="cuda")
+    L().call("showo_embed_bwd", L().ptr(dev(ids)), L().ptr(dev(dx)), L().ptr(dE), L().ptr(ws), T, H, V, S())
+    assert (dE.cpu() - want).abs().max() < 1e-4
+    dE2 = torch.zeros_like(dE)
+    L().call("showo_embed_bwd", L().ptr(dev(ids)), L().ptr(dev(dx)), L().ptr(dE2), L().ptr(ws), T, H, V, S())
+    assert torch.equal(dE, dE2)
+
+
+def test_adamw_matches_torch():
+    torch.manual_seed(1)
+    n = 10007
+    p = torch.randn(n).requires_grad_(True)
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    pd, m, v = dev(p.detach().clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = torch.randn(n)
+        p.grad = g.clone()
+        opt.step()
+        L().call("showo_adamw", L().ptr(pd), L().ptr(dev(g)), L().ptr(m), L().ptr(v), n, 1e-2, 0.9, 0.999, 1e-8, 0.01, step, S())
+        assert (pd.cpu() - p.detach()).abs().max() < 2e-6
+
+
+def test_dgelu():
+    torch.manual_seed(3)
+    f = bf16_round(torch.randn(64, 128) * 2).requires_grad_(True)
+    da = bf16_round(torch.randn(64, 128))
+    (O.gelu_new(f) * da).sum().backward()
+    out = torch.zeros((64, 128), dtype=torch.int16, device="cuda")
+    L().call("showo_dgelu_bf16", L().ptr(_bits(da)), L().ptr(_bits(f.detach())), L().ptr(out), 64 * 128, S())
+    assert (from_bf16_bits(out).cpu() - f.grad).abs().max() < 2 ** -8 * float(f.grad.abs().max()) + 1e-6
