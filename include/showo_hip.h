@@ -307,6 +307,29 @@ int showo_vq_decode_code(showo_vq* v, const int64_t* ids, int B, int h, int w, f
  * z_out (optional) fp32 [B,13,H/16,W/16] = pre-quantisation latents (for the |z|<eps agreement test). */
 int showo_vq_get_code(showo_vq* v, const float* pixels, int B, int H, int W, int64_t* ids, float* z_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training step (reference Showo.forward with labels + loss.backward(), models/modeling_showo.py:59-102,
+ * training/train.py:590-612).  A trainer borrows an engine's weights and workspaces and owns the saved activations,
+ * the transposed weight images of the dgrad GEMMs and one fp32 gradient buffer per reference parameter.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct showo_trainer showo_trainer;
+int showo_train_create(showo_engine* e, int max_batch, int max_seq, showo_trainer** out);
+void showo_train_destroy(showo_trainer* t);
+/* call after showo_engine_load changed weights (optimizer step): the transposed images are rebuilt lazily */
+int showo_train_invalidate_weights(showo_trainer* t);
+/* forward with saved activations.  ids int64 [B,L]; mask [B,1,L,L] fp32 or NULL (causal); labels int64 [B,L] or NULL.
+ * logits_out (optional) fp32 [B,L,V]; losses_out (optional, needs labels) fp32 [3] = (loss_t2i, loss_lm, loss_mmu). */
+int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L, int b_t2i,
+                        int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out, void* stream);
+/* gradients of g_t2i*loss_t2i + g_lm*loss_lm + g_mmu*loss_mmu of the last forward w.r.t. every parameter */
+int showo_train_backward(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len, float g_t2i,
+                         float g_lm, float g_mmu, void* stream);
+/* gradient buffer of a reference state-dict key (device pointer, element count) / copy of it */
+int showo_train_grad(showo_trainer* t, const char* key, float** ptr, int64_t* n);
+int showo_train_grad_copy(showo_trainer* t, const char* key, float* dst, int64_t n, void* stream);
+int showo_train_losses(showo_trainer* t, float* out3, void* stream);
+int showo_gelu_bf16(const uint16_t* f, uint16_t* a, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,14 @@ _PROTOS = {
     "showo_adamw": [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "showo_scale_f32": [c_p, c_i64, c_f, c_p],
     "showo_dgelu_bf16": [c_p, c_p, c_p, c_i64, c_p],
+    "showo_gelu_bf16": [c_p, c_p, c_i64, c_p],
+    "showo_train_create": [c_p, c_i, c_i, c_p],
+    "showo_train_invalidate_weights": [c_p],
+    "showo_train_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "showo_train_backward": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
+    "showo_train_grad": [c_p, C.c_char_p, c_p, c_p],
+    "showo_train_grad_copy": [c_p, C.c_char_p, c_p, c_i64, c_p],
+    "showo_train_losses": [c_p, c_p, c_p],
     "showo_attn_fwd_lse": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_head_transpose": [c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_p],
     "showo_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i,
@@ -87,7 +95,7 @@ _PROTOS = {
     "showo_prof_reset": [],
     "showo_prof_read": [c_i, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)],
 }
-_VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p]}
+_VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p], "showo_train_destroy": [c_p]}
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + ["showo_last_error"])
 
 EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3

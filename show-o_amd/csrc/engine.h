@@ -1,0 +1,58 @@
+// Internal layout of the transformer engine (shared by engine.hip and train_engine.hip).
+#pragma once
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include <set>
+#include <string>
+#include <vector>
+
+namespace showo {
+struct Layer {
+    bf16_t *wqkv = nullptr, *wd = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bd = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln_w = nullptr, *ln_b = nullptr, *qln_w = nullptr, *qln_b = nullptr, *kln_w = nullptr, *kln_b = nullptr;
+};
+}  // namespace showo
+
+using showo::bf16_t;
+using showo::set_error_hip;
+using showo::set_error_msg;
+
+struct showo_engine {
+    showo_engine_config cfg;
+    int H, nL, nH, F, V;
+    int64_t maxT;
+    std::vector<void*> allocs;
+    std::set<std::string> loaded;
+    int expected = 0;
+    // weights
+    float* embed = nullptr;
+    std::vector<showo::Layer> layers;
+    float *fln_w = nullptr, *fln_b = nullptr, *blm = nullptr, *cosT = nullptr, *sinT = nullptr;
+    bf16_t* wlm = nullptr;
+    // workspace
+    float* x = nullptr;
+    bf16_t *h = nullptr, *qkv = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *attn = nullptr, *ffn = nullptr, *hf = nullptr;
+    int32_t *iv = nullptr, *flag = nullptr, *rows = nullptr;
+    // t2i state
+    int64_t *ids_all = nullptr, *cur = nullptr, *sampled = nullptr;
+    float *sel = nullptr, *row_logits = nullptr;
+    int64_t row_logits_cap = 0;
+    // decode (KV cache) state: per-layer caches, capacity cap tokens
+    bf16_t *kcache = nullptr, *vtcache = nullptr;
+    int cache_cap = 0, cache_len = 0, prompt_len = 0;
+    int last_iv[4] = {0, 0, 0, 0};
+    int32_t* iv1 = nullptr;
+    int64_t* tok1 = nullptr;
+
+    template <class T>
+    int alloc(T** p, int64_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T));
+        if (e != hipSuccess) return set_error_hip(e, "hipMalloc", __FILE__, __LINE__);
+        allocs.push_back(q);
+        *p = (T*)q;
+        return 0;
+    }
+};
+

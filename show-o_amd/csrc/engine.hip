@@ -13,8 +13,7 @@
 //   attn   bf16 [T,H]; ffn bf16 [T,F]
 //   weights: Wqkv [3H,H], Wd [H,H], W1 [F,H], W2 [H,F], Wlm [V,H] bf16 row-major (= nn.Linear layout,
 //   K-contiguous, exactly what the MFMA GEMM's operand loader wants); biases / LayerNorm params fp32.
-#include "common.h"
-#include "../../include/showo_hip.h"
+#include "engine.h"
 #include <cstdio>
 #include <cstring>
 #include <set>
@@ -24,12 +23,6 @@
 using namespace showo;
 
 namespace {
-
-struct Layer {
-    bf16_t *wqkv = nullptr, *wd = nullptr, *w1 = nullptr, *w2 = nullptr;
-    float *bqkv = nullptr, *bd = nullptr, *b1 = nullptr, *b2 = nullptr;
-    float *ln_w = nullptr, *ln_b = nullptr, *qln_w = nullptr, *qln_b = nullptr, *kln_w = nullptr, *kln_b = nullptr;
-};
 
 __global__ void init_cur_kernel(const int64_t* ids, int ld, int img_start, int64_t mask_id, int64_t offset, int64_t* cur, int N,
                                 int total) {
@@ -63,44 +56,6 @@ __global__ void copy_i64_kernel(const int64_t* s, int64_t* d, int n) {
 }
 
 }  // namespace
-
-struct showo_engine {
-    showo_engine_config cfg;
-    int H, nL, nH, F, V;
-    int64_t maxT;
-    std::vector<void*> allocs;
-    std::set<std::string> loaded;
-    int expected = 0;
-    // weights
-    float* embed = nullptr;
-    std::vector<Layer> layers;
-    float *fln_w = nullptr, *fln_b = nullptr, *blm = nullptr, *cosT = nullptr, *sinT = nullptr;
-    bf16_t* wlm = nullptr;
-    // workspace
-    float* x = nullptr;
-    bf16_t *h = nullptr, *qkv = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *attn = nullptr, *ffn = nullptr, *hf = nullptr;
-    int32_t *iv = nullptr, *flag = nullptr, *rows = nullptr;
-    // t2i state
-    int64_t *ids_all = nullptr, *cur = nullptr, *sampled = nullptr;
-    float *sel = nullptr, *row_logits = nullptr;
-    int64_t row_logits_cap = 0;
-    // decode (KV cache) state: per-layer caches, capacity cap tokens
-    bf16_t *kcache = nullptr, *vtcache = nullptr;
-    int cache_cap = 0, cache_len = 0, prompt_len = 0;
-    int last_iv[4] = {0, 0, 0, 0};
-    int32_t* iv1 = nullptr;
-    int64_t* tok1 = nullptr;
-
-    template <class T>
-    int alloc(T** p, int64_t n) {
-        void* q = nullptr;
-        hipError_t e = hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T));
-        if (e != hipSuccess) return set_error_hip(e, "hipMalloc", __FILE__, __LINE__);
-        allocs.push_back(q);
-        *p = (T*)q;
-        return 0;
-    }
-};
 
 #define TRY(expr)            \
     do {                     \
@@ -185,7 +140,7 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     else if (k == "rope.cos") rc = copy_f32(e->cosT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
     else if (k == "rope.sin") rc = copy_f32(e->sinT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
     else if (sscanf(key, "showo.model.layers.%d.%127s", &li, sub) == 2 && li >= 0 && li < e->nL) {
-        Layer& l = e->layers[li];
+        showo::Layer& l = e->layers[li];
         std::string t(sub);
         if (t == "self_attn.q_proj.weight") rc = cast_w(l.wqkv, src, n, H * H, s);
         else if (t == "self_attn.k_proj.weight") rc = cast_w(l.wqkv + H * H, src, n, H * H, s);
@@ -220,7 +175,7 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, bool use_cache, c
     const int Lcap = use_cache ? e->cache_cap : L;
     const int Lp = use_cache ? e->cache_cap : ((L + 63) / 64) * 64;
     for (int li = 0; li < e->nL; ++li) {
-        Layer& l = e->layers[li];
+        showo::Layer& l = e->layers[li];
         bf16_t* Kd = use_cache ? e->kcache + (int64_t)li * nH * e->cache_cap * 64 : e->K;
         bf16_t* Vd = use_cache ? e->vtcache + (int64_t)li * nH * 64 * e->cache_cap : e->Vt;
         TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));

@@ -1,0 +1,320 @@
+// Training step of the Show-o transformer on gfx950: forward with saved activations, the three cross-entropies of
+// Showo.forward and the full backward into fp32 gradient buffers that carry the reference's state-dict names.
+// Replaces (reference): Showo.forward with labels (models/modeling_showo.py:59-102) + loss.backward()
+// (training/train.py:590-612) for the Phi stack (models/phi.py:774-790, 953-1183).
+//
+// GEMM forms (all on the one NT kernel C = A W^T, K-contiguous operands):
+//   forward   Y[T,N]   = X[T,K]     W[N,K]^T
+//   dgrad     dX[T,K]  = dY[T,N]    (W^T)[K,N]^T        -> needs the transposed weight copy W^T (made at load time)
+//   wgrad     dW[N,K]  = (dY^T)[N,Tp] (X^T)[K,Tp]^T     -> needs token-contiguous images of dY and X
+//             (showo_transpose_bf16; the bias gradient = column sums of dY comes out of the same pass)
+// Saved per layer: x (fp32 block input), h = LN(x), raw qkv, Q, K, V^T, lse, attention output, fc1 pre-activation.
+#include "engine.h"
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+using namespace showo;
+
+#define TRY(expr)            \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+namespace {
+struct LayerT {
+    bf16_t *wqkvT = nullptr, *wdT = nullptr, *w1T = nullptr, *w2T = nullptr;  // [K_in, N_out] images for dgrad
+    // saved activations
+    float* x = nullptr;
+    bf16_t *h = nullptr, *qkv = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *attn = nullptr, *f = nullptr;
+    float* lse = nullptr;
+    // gradients (fp32, reference parameter layout)
+    float *gwqkv = nullptr, *gbqkv = nullptr, *gwd = nullptr, *gbd = nullptr, *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
+    float *gln = nullptr;   // [2,H] (weight, bias)
+    float* gqk = nullptr;   // [4,64] (q_ln w, b, k_ln w, b)
+};
+struct Grad { float* p; int64_t n; };
+}  // namespace
+
+struct showo_trainer {
+    showo_engine* e;
+    int maxB, maxL, Tmax, Tp, Lp, Vp;
+    std::vector<void*> allocs;
+    std::vector<LayerT> L;
+    bf16_t* wlmT = nullptr;
+    std::map<std::string, Grad> grads;
+    // head
+    float *logits = nullptr, *gembed = nullptr, *gfln = nullptr, *gwlm = nullptr, *gblm = nullptr;
+    bf16_t *dlogits = nullptr, *bigT = nullptr;  // bigT: [max(Vp, F), Tp] transposed image of the dY side
+    // backward scratch
+    float *dy = nullptr, *dh = nullptr, *colpart = nullptr, *lnpart = nullptr, *qkpart = nullptr, *D = nullptr, *rowloss = nullptr;
+    bf16_t *dy16 = nullptr, *d_o = nullptr, *dff = nullptr, *dqk = nullptr, *dqkv = nullptr, *xT = nullptr, *QT = nullptr, *KT = nullptr, *dOT = nullptr;
+    void* ce_rows = nullptr;
+    int* counts = nullptr;
+    int* order_ws = nullptr;
+    float* losses = nullptr;
+    int64_t* ids = nullptr;
+    // state of the last forward
+    int B = 0, Lq = 0;
+    bool have_fwd = false;
+    bool has_mask = false;
+    bool weights_synced = false;
+
+    template <class T>
+    int alloc(T** p, int64_t n) {
+        void* q = nullptr;
+        hipError_t err = hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T));
+        if (err != hipSuccess) return set_error_hip(err, "hipMalloc(trainer)", __FILE__, __LINE__);
+        allocs.push_back(q);
+        *p = (T*)q;
+        return 0;
+    }
+    int galloc(const std::string& key, float** p, int64_t n) {
+        int rc = alloc(p, n);
+        if (!rc) grads[key] = Grad{*p, n};
+        return rc;
+    }
+};
+
+extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, showo_trainer** out) {
+    if (!e || !out) return set_error_msg(1, "train_create: null argument");
+    if (max_batch > e->cfg.max_batch || max_seq > e->cfg.max_seq || (int64_t)max_batch * max_seq > e->maxT)
+        return set_error_msg(5, "train_create: the engine workspace is smaller than the training batch");
+    if (e->cfg.rotary_dim != 32) return set_error_msg(1, "train: rotary_dim 32 only");
+    if (e->H % 64 || e->H > 2048) return set_error_msg(1, "train: hidden must be a multiple of 64 and <= 2048");
+    showo_trainer* t = new showo_trainer();
+    t->e = e;
+    t->maxB = max_batch; t->maxL = max_seq;
+    t->Tmax = max_batch * max_seq;
+    t->Tp = ((t->Tmax + 63) / 64) * 64;
+    t->Lp = ((max_seq + 63) / 64) * 64;
+    t->Vp = ((e->V + 63) / 64) * 64;
+    const int64_t H = e->H, F = e->F, V = e->V, T = t->Tmax, Tp = t->Tp, Vp = t->Vp, nH = e->nH;
+    int rc = 0;
+    t->L.resize(e->nL);
+    char key[160];
+    for (int i = 0; i < e->nL; ++i) {
+        LayerT& l = t->L[i];
+        rc |= t->alloc(&l.wqkvT, H * 3 * H); rc |= t->alloc(&l.wdT, H * H); rc |= t->alloc(&l.w1T, H * F); rc |= t->alloc(&l.w2T, F * H);
+        rc |= t->alloc(&l.x, T * H); rc |= t->alloc(&l.h, T * H); rc |= t->alloc(&l.qkv, T * 3 * H);
+        rc |= t->alloc(&l.Q, T * H); rc |= t->alloc(&l.K, T * H); rc |= t->alloc(&l.Vt, (int64_t)max_batch * H * t->Lp);
+        rc |= t->alloc(&l.attn, T * H); rc |= t->alloc(&l.f, T * F); rc |= t->alloc(&l.lse, (int64_t)max_batch * nH * max_seq);
+        if (rc) break;
+        hipMemset(l.Vt, 0, (size_t)max_batch * H * t->Lp * sizeof(bf16_t));
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        rc |= t->alloc(&l.gwqkv, 3 * H * H); rc |= t->alloc(&l.gbqkv, 3 * H);
+        for (int j = 0; j < 3 && !rc; ++j) {
+            snprintf(key, sizeof key, "showo.model.layers.%d.self_attn.%s.weight", i, names[j]);
+            t->grads[key] = Grad{l.gwqkv + j * H * H, H * H};
+            snprintf(key, sizeof key, "showo.model.layers.%d.self_attn.%s.bias", i, names[j]);
+            t->grads[key] = Grad{l.gbqkv + j * H, H};
+        }
+        snprintf(key, sizeof key, "showo.model.layers.%d.self_attn.dense.weight", i); rc |= t->galloc(key, &l.gwd, H * H);
+        snprintf(key, sizeof key, "showo.model.layers.%d.self_attn.dense.bias", i); rc |= t->galloc(key, &l.gbd, H);
+        snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc1.weight", i); rc |= t->galloc(key, &l.gw1, F * H);
+        snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc1.bias", i); rc |= t->galloc(key, &l.gb1, F);
+        snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc2.weight", i); rc |= t->galloc(key, &l.gw2, H * F);
+        snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc2.bias", i); rc |= t->galloc(key, &l.gb2, H);
+        rc |= t->alloc(&l.gln, 2 * H);
+        rc |= t->alloc(&l.gqk, 256);
+        if (rc) break;
+        snprintf(key, sizeof key, "showo.model.layers.%d.input_layernorm.weight", i); t->grads[key] = Grad{l.gln, H};
+        snprintf(key, sizeof key, "showo.model.layers.%d.input_layernorm.bias", i); t->grads[key] = Grad{l.gln + H, H};
+        const char* qk[4] = {"q_layernorm.weight", "q_layernorm.bias", "k_layernorm.weight", "k_layernorm.bias"};
+        for (int j = 0; j < 4; ++j) {
+            snprintf(key, sizeof key, "showo.model.layers.%d.self_attn.%s", i, qk[j]);
+            t->grads[key] = Grad{l.gqk + 64 * j, 64};
+        }
+    }
+    rc |= t->alloc(&t->wlmT, H * Vp);
+    rc |= t->galloc("showo.model.embed_tokens.weight", &t->gembed, V * H);
+    rc |= t->alloc(&t->gfln, 2 * H);
+    rc |= t->galloc("showo.lm_head.weight", &t->gwlm, V * H);
+    rc |= t->galloc("showo.lm_head.bias", &t->gblm, Vp);
+    if (!rc) {
+        t->grads["showo.lm_head.bias"].n = V;
+        t->grads["showo.model.final_layernorm.weight"] = Grad{t->gfln, H};
+        t->grads["showo.model.final_layernorm.bias"] = Grad{t->gfln + H, H};
+    }
+    rc |= t->alloc(&t->logits, T * V);
+    rc |= t->alloc(&t->dlogits, T * Vp);
+    const int64_t bigrows = Vp > F ? Vp : F;
+    rc |= t->alloc(&t->bigT, bigrows * Tp);
+    rc |= t->alloc(&t->xT, F * Tp);
+    rc |= t->alloc(&t->dy, T * H); rc |= t->alloc(&t->dh, T * H); rc |= t->alloc(&t->dy16, T * H); rc |= t->alloc(&t->d_o, T * H);
+    rc |= t->alloc(&t->dff, T * F); rc |= t->alloc(&t->dqk, T * 2 * H); rc |= t->alloc(&t->dqkv, T * 3 * H);
+    rc |= t->alloc(&t->QT, (int64_t)max_batch * H * t->Lp); rc |= t->alloc(&t->KT, (int64_t)max_batch * H * t->Lp);
+    rc |= t->alloc(&t->dOT, (int64_t)max_batch * H * t->Lp);
+    rc |= t->alloc(&t->D, (int64_t)max_batch * nH * max_seq);
+    rc |= t->alloc(&t->colpart, (Tp / 64) * bigrows);
+    rc |= t->alloc(&t->lnpart, (int64_t)showo_ln_bwd_blocks((int)T) * 2 * H);
+    rc |= t->alloc(&t->qkpart, (int64_t)showo_qkln_rope_bwd_blocks((int)T, (int)nH) * 256);
+    rc |= t->alloc(&t->rowloss, 2 * T);
+    rc |= t->alloc((char**)&t->ce_rows, 12 * T);
+    rc |= t->alloc(&t->counts, 4);
+    rc |= t->alloc(&t->order_ws, 2 * T);
+    rc |= t->alloc(&t->losses, 4);
+    rc |= t->alloc(&t->ids, T);
+    if (rc) { showo_train_destroy(t); return rc; }
+    *out = t;
+    return 0;
+}
+
+extern "C" void showo_train_destroy(showo_trainer* t) {
+    if (!t) return;
+    for (void* p : t->allocs) hipFree(p);
+    delete t;
+}
+
+extern "C" int showo_train_invalidate_weights(showo_trainer* t) {
+    if (!t) return set_error_msg(1, "train: null handle");
+    t->weights_synced = false;
+    return 0;
+}
+
+// transposed bf16 weight images for the dgrad GEMMs (call after the engine's weights changed)
+static int sync_weights(showo_trainer* t, hipStream_t s) {
+    if (t->weights_synced) return 0;
+    showo_engine* e = t->e;
+    const int H = e->H, F = e->F, V = e->V;
+    for (int i = 0; i < e->nL; ++i) {
+        Layer& w = e->layers[i];
+        LayerT& l = t->L[i];
+        TRY(showo_transpose_bf16(w.wqkv, H, l.wqkvT, 3 * H, H, 3 * H, 0, nullptr, nullptr, 0, s));  // [3H,H] -> [H,3H]
+        TRY(showo_transpose_bf16(w.wd, H, l.wdT, H, H, H, 0, nullptr, nullptr, 0, s));
+        TRY(showo_transpose_bf16(w.w1, H, l.w1T, F, H, F, 0, nullptr, nullptr, 0, s));                // [F,H] -> [H,F]
+        TRY(showo_transpose_bf16(w.w2, F, l.w2T, H, F, H, 0, nullptr, nullptr, 0, s));                // [H,F] -> [F,H]
+    }
+    TRY(showo_transpose_bf16(e->wlm, H, t->wlmT, V, H, t->Vp, 0, nullptr, nullptr, 0, s));            // [V,H] -> [H,Vp]
+    t->weights_synced = true;
+    return 0;
+}
+
+extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L,
+                                   int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out,
+                                   void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!t || !ids) return set_error_msg(1, "train_forward: null argument");
+    showo_engine* e = t->e;
+    if (showo_engine_missing(e) != 0) return set_error_msg(4, "train: weights missing");
+    if (B > t->maxB || L > t->maxL || (int64_t)B * L > t->Tmax) return set_error_msg(5, "train: batch exceeds the trainer workspace");
+    if ((e->H % 64) || (e->F % 64)) return set_error_msg(1, "train: hidden/ffn must be multiples of 64");
+    TRY(sync_weights(t, s));
+    const int H = e->H, F = e->F, V = e->V, nH = e->nH, T = B * L;
+    const int Lp = ((L + 63) / 64) * 64;
+    SHOWO_CHECK_HIP(hipMemcpyAsync(t->ids, ids, (size_t)T * 8, hipMemcpyDeviceToDevice, s));
+    TRY(showo_embed_f32(ids, e->embed, e->x, T, H, V, s));
+    const int32_t *iv = nullptr, *flag = nullptr;
+    if (mask) {
+        TRY(showo_mask_compress(mask, e->iv, e->flag, B, L, L, s));
+        iv = e->iv; flag = e->flag;
+    }
+    for (int i = 0; i < e->nL; ++i) {
+        Layer& w = e->layers[i];
+        LayerT& l = t->L[i];
+        SHOWO_CHECK_HIP(hipMemcpyAsync(l.x, e->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        TRY(showo_layernorm_f32_bf16(e->x, w.ln_w, w.ln_b, l.h, nullptr, T, H, e->cfg.ln_eps, s));
+        TRY(showo_gemm_bf16(l.h, H, w.wqkv, H, w.bqkv, 0, l.qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
+        TRY(showo_qk_prep(l.qkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt, B, L, nH, e->cfg.rotary_dim,
+                          e->cfg.ln_eps, 0, L, Lp, s));
+        TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
+        TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+        TRY(showo_gemm_bf16(l.h, H, w.w1, H, w.b1, 0, l.f, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));
+        TRY(showo_gelu_bf16(l.f, e->ffn, (int64_t)T * F, s));
+        TRY(showo_gemm_bf16(e->ffn, F, w.w2, F, w.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+    }
+    TRY(showo_layernorm_f32_bf16(e->x, e->fln_w, e->fln_b, e->hf, nullptr, T, H, e->cfg.ln_eps, s));
+    TRY(showo_gemm_bf16(e->hf, H, e->wlm, H, e->blm, 0, t->logits, V, nullptr, 0, T, V, H, SHOWO_EPI_F32, s));
+    if (logits_out) SHOWO_CHECK_HIP(hipMemcpyAsync(logits_out, t->logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s));
+    t->B = B; t->Lq = L;
+    t->have_fwd = true;
+    t->has_mask = mask != nullptr;
+    if (labels) {
+        TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, 0.f, 0.f, 0.f, t->ce_rows, t->counts,
+                          t->rowloss, nullptr, 0, t->losses, s));
+        if (losses_out) SHOWO_CHECK_HIP(hipMemcpyAsync(losses_out, t->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+// d(g_t2i loss_t2i + g_lm loss_lm + g_mmu loss_mmu) / d(parameters) of the last showo_train_forward
+extern "C" int showo_train_backward(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len,
+                                    float g_t2i, float g_lm, float g_mmu, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!t || !t->have_fwd) return set_error_msg(1, "train_backward: run showo_train_forward first");
+    if (!labels) return set_error_msg(1, "train_backward: labels required");
+    showo_engine* e = t->e;
+    const int H = e->H, F = e->F, V = e->V, nH = e->nH, B = t->B, L = t->Lq, T = B * L, Vp = t->Vp;
+    const int Tp = ((T + 63) / 64) * 64, Lp = ((L + 63) / 64) * 64;
+    const int32_t* iv = t->has_mask ? e->iv : nullptr;  // compressed by the forward (no mask -> causal)
+    // ---- loss + head
+    TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, g_t2i, g_lm, g_mmu, t->ce_rows, t->counts,
+                      t->rowloss, t->dlogits, Vp, nullptr, s));
+    TRY(showo_transpose_bf16(t->dlogits, Vp, t->bigT, T, Vp, Tp, 0, t->colpart, t->gblm, 0, s));  // dlogits^T + lm_head bias grad
+    TRY(showo_transpose_bf16(e->hf, H, t->xT, T, H, Tp, 0, nullptr, nullptr, 0, s));
+    TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, t->gwlm, H, nullptr, 0, V, H, Tp, SHOWO_EPI_F32, s));      // dWlm [V,H]
+    TRY(showo_gemm_bf16(t->dlogits, Vp, t->wlmT, Vp, nullptr, 0, t->dh, H, nullptr, 0, T, H, Vp, SHOWO_EPI_F32, s));   // d hf
+    SHOWO_CHECK_HIP(hipMemsetAsync(t->dy, 0, (size_t)T * H * sizeof(float), s));
+    TRY(showo_ln_bwd(e->x, e->fln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, t->gfln, T, H, e->cfg.ln_eps, s));
+    // ---- blocks, last to first
+    for (int i = e->nL - 1; i >= 0; --i) {
+        Layer& w = e->layers[i];
+        LayerT& l = t->L[i];
+        // dy^T (+ bias grads of fc2 and dense: both are column sums of dy)
+        TRY(showo_transpose_bf16(t->dy16, H, t->bigT, T, H, Tp, 0, t->colpart, l.gb2, 0, s));
+        SHOWO_CHECK_HIP(hipMemcpyAsync(l.gbd, l.gb2, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        // MLP
+        TRY(showo_transpose_bf16(l.f, F, t->xT, T, F, Tp, 1, nullptr, nullptr, 0, s));                                      // gelu(f)^T
+        TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, l.gw2, F, nullptr, 0, H, F, Tp, SHOWO_EPI_F32, s));         // dW2 [H,F]
+        TRY(showo_transpose_bf16(l.attn, H, t->xT, T, H, Tp, 0, nullptr, nullptr, 0, s));                                   // attn^T
+        TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, l.gwd, H, nullptr, 0, H, H, Tp, SHOWO_EPI_F32, s));         // dWd [H,H]
+        TRY(showo_gemm_bf16(t->dy16, H, l.w2T, H, nullptr, 0, t->dff, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));          // d a
+        TRY(showo_dgelu_bf16(t->dff, l.f, t->dff, (int64_t)T * F, s));                                                      // d f
+        TRY(showo_transpose_bf16(t->dff, F, t->bigT, T, F, Tp, 0, t->colpart, l.gb1, 0, s));                                // df^T, db1
+        TRY(showo_transpose_bf16(l.h, H, t->xT, T, H, Tp, 0, nullptr, nullptr, 0, s));                                      // h^T
+        TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, l.gw1, H, nullptr, 0, F, H, Tp, SHOWO_EPI_F32, s));         // dW1 [F,H]
+        TRY(showo_gemm_bf16(t->dff, F, l.w1T, F, nullptr, 0, t->dh, H, nullptr, 0, T, H, F, SHOWO_EPI_F32, s));             // dh (mlp)
+        // attention
+        TRY(showo_gemm_bf16(t->dy16, H, l.wdT, H, nullptr, 0, t->d_o, H, nullptr, 0, T, H, H, SHOWO_EPI_BF16, s));          // d o
+        TRY(showo_head_transpose(l.Q, t->QT, B, nH, L, Lp, (int64_t)nH * L * 64, (int64_t)L * 64, 64, s));
+        TRY(showo_head_transpose(l.K, t->KT, B, nH, L, Lp, (int64_t)nH * L * 64, (int64_t)L * 64, 64, s));
+        TRY(showo_attn_bwd(l.Q, l.K, t->QT, t->KT, l.qkv + 2 * H, 3 * H, l.attn, t->d_o, H, t->dOT, l.lse, t->D, iv, nullptr, t->dqk, 2 * H,
+                           t->dqk + H, 2 * H, t->dqkv + 2 * H, 3 * H, B, nH, L, Lp, s));
+        TRY(showo_qkln_rope_bwd(t->dqk, t->dqk + H, 2 * H, l.qkv, w.qln_w, w.kln_w, e->cosT, e->sinT, t->dqkv, t->qkpart, l.gqk, T, L,
+                                nH, e->cfg.rotary_dim, e->cfg.ln_eps, s));
+        TRY(showo_transpose_bf16(t->dqkv, 3 * H, t->bigT, T, 3 * H, Tp, 0, t->colpart, l.gbqkv, 0, s));                     // dqkv^T, dbqkv
+        TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, l.gwqkv, H, nullptr, 0, 3 * H, H, Tp, SHOWO_EPI_F32, s));   // dWqkv (xT = h^T)
+        TRY(showo_gemm_bf16(t->dqkv, 3 * H, l.wqkvT, 3 * H, nullptr, 0, t->dh, H, t->dh, H, T, H, 3 * H, SHOWO_EPI_RESID_F32, s));  // dh += attn part
+        // LayerNorm + residual
+        TRY(showo_ln_bwd(l.x, w.ln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, l.gln, T, H, e->cfg.ln_eps, s));
+    }
+    // ---- embedding
+    SHOWO_CHECK_HIP(hipMemsetAsync(t->gembed, 0, (size_t)V * H * sizeof(float), s));
+    TRY(showo_embed_bwd(t->ids, t->dy, t->gembed, t->order_ws, T, H, V, s));
+    return 0;
+}
+
+extern "C" int showo_train_grad(showo_trainer* t, const char* key, float** ptr, int64_t* n) {
+    if (!t || !key || !ptr || !n) return set_error_msg(1, "train_grad: null argument");
+    auto it = t->grads.find(key);
+    if (it == t->grads.end()) return set_error_msg(3, "train_grad: unknown state-dict key");
+    *ptr = it->second.p;
+    *n = it->second.n;
+    return 0;
+}
+
+extern "C" int showo_train_losses(showo_trainer* t, float* out3, void* stream) {
+    if (!t || !out3) return set_error_msg(1, "train_losses: null argument");
+    SHOWO_CHECK_HIP(hipMemcpyAsync(out3, t->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int showo_train_grad_copy(showo_trainer* t, const char* key, float* dst, int64_t n, void* stream) {
+    float* p = nullptr;
+    int64_t m = 0;
+    TRY(showo_train_grad(t, key, &p, &m));
+    if (m != n) return set_error_msg(2, "train_grad_copy: element count mismatch");
+    SHOWO_CHECK_HIP(hipMemcpyAsync(dst, p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      bf16_t* __restrict__ dx16, float* __restrict__ part, int T, int H, float eps) {
     extern __shared__ float red[];  // [4][2][H] cross-wave reduction of the column partials
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nv = H / 256;  // float4 groups per lane (H % 256 == 0)
+    const int nv = (H + 255) / 256;  // float4 groups per lane (H % 4 == 0; lanes past the row end idle)
     float ag[8][4], ab[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i < nv) {
+            if (i < nv && (i * 64 + lane) * 4 < H) {
                 xv[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
                 s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
             }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i < nv) {
+            if (i < nv && (i * 64 + lane) * 4 < H) {
                 xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
                 q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
             }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat) with g = dh * gamma
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i < nv) {
+            if (i < nv && (i * 64 + lane) * 4 < H) {
                 const int c = (i * 64 + lane) * 4;
                 const float4 d = *reinterpret_cast<const float4*>(gr + c);
                 const float4 w = *reinterpret_cast<const float4*>(gamma + c);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i < nv) {
+            if (i < nv && (i * 64 + lane) * 4 < H) {
                 const int c = (i * 64 + lane) * 4;
                 float4 o = *reinterpret_cast<const float4*>(dy + (int64_t)r * H + c);
                 o.x += rstd * (gv[i].x - m1 - xv[i].x * m2);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     // block partials: red[wave][0|1][c]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        if (i < nv) {
+        if (i < nv && (i * 64 + lane) * 4 < H) {
             const int c = (i * 64 + lane) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -402,6 +402,21 @@ __global__ void scale_f32_kernel(float* __restrict__ x, int64_t n, float s) {
     for (; i < n; i += stride) x[i] *= s;
 }
 
+__global__ void gelu_kernel(const bf16_t* __restrict__ f, bf16_t* __restrict__ a, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+    for (; i < n; i += stride) {
+        const uint4 b = *reinterpret_cast<const uint4*>(f + i);
+        const bf16_t* eb = reinterpret_cast<const bf16_t*>(&b);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = gelu_new_f(bf2f(eb[j]));
+        uint4 u;
+        u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(a + i) = u;
+    }
+}
+
 // dgrad epilogue helper: d_f bf16 = d_a (bf16) * gelu_new'(f)   (elementwise, when not fused in a GEMM epilogue)
 __global__ void dgelu_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ f, bf16_t* __restrict__ df, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -437,7 +452,7 @@ extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int
 extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16,
                             float* part, float* dgb, int T, int H, float eps, void* stream) {
     if (T <= 0) return 0;
-    if ((H % 256) || H > 2048) return set_error_msg(1, "ln_bwd: H must be a multiple of 256 and <= 2048");
+    if ((H % 4) || H > 2048) return set_error_msg(1, "ln_bwd: H must be a multiple of 4 and <= 2048");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (T + LNB_ROWS - 1) / LNB_ROWS;
     static bool attr_set = false;
@@ -524,6 +539,16 @@ extern "C" int showo_dgelu_bf16(const uint16_t* da, const uint16_t* f, uint16_t*
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 65536) blocks = 65536;
     dgelu_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(da, f, df, n);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_gelu_bf16(const uint16_t* f, uint16_t* a, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return set_error_msg(1, "gelu: n % 8 == 0 required");
+    int blocks = (int)((n / 8 + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    gelu_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(f, a, n);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

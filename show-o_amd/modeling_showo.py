@@ -108,6 +108,46 @@ class _PhiForCausalLMParams(nn.Module):
         return self.model.embed_tokens
 
 
+class _ShowoTrainFn(torch.autograd.Function):
+    """Showo.forward with labels (reference models/modeling_showo.py:80-102) as one autograd node: forward runs the HIP
+    training forward (activations stay in the trainer), backward runs the HIP backward for the incoming loss weights
+    and hands the parameter gradients (reference names and shapes) back to autograd."""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, attention_mask, labels, b_t2i, b_lm, b_mmu, max_seq_length, *params):
+        tr = model.trainer()
+        B, L = input_ids.shape
+        ids = input_ids.to(torch.int64).contiguous()
+        lab = labels.to(torch.int64).contiguous()
+        mask = None
+        if attention_mask is not None:
+            if tuple(attention_mask.shape) != (B, 1, L, L):
+                raise ValueError(f"Attention mask should be of size {(B, 1, L, L)}, but is {tuple(attention_mask.shape)}")
+            mask = attention_mask.detach().float().contiguous()
+        logits = torch.empty((B, L, model.vocab_size), dtype=torch.float32, device=ids.device)
+        losses = torch.empty(3, dtype=torch.float32, device=ids.device)
+        _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
+                  max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
+        ctx.model, ctx.lab, ctx.meta = model, lab, (b_t2i, b_lm, b_mmu, max_seq_length)
+        ctx.names = ["showo." + n for n, _ in model.showo.named_parameters()]
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.mark_non_differentiable(logits)
+        return logits, losses[0].clone(), losses[1].clone(), losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_logits, g_t2i, g_lm, g_mmu):
+        model = ctx.model
+        g = [0.0 if x is None else float(x) for x in (g_t2i, g_lm, g_mmu)]
+        b_t2i, b_lm, b_mmu, msl = ctx.meta
+        _lib.call("showo_train_backward", model._trainer, _lib.ptr(ctx.lab), b_t2i, b_lm, b_mmu, msl, g[0], g[1], g[2], _lib.stream())
+        grads = []
+        for name, shape in zip(ctx.names, ctx.shapes):
+            t = torch.empty(shape, dtype=torch.float32, device=ctx.lab.device)
+            _lib.call("showo_train_grad_copy", model._trainer, name.encode(), _lib.ptr(t), t.numel(), _lib.stream())
+            grads.append(t)
+        return (None,) * 8 + tuple(grads)
+
+
 class Showo(nn.Module):
     _supports_gradient_checkpointing = True
 
@@ -134,6 +174,8 @@ class Showo(nn.Module):
         self._engine = None
         self._engine_key = None
         self._engine_versions = None
+        self._trainer = None
+        self._weights_changed = True
         self.max_batch = int(kwargs.get("max_batch", 32))
         self.max_seq = int(kwargs.get("max_seq", 1280))
 
@@ -163,9 +205,26 @@ class Showo(nn.Module):
         self._drop_engine()
 
     def _drop_engine(self):
+        if getattr(self, "_trainer", None) is not None:
+            _lib.load().showo_train_destroy(self._trainer)
+            self._trainer = None
         if self._engine is not None:
             _lib.load().showo_engine_destroy(self._engine)
         self._engine, self._engine_versions = None, None
+
+    def trainer(self):
+        """HIP training state (saved activations, transposed weight images, fp32 gradient buffers); created lazily."""
+        eng = self.engine()
+        if self._trainer is None:
+            import ctypes as C
+            h = C.c_void_p()
+            _lib.check(_lib.load().showo_train_create(eng, self.max_batch, self.max_seq, C.byref(h)), "showo_train_create")
+            self._trainer = h
+            self._weights_changed = True
+        if self._weights_changed:
+            _lib.call("showo_train_invalidate_weights", self._trainer)
+            self._weights_changed = False
+        return self._trainer
 
     def __del__(self):
         try:
@@ -212,6 +271,7 @@ class Showo(nn.Module):
         for k, v in self._engine_params():
             ver = (v.data_ptr(), v._version)
             if self._engine_versions.get(k) != ver:
+                self._weights_changed = True
                 src = v.detach()
                 if src.dtype != torch.float32 or not src.is_contiguous():
                     src = src.float().contiguous()
@@ -228,6 +288,12 @@ class Showo(nn.Module):
     def forward(self, input_ids, input_embeddings=None, attention_mask=None, labels=None, label_smoothing=0.0,
                 batch_size_t2i=0, batch_size_lm=0, batch_size_mmu=0, max_seq_length=128, labels_mask_text=None,
                 labels_mask_image=None, **kwargs):
+        if labels is not None:
+            if input_embeddings is not None:
+                raise NotImplementedError("training from input_embeddings (w_clip_vit) is not on the HIP path yet")
+            params = [p for _, p in self.showo.named_parameters()]
+            return _ShowoTrainFn.apply(self, input_ids, attention_mask, labels, int(batch_size_t2i), int(batch_size_lm),
+                                       int(batch_size_mmu), int(max_seq_length), *params)
         eng = self.engine()
         if input_embeddings is None:
             B, L = input_ids.shape
@@ -249,7 +315,7 @@ class Showo(nn.Module):
                   _lib.stream())
         if labels is None:
             return logits
-        raise NotImplementedError("training losses/backward on the HIP path land in a later round (SURVEY.md §8 rows T1/T2)")
+        raise AssertionError("unreachable")
 
     # ---- Showo.t2i_generate (reference models/modeling_showo.py:104-181) -----------------------------------
     def t2i_generate(self, input_ids=None, uncond_input_ids=None, attention_mask=None, temperature=1.0, timesteps=18,

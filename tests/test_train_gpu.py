@@ -115,7 +115,7 @@ def test_transpose_colsum_and_gelu_mode():
     assert (got[:, :T] - O.gelu_new(x).T).abs().max() < 2 ** -8 * 4 and (got[:, T:] == 0).all()
 
 
-@pytest.mark.parametrize("T,H", [(37, 256), (100, 2048)])
+@pytest.mark.parametrize("T,H", [(37, 256), (100, 2048), (50, 128)])
 def test_layernorm_backward(T, H):
     torch.manual_seed(T)
     x = (torch.randn(T, H) * 1.5 + 0.2).requires_grad_(True)
@@ -243,3 +243,48 @@ def test_dgelu():
     out = torch.zeros((64, 128), dtype=torch.int16, device="cuda")
     L().call("showo_dgelu_bf16", L().ptr(_bits(da)), L().ptr(_bits(f.detach())), L().ptr(out), 64 * 128, S())
     assert (from_bf16_bits(out).cpu() - f.grad).abs().max() < 2 ** -8 * float(f.grad.abs().max()) + 1e-6
+
+
+def test_tiny_training_step_vs_reference_golden():
+    """Showo.forward with labels + backward on the mixed 2 t2i + 1 lm + 2 mmu batch of the golden file: the three losses
+    and the parameter gradients the REFERENCE produced (oracle/make_golden.py) vs the HIP training path (bf16 operands)."""
+    g = util.golden("showo_tiny_forward.npz")
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd).train()
+    ids, mask, labels = dev(g["train_ids"]), dev(g["train_mask"]), dev(g["train_labels"])
+    logits, l1, l2, l3 = m(ids, attention_mask=mask, labels=labels, batch_size_t2i=2, batch_size_lm=1, batch_size_mmu=2,
+                           max_seq_length=d.max_text_len)
+    want = g["train_losses"]
+    got = [float(l1), float(l2), float(l3)]
+    print(f"[parity] tiny training losses {got} reference {want.tolist()}")
+    for a, b in zip(got, want):
+        assert abs(a - b) < 5e-3 * abs(b)
+    rmax, rrms = util.relerr(logits, torch.from_numpy(g["train_logits"]))
+    assert rrms < 1e-2
+    (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("grad::showo"):
+            continue
+        name = k[len("grad::"):]
+        gr = named[name].grad
+        assert gr is not None, name
+        rmax, rrms = util.relerr(gr, torch.from_numpy(g[k]))
+        print(f"[parity] grad {name}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+        worst = max(worst, rrms)
+        assert rrms < 3e-2 and rmax < 8e-2, name
+    rows = torch.from_numpy(g["grad::embed_row_ids"])
+    ge = named["showo.model.embed_tokens.weight"].grad[rows.cuda()]
+    rmax, rrms = util.relerr(ge, torch.from_numpy(g["grad::embed_rows"]))
+    print(f"[parity] grad embed rows: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rrms < 3e-2
+    # a second backward pass gives bit-identical gradients (fixed-order reductions)
+    g1 = {n: p.grad.clone() for n, p in named.items() if p.grad is not None}
+    m.zero_grad()
+    logits, l1, l2, l3 = m(ids, attention_mask=mask, labels=labels, batch_size_t2i=2, batch_size_lm=1, batch_size_mmu=2,
+                           max_seq_length=d.max_text_len)
+    (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+    for n, p in named.items():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g1[n]), n
