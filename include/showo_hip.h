@@ -324,6 +324,15 @@ int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask,
 /* gradients of g_t2i*loss_t2i + g_lm*loss_lm + g_mmu*loss_mmu of the last forward w.r.t. every parameter */
 int showo_train_backward(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len, float g_t2i,
                          float g_lm, float g_mmu, void* stream);
+/* the same backward in three phases (head -> blocks nL-1 .. 0 -> embedding): a data-parallel driver starts the gradient
+ * exchange of a finished bucket while the next phase runs */
+int showo_train_backward_head(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len,
+                              float g_t2i, float g_lm, float g_mmu, void* stream);
+int showo_train_backward_layer(showo_trainer* t, int layer, void* stream);
+int showo_train_backward_embed(showo_trainer* t, void* stream);
+/* all gradients live in one flat fp32 buffer; bucket 0 = embedding, 1 + i = block i, nL + 1 = head */
+int showo_train_num_buckets(showo_trainer* t);
+int showo_train_bucket(showo_trainer* t, int bucket, float** ptr, int64_t* n);
 /* gradient buffer of a reference state-dict key (device pointer, element count) / copy of it */
 int showo_train_grad(showo_trainer* t, const char* key, float** ptr, int64_t* n);
 int showo_train_grad_copy(showo_trainer* t, const char* key, float* dst, int64_t n, void* stream);

@@ -49,6 +49,11 @@ _PROTOS = {
     "showo_train_invalidate_weights": [c_p],
     "showo_train_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "showo_train_backward": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
+    "showo_train_backward_head": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
+    "showo_train_backward_layer": [c_p, c_i, c_p],
+    "showo_train_backward_embed": [c_p, c_p],
+    "showo_train_num_buckets": [c_p],
+    "showo_train_bucket": [c_p, c_i, c_p, c_p],
     "showo_train_grad": [c_p, C.c_char_p, c_p, c_p],
     "showo_train_grad_copy": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_train_losses": [c_p, c_p, c_p],

@@ -70,10 +70,21 @@ struct showo_trainer {
         *p = (T*)q;
         return 0;
     }
+    // gradients live in ONE flat fp32 buffer (bucket = contiguous range: embed | layer 0 .. nL-1 | head), so a data-parallel
+    // job all-reduces a bucket with one collective while the backward of the next block runs
+    float* gflat = nullptr;
+    int64_t gflat_n = 0, gcursor = 0;
+    std::vector<std::pair<int64_t, int64_t>> buckets;  // (offset, count)
+    float* carve(int64_t n) {
+        n = (n + 63) & ~(int64_t)63;  // keep every tensor 256-B aligned
+        float* p = gflat + gcursor;
+        gcursor += n;
+        return p;
+    }
     int galloc(const std::string& key, float** p, int64_t n) {
-        int rc = alloc(p, n);
-        if (!rc) grads[key] = Grad{*p, n};
-        return rc;
+        *p = carve(n);
+        grads[key] = Grad{*p, n};
+        return 0;
     }
 };
 
@@ -94,6 +105,15 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     int rc = 0;
     t->L.resize(e->nL);
     char key[160];
+    {
+        auto al = [](int64_t n) { return (n + 63) & ~(int64_t)63; };
+        const int64_t per_layer = al(3 * H * H) + al(3 * H) + al(H * H) + al(H) + al(F * H) + al(F) + al(H * F) + al(H) + al(2 * H) + al(256);
+        t->gflat_n = al(V * H) + e->nL * per_layer + al(2 * H) + al(V * H) + al(Vp);
+        rc |= t->alloc(&t->gflat, t->gflat_n);
+        if (rc) { showo_train_destroy(t); return rc; }
+        hipMemset(t->gflat, 0, (size_t)t->gflat_n * sizeof(float));
+    }
+    { int64_t c0 = t->gcursor; t->galloc("showo.model.embed_tokens.weight", &t->gembed, V * H); t->buckets.push_back({c0, t->gcursor - c0}); }
     for (int i = 0; i < e->nL; ++i) {
         LayerT& l = t->L[i];
         rc |= t->alloc(&l.wqkvT, H * 3 * H); rc |= t->alloc(&l.wdT, H * H); rc |= t->alloc(&l.w1T, H * F); rc |= t->alloc(&l.w2T, F * H);
@@ -103,7 +123,8 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
         if (rc) break;
         hipMemset(l.Vt, 0, (size_t)max_batch * H * t->Lp * sizeof(bf16_t));
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
-        rc |= t->alloc(&l.gwqkv, 3 * H * H); rc |= t->alloc(&l.gbqkv, 3 * H);
+        const int64_t lc0 = t->gcursor;
+        l.gwqkv = t->carve(3 * H * H); l.gbqkv = t->carve(3 * H);
         for (int j = 0; j < 3 && !rc; ++j) {
             snprintf(key, sizeof key, "showo.model.layers.%d.self_attn.%s.weight", i, names[j]);
             t->grads[key] = Grad{l.gwqkv + j * H * H, H * H};
@@ -116,9 +137,9 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
         snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc1.bias", i); rc |= t->galloc(key, &l.gb1, F);
         snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc2.weight", i); rc |= t->galloc(key, &l.gw2, H * F);
         snprintf(key, sizeof key, "showo.model.layers.%d.mlp.fc2.bias", i); rc |= t->galloc(key, &l.gb2, H);
-        rc |= t->alloc(&l.gln, 2 * H);
-        rc |= t->alloc(&l.gqk, 256);
-        if (rc) break;
+        l.gln = t->carve(2 * H);
+        l.gqk = t->carve(256);
+        t->buckets.push_back({lc0, t->gcursor - lc0});
         snprintf(key, sizeof key, "showo.model.layers.%d.input_layernorm.weight", i); t->grads[key] = Grad{l.gln, H};
         snprintf(key, sizeof key, "showo.model.layers.%d.input_layernorm.bias", i); t->grads[key] = Grad{l.gln + H, H};
         const char* qk[4] = {"q_layernorm.weight", "q_layernorm.bias", "k_layernorm.weight", "k_layernorm.bias"};
@@ -128,10 +149,11 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
         }
     }
     rc |= t->alloc(&t->wlmT, H * Vp);
-    rc |= t->galloc("showo.model.embed_tokens.weight", &t->gembed, V * H);
-    rc |= t->alloc(&t->gfln, 2 * H);
-    rc |= t->galloc("showo.lm_head.weight", &t->gwlm, V * H);
-    rc |= t->galloc("showo.lm_head.bias", &t->gblm, Vp);
+    const int64_t hc0 = t->gcursor;
+    t->gfln = t->carve(2 * H);
+    t->galloc("showo.lm_head.weight", &t->gwlm, V * H);
+    t->galloc("showo.lm_head.bias", &t->gblm, Vp);
+    t->buckets.push_back({hc0, t->gcursor - hc0});
     if (!rc) {
         t->grads["showo.lm_head.bias"].n = V;
         t->grads["showo.model.final_layernorm.weight"] = Grad{t->gfln, H};
@@ -238,16 +260,21 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
     return 0;
 }
 
-// d(g_t2i loss_t2i + g_lm loss_lm + g_mmu loss_mmu) / d(parameters) of the last showo_train_forward
-extern "C" int showo_train_backward(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len,
-                                    float g_t2i, float g_lm, float g_mmu, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (!t || !t->have_fwd) return set_error_msg(1, "train_backward: run showo_train_forward first");
+// ---- backward, in three phases so that a data-parallel driver can start the gradient exchange of a finished bucket
+// while the next block is still running: head (bucket nL+1) -> blocks nL-1 .. 0 (buckets i+1) -> embedding (bucket 0)
+#define BW_PROLOGUE                                                                                                   \
+    hipStream_t s = (hipStream_t)stream;                                                                              \
+    if (!t || !t->have_fwd) return set_error_msg(1, "train_backward: run showo_train_forward first");                  \
+    showo_engine* e = t->e;                                                                                           \
+    const int H = e->H, F = e->F, V = e->V, nH = e->nH, B = t->B, L = t->Lq, T = B * L, Vp = t->Vp;                    \
+    const int Tp = ((T + 63) / 64) * 64, Lp = ((L + 63) / 64) * 64;                                                   \
+    const int32_t* iv = t->has_mask ? e->iv : nullptr;                                                                \
+    (void)F; (void)V; (void)nH; (void)Vp; (void)Tp; (void)Lp; (void)iv; (void)s;
+
+extern "C" int showo_train_backward_head(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len,
+                                         float g_t2i, float g_lm, float g_mmu, void* stream) {
+    BW_PROLOGUE
     if (!labels) return set_error_msg(1, "train_backward: labels required");
-    showo_engine* e = t->e;
-    const int H = e->H, F = e->F, V = e->V, nH = e->nH, B = t->B, L = t->Lq, T = B * L, Vp = t->Vp;
-    const int Tp = ((T + 63) / 64) * 64, Lp = ((L + 63) / 64) * 64;
-    const int32_t* iv = t->has_mask ? e->iv : nullptr;  // compressed by the forward (no mask -> causal)
     // ---- loss + head
     TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, g_t2i, g_lm, g_mmu, t->ce_rows, t->counts,
                       t->rowloss, t->dlogits, Vp, nullptr, s));
@@ -257,8 +284,13 @@ extern "C" int showo_train_backward(showo_trainer* t, const int64_t* labels, int
     TRY(showo_gemm_bf16(t->dlogits, Vp, t->wlmT, Vp, nullptr, 0, t->dh, H, nullptr, 0, T, H, Vp, SHOWO_EPI_F32, s));   // d hf
     SHOWO_CHECK_HIP(hipMemsetAsync(t->dy, 0, (size_t)T * H * sizeof(float), s));
     TRY(showo_ln_bwd(e->x, e->fln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, t->gfln, T, H, e->cfg.ln_eps, s));
-    // ---- blocks, last to first
-    for (int i = e->nL - 1; i >= 0; --i) {
+    return 0;
+}
+
+extern "C" int showo_train_backward_layer(showo_trainer* t, int i, void* stream) {
+    BW_PROLOGUE
+    if (i < 0 || i >= e->nL) return set_error_msg(1, "train_backward_layer: bad layer index");
+    {
         Layer& w = e->layers[i];
         LayerT& l = t->L[i];
         // dy^T (+ bias grads of fc2 and dense: both are column sums of dy)
@@ -288,12 +320,34 @@ extern "C" int showo_train_backward(showo_trainer* t, const int64_t* labels, int
         TRY(showo_gemm_bf16(t->dqkv, 3 * H, l.wqkvT, 3 * H, nullptr, 0, t->dh, H, t->dh, H, T, H, 3 * H, SHOWO_EPI_RESID_F32, s));  // dh += attn part
         // LayerNorm + residual
         TRY(showo_ln_bwd(l.x, w.ln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, l.gln, T, H, e->cfg.ln_eps, s));
-    }
+        }
+    return 0;
+}
+
+extern "C" int showo_train_backward_embed(showo_trainer* t, void* stream) {
+    BW_PROLOGUE
     // ---- embedding
     SHOWO_CHECK_HIP(hipMemsetAsync(t->gembed, 0, (size_t)V * H * sizeof(float), s));
     TRY(showo_embed_bwd(t->ids, t->dy, t->gembed, t->order_ws, T, H, V, s));
     return 0;
 }
+
+// d(g_t2i loss_t2i + g_lm loss_lm + g_mmu loss_mmu) / d(parameters) of the last showo_train_forward
+extern "C" int showo_train_backward(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len,
+                                    float g_t2i, float g_lm, float g_mmu, void* stream) {
+    TRY(showo_train_backward_head(t, labels, b_t2i, b_lm, b_mmu, max_seq_len, g_t2i, g_lm, g_mmu, stream));
+    for (int i = t->e->nL - 1; i >= 0; --i) TRY(showo_train_backward_layer(t, i, stream));
+    return showo_train_backward_embed(t, stream);
+}
+
+// bucket b of the flat gradient buffer: 0 = embedding, 1 + i = block i, nL + 1 = head (final LayerNorm, lm_head)
+extern "C" int showo_train_bucket(showo_trainer* t, int b, float** ptr, int64_t* n) {
+    if (!t || !ptr || !n || b < 0 || b >= (int)t->buckets.size()) return set_error_msg(1, "train_bucket: bad argument");
+    *ptr = t->gflat + t->buckets[b].first;
+    *n = t->buckets[b].second;
+    return 0;
+}
+extern "C" int showo_train_num_buckets(showo_trainer* t) { return t ? (int)t->buckets.size() : -1; }
 
 extern "C" int showo_train_grad(showo_trainer* t, const char* key, float** ptr, int64_t* n) {
     if (!t || !key || !ptr || !n) return set_error_msg(1, "train_grad: null argument");

@@ -1,0 +1,107 @@
+"""Data-parallel training step on the HIP path (reference training/train.py:510-628 + accelerate/DeepSpeed gradient
+exchange, accelerate_configs/*.yaml).
+
+`Trainer.step()` = Showo.forward with labels -> backward -> gradient exchange -> AdamW, all on HIP kernels; the only
+collective of the step is the gradient average (RCCL through torch.distributed, one all-reduce per gradient bucket:
+head, then transformer blocks last to first, then the embedding), issued as soon as the bucket's backward kernels are
+queued so that it overlaps the backward of the next block.  One process per GPU; every rank draws its own batch and the
+three losses are per-rank means, averaged across ranks by the gradient average exactly as DDP does.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+NO_DECAY = ("bias", "layer_norm.weight", "mlm_ln.weight", "embeddings.weight")  # reference training/train.py:211
+
+
+class _DevView:
+    """zero-copy torch view of a raw device buffer owned by the HIP library (__cuda_array_interface__ v2)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, n, device):
+    return torch.as_tensor(_DevView(ptr, n), device=device)
+
+
+def average_buckets(buckets, group=None, async_op=True):
+    """average every tensor of `buckets` over the process group (SUM then 1/world: AVG is not available on gloo)"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    works = []
+    for b in buckets:
+        w = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        works.append((w, b))
+    for w, b in works:
+        if w is not None:
+            w.wait()
+        b.mul_(1.0 / world)
+    return buckets
+
+
+class Trainer:
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0), group=None):
+        self.model, self.lr, self.betas, self.eps, self.wd, self.coeffs, self.group = model, lr, betas, eps, weight_decay, coeffs, group
+        self.step_count = 0
+        self.params = [("showo." + n, p) for n, p in model.showo.named_parameters()]
+        dev = self.params[0][1].device
+        self.m = {n: torch.zeros_like(p) for n, p in self.params}
+        self.v = {n: torch.zeros_like(p) for n, p in self.params}
+        self.tr = model.trainer()
+        lib = _lib.load()
+        self.buckets = []
+        for b in range(lib.showo_train_num_buckets(self.tr)):
+            ptr, n = C.c_void_p(), C.c_int64()
+            _lib.check(lib.showo_train_bucket(self.tr, b, C.byref(ptr), C.byref(n)), "showo_train_bucket")
+            self.buckets.append(device_view(ptr.value, n.value, dev))
+        self.grad_ptr = {}
+        for n, p in self.params:
+            ptr, cnt = C.c_void_p(), C.c_int64()
+            _lib.check(lib.showo_train_grad(self.tr, n.encode(), C.byref(ptr), C.byref(cnt)), "showo_train_grad")
+            assert cnt.value == p.numel(), n
+            self.grad_ptr[n] = ptr.value
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) else None
+
+    def _exchange(self, bucket, works):
+        if self.dist is None:
+            return
+        works.append((self.dist.all_reduce(self.buckets[bucket], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), bucket))
+
+    def step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
+        """one optimisation step; returns the three losses (fp32 device tensor [3])"""
+        m, tr, s = self.model, self.tr, _lib.stream
+        tr = m.trainer()  # re-syncs the transposed weight images if the weights changed
+        B, L = input_ids.shape
+        ids = input_ids.to(torch.int64).contiguous()
+        lab = labels.to(torch.int64).contiguous()
+        mask = None if attention_mask is None else attention_mask.detach().float().contiguous()
+        losses = torch.empty(3, dtype=torch.float32, device=ids.device)
+        _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
+                  batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
+        works = []
+        nL = m.arch["num_hidden_layers"]
+        _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,
+                  self.coeffs[0], self.coeffs[1], self.coeffs[2], s())
+        self._exchange(nL + 1, works)
+        for i in range(nL - 1, -1, -1):
+            _lib.call("showo_train_backward_layer", tr, i, s())
+            self._exchange(i + 1, works)
+        _lib.call("showo_train_backward_embed", tr, s())
+        self._exchange(0, works)
+        if self.dist is not None:
+            inv = 1.0 / self.dist.get_world_size(self.group)
+            for w, b in works:
+                w.wait()
+                _lib.call("showo_scale_f32", self.buckets[b].data_ptr(), self.buckets[b].numel(), inv, s())
+        self.step_count += 1
+        for n, p in self.params:
+            wd = 0.0 if any(nd in n for nd in NO_DECAY) else self.wd
+            _lib.call("showo_adamw", p.data_ptr(), self.grad_ptr[n], self.m[n].data_ptr(), self.v[n].data_ptr(), p.numel(), self.lr,
+                      self.betas[0], self.betas[1], self.eps, wd, self.step_count, s())
+            _lib.call("showo_engine_load", m._engine, n.encode(), p.data_ptr(), p.numel(), s())  # refresh the bf16 image
+        m._weights_changed = True
+        return losses
