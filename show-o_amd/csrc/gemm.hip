@@ -1165,15 +1165,11 @@ int pick_bm(int M, int N) {
         int dev = 0;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
     }
-    const int cand[3] = {256, 208, 160};
+    // measured (tools/gemm_bench.cpp, bench.py A/B): the kernels run power-limited, so a shorter tile only pays when it
+    // removes a mostly idle last round; 160 never won at the shapes of this model and is only selectable explicitly
     const int tilesN = (N + B2 - 1) / B2;
-    int best = 256;
-    long bestc = -1;
-    for (int c : cand) {
-        long tiles = (long)((M + c - 1) / c) * tilesN;
-        long cost = ((tiles + cus - 1) / cus) * c;
-        if (bestc < 0 || cost < bestc) { bestc = cost; best = c; }
-    }
+    auto cost = [&](int c) { long tiles = (long)((M + c - 1) / c) * tilesN; return ((tiles + cus - 1) / cus) * c; };
+    const int best = (cost(208) * 10 <= cost(256) * 9) ? 208 : 256;
     return best;
 }
 

@@ -74,13 +74,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         if (tid < 64 && c0 + tid < C) colpart[(int64_t)blockIdx.y * C + c0 + tid] = (cs[0][tid] + cs[1][tid]) + (cs[2][tid] + cs[3][tid]);
     }
 }
-// out[c] (+)= sum over blocks of part[blk][c], in block order
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(int64_t)k * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+// out[c] (+)= sum over blocks of part[blk][c].  Fixed order: 8 interleaved subsets (block k belongs to subset k % 8, summed in
+// block order), combined as ((0+1)+(2+3))+((4+5)+(6+7)) -- bit-reproducible.  A block covers 64 columns: wave w sums
+// subsets w and w + 4 with lane = column (coalesced rows).
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C,
+                                                              int accumulate) {
+    __shared__ float sub[8][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        for (int k = w; k < nblk; k += 8) s0 += part[(int64_t)k * C + c];
+        for (int k = w + 4; k < nblk; k += 8) s1 += part[(int64_t)k * C + c];
+    }
+    sub[w][lane] = s0;
+    sub[w + 4][lane] = s1;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const float s = ((sub[0][lane] + sub[1][lane]) + (sub[2][lane] + sub[3][lane])) +
+                        ((sub[4][lane] + sub[5][lane]) + (sub[6][lane] + sub[7][lane]));
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 //        part[blk][4][64] = per-block partials of (dqln_w, dqln_b, dkln_w, dkln_b).
 //   One wave per (token, head) row, lane = head dim.
 // ------------------------------------------------------------------------------------------------
-constexpr int QKB_ROWS = 64;  // rows (token, head pairs) per wave per block
+constexpr int QKB_ROWS = 8;  // rows (token, head pairs) per wave per block (short: occupancy hides the shuffle latency)
 __global__ __launch_bounds__(256) void qkln_rope_bwd_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, int ldg,
                                                             const bf16_t* __restrict__ qkv, const float* __restrict__ qw,
                                                             const float* __restrict__ kw, const float* __restrict__ cosT,
@@ -327,19 +341,26 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         }
     }
 }
-// losses[g] = sum over rows of group g (row order) / count[g]
-__global__ void ce_finalize_kernel(const float* __restrict__ rowloss, const CeRow* __restrict__ rows, const int* __restrict__ counts,
-                                   float* __restrict__ losses, int R) {
-    const int g = threadIdx.x;
-    if (g >= 3) return;
-    double s = 0.0;
-    for (int r = 0; r < R; ++r) {
+// losses[g] = sum over the rows of group g / count[g].  Fixed order: thread t sums rows t, t+256, .. (double), then a
+// fixed binary tree over the 256 partials.
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ rowloss, const CeRow* __restrict__ rows,
+                                                          const int* __restrict__ counts, float* __restrict__ losses, int R) {
+    __shared__ double red[3][256];
+    const int t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int r = t; r < R; r += 256) {
         const int bits = rows[r].bits;
-        if (g == 0 && (bits & 1)) s += rowloss[2 * r];
-        if (g == 1 && (bits & 2)) s += rowloss[2 * r + 1];
-        if (g == 2 && (bits & 4)) s += rowloss[2 * r + 1];
+        if (bits & 1) s0 += rowloss[2 * r];
+        if (bits & 2) s1 += rowloss[2 * r + 1];
+        if (bits & 4) s2 += rowloss[2 * r + 1];
     }
-    losses[g] = (float)(s / (double)counts[g]);  // 0/0 -> nan like F.cross_entropy on an empty selection
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
+        __syncthreads();
+    }
+    if (t < 3) losses[t] = (float)(red[t][0] / (double)counts[t]);  // 0/0 -> nan like F.cross_entropy on an empty selection
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,10 +386,20 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         float* __restrict__ dE, int T, int H) {
     const int i = blockIdx.x;
     if (!runstart[i]) return;
+    int end = i + 1;
+    while (end < T && !runstart[end]) ++end;
     const int64_t id = ids[order[i]];
     for (int c = threadIdx.x * 4; c < H; c += 1024) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = i; j < T && (j == i || !runstart[j]); ++j) {
+        int j = i;
+        for (; j + 8 <= end; j += 8) {  // 8 independent row loads in flight, summed in position order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dx + (int64_t)order[j + u] * H + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; j < end; ++j) {
             const float4 v = *reinterpret_cast<const float4*>(dx + (int64_t)order[j] * H + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -444,7 +475,7 @@ extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int
     if (colsum && !colpart) return set_error_msg(1, "transpose: column sums need the partial buffer [Tp/64, C]");
     hipStream_t s = (hipStream_t)stream;
     transpose_kernel<<<dim3((C + 63) / 64, Tp / 64), dim3(256), 0, s>>>(x, xt, colsum ? colpart : nullptr, T, C, ld, Tp, mode);
-    if (colsum) colsum_finalize_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(colpart, colsum, Tp / 64, C, accumulate);
+    if (colsum) colsum_finalize_kernel<<<dim3((C + 63) / 64), dim3(256), 0, s>>>(colpart, colsum, Tp / 64, C, accumulate);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -462,7 +493,7 @@ extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh,
     }
     ln_bwd_kernel<<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, T, H, eps);
     // part is [nblk][2][H]: reduce it as a [nblk, 2H] matrix -> dgb = (dgamma[H], dbeta[H])
-    colsum_finalize_kernel<<<dim3((2 * H + 255) / 256), dim3(256), 0, s>>>(part, dgb, nblk, 2 * H, 0);
+    colsum_finalize_kernel<<<dim3((2 * H + 63) / 64), dim3(256), 0, s>>>(part, dgb, nblk, 2 * H, 0);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -477,7 +508,7 @@ extern "C" int showo_qkln_rope_bwd(const uint16_t* dq, const uint16_t* dk, int l
     const int64_t rows = (int64_t)T * nH;
     const int nblk = (int)((rows + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS));
     qkln_rope_bwd_kernel<<<dim3(nblk), dim3(256), 0, s>>>(dq, dk, ldg, qkv, qw, kw, cos_tab, sin_tab, dqkv, part, T, L, nH, eps);
-    colsum_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(part, dparams, nblk, 256, 0);  // (dqw, dqb, dkw, dkb) x 64
+    colsum_finalize_kernel<<<dim3(4), dim3(256), 0, s>>>(part, dparams, nblk, 256, 0);  // (dqw, dqb, dkw, dkb) x 64
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -494,7 +525,7 @@ extern "C" int showo_ce_loss(const float* logits, int ldl, const int64_t* labels
     SHOWO_CHECK_HIP(hipMemsetAsync(counts, 0, 3 * sizeof(int), s));
     ce_rows_kernel<<<dim3((R + 255) / 256), dim3(256), 0, s>>>(labels, rows, counts, B, L, b_t2i, b_lm, b_mmu, max_seq_len);
     ce_kernel<<<dim3(R), dim3(256), 0, s>>>(logits, ldl, rows, counts, g_t2i, g_lm, g_mmu, dlogits, ldd, rowloss, V);
-    if (losses) ce_finalize_kernel<<<dim3(1), dim3(64), 0, s>>>(rowloss, rows, counts, losses, R);
+    if (losses) ce_finalize_kernel<<<dim3(1), dim3(256), 0, s>>>(rowloss, rows, counts, losses, R);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
