@@ -89,13 +89,29 @@ def cpu_baseline(d, O, budget_s=30.0):
                       f"scaled x18/{n}; decode_code omitted (<1% of FLOPs)"}
 
 
+def aggregate(dt, units_local, dist=None, device="cpu"):
+    """whole-job numbers of a replica-parallel run: (max elapsed time over ranks, units processed by all ranks).
+    Independent units, no data-path collective: this MAX / SUM pair is the only communication of the benchmark."""
+    if dist is None:
+        return dt, units_local
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    u = torch.tensor([float(units_local)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(round(float(u.item())))
+
+
 def main():
+    if "--workload" in sys.argv and sys.argv[sys.argv.index("--workload") + 1] == "train":
+        import bench_train
+        return bench_train.main(sys.argv[1:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="t2i", help="t2i (default, the headline metric) | train (bench_train.py: stage-1 step time)")
     a = ap.parse_args()
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # shows where a stuck run is
@@ -172,10 +188,7 @@ def main():
     dt = time.perf_counter() - t0
     L.call("showo_prof_enable", 0)
     log(f"timed {a.steps} steps in {dt:.2f}s")
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, images = aggregate(dt, B * a.steps, dist, "cuda")
     ms_gemm, n_gemm, fl_gemm = C.c_double(), C.c_int64(), C.c_double()
     L.call("showo_prof_read", 0, C.byref(ms_gemm), C.byref(n_gemm), C.byref(fl_gemm))
     ms_attn, n_attn, fl_attn = C.c_double(), C.c_int64(), C.c_double()
@@ -185,7 +198,6 @@ def main():
     L.call("showo_prof_reset")
 
     if rank == 0:
-        images = B * a.steps * world
         value = images / dt
         peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
         ach = fl_gemm.value / (ms_gemm.value * 1e-3) / 1e12 if ms_gemm.value > 0 else 0.0

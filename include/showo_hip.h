@@ -337,6 +337,12 @@ int showo_train_bucket(showo_trainer* t, int bucket, float** ptr, int64_t* n);
 int showo_train_grad(showo_trainer* t, const char* key, float** ptr, int64_t* n);
 int showo_train_grad_copy(showo_trainer* t, const char* key, float* dst, int64_t n, void* stream);
 int showo_train_losses(showo_trainer* t, float* out3, void* stream);
+/* optimizer (torch.optim.AdamW with the reference's two parameter groups, training/train.py:205-231): register the fp32
+ * master tensor and the two moment buffers of a state-dict key once, then one call per step updates every parameter from
+ * the gradients of the last backward and refreshes the engine's bf16 weight images. */
+int showo_train_bind_param(showo_trainer* t, const char* key, float* param, float* exp_avg, float* exp_avg_sq, int64_t n);
+int showo_train_adamw_step(showo_trainer* t, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           void* stream);
 int showo_gelu_bf16(const uint16_t* f, uint16_t* a, int64_t n, void* stream);
 
 #ifdef __cplusplus

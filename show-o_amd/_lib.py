@@ -57,6 +57,8 @@ _PROTOS = {
     "showo_train_grad": [c_p, C.c_char_p, c_p, c_p],
     "showo_train_grad_copy": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_train_losses": [c_p, c_p, c_p],
+    "showo_train_bind_param": [c_p, C.c_char_p, c_p, c_p, c_p, c_i64],
+    "showo_train_adamw_step": [c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "showo_attn_fwd_lse": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_head_transpose": [c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i, c_p],
     "showo_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i,

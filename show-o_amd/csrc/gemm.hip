@@ -183,10 +183,13 @@ template <int EPI, class Loader, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
     Loader ld = ld_in;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);          // [2][128*64]
-    bf16_t* sA = sW + 2 * LDS_TILE;                              // [2][128*64]
-    bf16_t* sWl = sA + 2 * LDS_TILE;                             // SPLIT only
-    bf16_t* sAl = sWl + 2 * LDS_TILE;
+    // plain: [2][128*64] per operand (double-buffered, 64 KiB).  SPLIT: four operand images, SINGLE-buffered (64 KiB, two
+    // barriers per k-tile) so that two blocks share a CU and overlap each other's staging and MFMA phases.
+    constexpr int NBUF = SPLIT ? 1 : 2;
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* sA = sW + NBUF * LDS_TILE;
+    bf16_t* sWl = sA + NBUF * LDS_TILE;                          // SPLIT only
+    bf16_t* sAl = sWl + NBUF * LDS_TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = SPLIT ? 0 : (kt & 1);
         if (kt + 1 < nk) gload(kt + 1);
         const bf16_t* bW = sW + cur * LDS_TILE;
         const bf16_t* bA = sA + cur * LDS_TILE;
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) swrite(cur ^ 1);
+        if (SPLIT) __syncthreads();  // single buffer: every wave is done reading before the next tile is written
+        if (kt + 1 < nk) swrite(SPLIT ? 0 : (cur ^ 1));
         __syncthreads();
     }
 
@@ -325,7 +329,7 @@ template <int EPI, class Loader, bool SPLIT = false>
 int launch(const GemmArgs& g, const Loader& ld, hipStream_t s) {
     static bool attr_set = false;
     auto kfn = gemm_kernel<EPI, Loader, SPLIT>;
-    const int smem = SPLIT ? 2 * SMEM_BYTES : SMEM_BYTES;
+    const int smem = SMEM_BYTES;  // 64 KiB in both modes (SPLIT: 4 single-buffered images)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm)", __FILE__, __LINE__);

@@ -35,6 +35,7 @@ struct LayerT {
     float* gqk = nullptr;   // [4,64] (q_ln w, b, k_ln w, b)
 };
 struct Grad { float* p; int64_t n; };
+struct Bound { std::string key; float *p, *m, *v; int64_t n; bool decay; };
 }  // namespace
 
 struct showo_trainer {
@@ -44,6 +45,7 @@ struct showo_trainer {
     std::vector<LayerT> L;
     bf16_t* wlmT = nullptr;
     std::map<std::string, Grad> grads;
+    std::vector<Bound> bound;  // master weights + AdamW moments registered by the host (showo_train_bind_param)
     // head
     float *logits = nullptr, *gembed = nullptr, *gfln = nullptr, *gwlm = nullptr, *gblm = nullptr;
     bf16_t *dlogits = nullptr, *bigT = nullptr;  // bigT: [max(Vp, F), Tp] transposed image of the dY side
@@ -370,5 +372,37 @@ extern "C" int showo_train_grad_copy(showo_trainer* t, const char* key, float* d
     TRY(showo_train_grad(t, key, &p, &m));
     if (m != n) return set_error_msg(2, "train_grad_copy: element count mismatch");
     SHOWO_CHECK_HIP(hipMemcpyAsync(dst, p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// ---- optimizer: the host registers its fp32 master tensors and moment buffers once; one call then updates everything
+extern "C" int showo_train_bind_param(showo_trainer* t, const char* key, float* param, float* exp_avg, float* exp_avg_sq, int64_t n) {
+    if (!t || !key || !param || !exp_avg || !exp_avg_sq) return set_error_msg(1, "train_bind_param: null argument");
+    auto it = t->grads.find(key);
+    if (it == t->grads.end()) return set_error_msg(3, "train_bind_param: unknown state-dict key");
+    if (it->second.n != n) return set_error_msg(2, "train_bind_param: element count mismatch");
+    std::string k(key);
+    // reference rule (training/train.py:211): no weight decay for names containing one of these substrings
+    const char* nd[4] = {"bias", "layer_norm.weight", "mlm_ln.weight", "embeddings.weight"};
+    bool decay = true;
+    for (const char* x : nd) decay = decay && k.find(x) == std::string::npos;
+    for (auto& b : t->bound)
+        if (b.key == k) { b.p = param; b.m = exp_avg; b.v = exp_avg_sq; b.n = n; b.decay = decay; return 0; }
+    t->bound.push_back(Bound{k, param, exp_avg, exp_avg_sq, n, decay});
+    return 0;
+}
+
+// torch.optim.AdamW.step() over every bound parameter with the gradients of the last backward, followed by the refresh of
+// the engine's bf16 weight images (the transposed images are rebuilt lazily by the next forward)
+extern "C" int showo_train_adamw_step(showo_trainer* t, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                      void* stream) {
+    if (!t) return set_error_msg(1, "train_adamw_step: null handle");
+    if (t->bound.empty()) return set_error_msg(1, "train_adamw_step: no parameters bound");
+    for (auto& b : t->bound) {
+        const Grad& g = t->grads[b.key];
+        TRY(showo_adamw(b.p, g.p, b.m, b.v, b.n, lr, beta1, beta2, eps, b.decay ? weight_decay : 0.f, step, stream));
+        TRY(showo_engine_load(t->e, b.key.c_str(), b.p, b.n, stream));
+    }
+    t->weights_synced = false;
     return 0;
 }

@@ -57,12 +57,8 @@ class Trainer:
             ptr, n = C.c_void_p(), C.c_int64()
             _lib.check(lib.showo_train_bucket(self.tr, b, C.byref(ptr), C.byref(n)), "showo_train_bucket")
             self.buckets.append(device_view(ptr.value, n.value, dev))
-        self.grad_ptr = {}
-        for n, p in self.params:
-            ptr, cnt = C.c_void_p(), C.c_int64()
-            _lib.check(lib.showo_train_grad(self.tr, n.encode(), C.byref(ptr), C.byref(cnt)), "showo_train_grad")
-            assert cnt.value == p.numel(), n
-            self.grad_ptr[n] = ptr.value
+        for n, p in self.params:  # master weights + moments are registered once; the step is one C call
+            _lib.call("showo_train_bind_param", self.tr, n.encode(), p.data_ptr(), self.m[n].data_ptr(), self.v[n].data_ptr(), p.numel())
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) else None
 
@@ -74,7 +70,6 @@ class Trainer:
     def step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
         """one optimisation step; returns the three losses (fp32 device tensor [3])"""
         m, tr, s = self.model, self.tr, _lib.stream
-        tr = m.trainer()  # re-syncs the transposed weight images if the weights changed
         B, L = input_ids.shape
         ids = input_ids.to(torch.int64).contiguous()
         lab = labels.to(torch.int64).contiguous()
@@ -98,10 +93,5 @@ class Trainer:
                 w.wait()
                 _lib.call("showo_scale_f32", self.buckets[b].data_ptr(), self.buckets[b].numel(), inv, s())
         self.step_count += 1
-        for n, p in self.params:
-            wd = 0.0 if any(nd in n for nd in NO_DECAY) else self.wd
-            _lib.call("showo_adamw", p.data_ptr(), self.grad_ptr[n], self.m[n].data_ptr(), self.v[n].data_ptr(), p.numel(), self.lr,
-                      self.betas[0], self.betas[1], self.eps, wd, self.step_count, s())
-            _lib.call("showo_engine_load", m._engine, n.encode(), p.data_ptr(), p.numel(), s())  # refresh the bf16 image
-        m._weights_changed = True
+        _lib.call("showo_train_adamw_step", tr, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, s())
         return losses
