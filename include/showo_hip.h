@@ -153,7 +153,7 @@ int showo_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16_t* QT, con
  * ------------------------------------------------------------------------------------------- */
 /* X bf16 [T, C] (row stride ld) -> XT bf16 [C, Tp] (Tp % 64 == 0, columns >= T zero): the k-contiguous operand of the
  * weight-gradient GEMMs dW = dY^T X.  mode 1 writes gelu_new(X)^T (the MLP activation from the saved pre-activation).
- * colsum (optional, fp32 [C]): column sums of X = bias gradient (accumulate != 0 adds); colpart: scratch fp32 [Tp/64, C]. */
+ * colsum (optional, fp32 [C]): column sums of X = bias gradient (accumulate != 0 adds); colpart: scratch fp32 [Tp/64 + 8, C]. */
 int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int T, int C, int Tp, int mode, float* colpart, float* colsum,
                          int accumulate, void* stream);
 /* LayerNorm backward fused with the residual add of the parallel block (phi.py:774-790): dx = dy + dLN(x)^T dh.

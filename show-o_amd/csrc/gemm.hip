@@ -1309,6 +1309,235 @@ extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const fl
     return dispatch(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
 }
 
+// =====================================================================================================
+// Split-precision 3x3 convolution on the phase-split template (the VQGAN hot kernel: 84 % of MAGVITv2.get_code).
+//   out[M, Cout] = im2col(x)[M, 9 Cin] W[Cout, 9 Cin]^T with x = xh + xl, W = Wh + Wl (bf16 pairs): per fragment pair
+//   three MFMAs (Wh xh + Wh xl + Wl xh) into fp32 accumulators.
+// Tile 128 (cout) x 256 (pixels) x 32 (k), 8 waves = 2 groups x (2 along n x 2 along m), wave tile 64 x 64 (4 x 4 fragments).
+// LDS per k-tile: Wh, Wl [128][32] and Ah, Al [256][32] bf16 = 48 KiB, double-buffered (96 KiB).  Rows are 64 B; a DMA piece
+// (1 KiB wave-instruction) is 16 rows; chunk c of row r sits at c ^ ((-(r >> 2)) & 3): a 16x32 fragment read (ds_read_b128,
+// lane -> row lane & 15, chunk lane >> 4) touches 16 distinct 16-B slots per lane group.
+// The im2col gather (3x3 taps, nearest-2x upsample, pad-(0,1,0,1)+stride-2) is folded into the per-lane DMA source address;
+// out-of-image taps read a zero page.  A wave stages the SAME 16 rows of the hi and the lo image, so one address computation
+// feeds two DMAs.  Schedule = gemm2p (2 phases per k-tile, groups one barrier apart, counted vmcnt):
+//   ph0: read W (8 b128) + A frags m0,m1 (4); DMA W + A-lo rows of tile t+1 (4 pieces); vmcnt(4); 24 MFMAs
+//   ph1: read A frags m2,m3 (4);              DMA A-hi rows of tile t+1 (2 pieces);     vmcnt(2); 24 MFMAs
+// =====================================================================================================
+constexpr int CS_WROWS = 128, CS_AROWS = 256, CS_BK = 32;
+constexpr int CS_BUF = (2 * CS_WROWS + 2 * CS_AROWS) * CS_BK;  // elements per buffer (48 KiB)
+constexpr int CS_SMEM = 2 * CS_BUF * 2;                        // 96 KiB
+
+struct ConvRow {  // per-lane im2col state of one staged output pixel
+    const bf16_t* img;  // image base of the hi operand
+    int oy, ox;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = (g.M + CS_AROWS - 1) / CS_AROWS, tilesN = (g.N + CS_WROWS - 1) / CS_WROWS;
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = bid / tilesM, tm = bid - tn * tilesM;  // pixels fastest: neighbouring blocks share the weight panel
+    const int m0 = tm * CS_AROWS, n0 = tn * CS_WROWS;
+    const int nk = g.K / CS_BK;
+    const int grp = wave >> 2, wn = wave & 1, wmg = (wave >> 1) & 1;
+    const int arow0 = grp * 128 + wmg * 64;  // first tile row (pixel) of this wave
+
+    // ---- DMA roles.  Piece = 16 rows x 64 B; lane -> row lane >> 2, physical chunk lane & 3 = logical chunk ^ f(row >> 2)
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((0 - (prow >> 2)) & 3);
+    const int koff = lchunk * 8;  // k offset (elements) of this lane inside the 32-wide k-tile
+    // W rows: wave w stages rows 16 w .. 16 w + 15 of the weight tile (hi and lo image)
+    uint32_t woffb;
+    {
+        int n = n0 + wave * 16 + prow;
+        n = n < g.N ? n : g.N - 1;
+        woffb = (uint32_t)(((int64_t)n * g.ldw + koff) * 2);
+    }
+    const char* whb = reinterpret_cast<const char*>(g.W);
+    const char* wlb = reinterpret_cast<const char*>(g.Wlo);
+    // A rows: "lo" rows of a wave = its fragments m0,m1 (tile rows arow0 + 0..31), "hi" rows = m2,m3 (arow0 + 32..63).
+    // 8 lo pieces and 8 hi pieces per tile; wave w stages lo piece w and hi piece w: tile rows (w >> 1) * 64 + (w & 1) * 16 (+ 32)
+    ConvRow rlo, rhi;
+    const int64_t xlo_delta = c.Xlo - c.X;
+    const int hw = c.Hout * c.Wout;
+    {
+        const int base = (wave >> 1) * 64 + (wave & 1) * 16 + prow;
+        int m = m0 + base;
+        m = m < g.M ? m : g.M - 1;
+        int b = m / hw, p = m - b * hw;
+        rlo.oy = p / c.Wout; rlo.ox = p - rlo.oy * c.Wout;
+        rlo.img = c.X + (int64_t)b * c.Hin * c.Win * c.Cin;
+        m = m0 + base + 32;
+        m = m < g.M ? m : g.M - 1;
+        b = m / hw; p = m - b * hw;
+        rhi.oy = p / c.Wout; rhi.ox = p - rhi.oy * c.Wout;
+        rhi.img = c.X + (int64_t)b * c.Hin * c.Win * c.Cin;
+    }
+    auto src = [&](const ConvRow& r, int ky, int kx, int cb) -> const bf16_t* {
+        int iy, ix;
+        bool ok;
+        if (c.mode == 2) {
+            iy = 2 * r.oy + ky; ix = 2 * r.ox + kx;
+            ok = iy < c.Hin && ix < c.Win;
+        } else if (c.mode == 1) {
+            const int uy = r.oy + ky - 1, ux = r.ox + kx - 1;
+            ok = uy >= 0 && ux >= 0 && uy < c.Hout && ux < c.Wout;
+            iy = uy >> 1; ix = ux >> 1;
+        } else {
+            iy = r.oy + ky - 1; ix = r.ox + kx - 1;
+            ok = iy >= 0 && ix >= 0 && iy < c.Hin && ix < c.Win;
+        }
+        return ok ? r.img + ((int64_t)iy * c.Win + ix) * c.Cin + cb + koff : nullptr;
+    };
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    // LDS layout of a buffer (elements): Wh [128][32] | Wl [128][32] | Ah [256][32] | Al [256][32]
+    constexpr int O_WL = CS_WROWS * CS_BK, O_AH = 2 * CS_WROWS * CS_BK, O_AL = O_AH + CS_AROWS * CS_BK;
+    const int a_lo_row = (wave >> 1) * 64 + (wave & 1) * 16;
+#define CS_DMA_W(BUF, K0)                                                                                         \
+    do {                                                                                                          \
+        bf16_t* d_ = smem + (BUF) * CS_BUF + wave * 16 * CS_BK;                                                   \
+        glds16(reinterpret_cast<const bf16_t*>(whb + (size_t)(K0) * 2 + (size_t)woffb), d_);                      \
+        glds16(reinterpret_cast<const bf16_t*>(wlb + (size_t)(K0) * 2 + (size_t)woffb), d_ + O_WL);               \
+    } while (0)
+#define CS_DMA_A(BUF, ROW, R, KY, KX, CB)                                                                         \
+    do {                                                                                                          \
+        const bf16_t* p_ = src(R, KY, KX, CB);                                                                    \
+        bf16_t* d_ = smem + (BUF) * CS_BUF + O_AH + (ROW) * CS_BK;                                                \
+        glds16(p_ ? p_ : zero, d_);                                                                               \
+        glds16(p_ ? p_ + xlo_delta : zero, d_ + (O_AL - O_AH));                                                   \
+    } while (0)
+
+    // ---- fragment read offsets (elements): lane -> row lane & 15, logical chunk lane >> 4
+    const int fr = lane & 15, fg = lane >> 4;
+    const int lsw = fr * CS_BK + ((fg ^ ((0 - (fr >> 2)) & 3)) << 3);
+    const bf16_t* ldsW = smem + (wn * 64) * CS_BK + lsw;
+    const bf16_t* ldsA = smem + O_AH + arow0 * CS_BK + lsw;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 wh[4], wl[4], ah[2], al[2];
+
+#define CS_READ_W(BUF)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        wh[i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * CS_BUF + i * 16 * CS_BK);                         \
+        wl[i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * CS_BUF + O_WL + i * 16 * CS_BK);                  \
+    }
+#define CS_READ_A(BUF, MB)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
+        ah[j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * CS_BUF + ((MB) + j) * 16 * CS_BK);                \
+        al[j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * CS_BUF + (O_AL - O_AH) + ((MB) + j) * 16 * CS_BK); \
+    }
+#define CS_MFMA(MB)                                                                                               \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ah[j], acc[i][(MB) + j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], al[j], acc[i][(MB) + j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+                acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][(MB) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+    // tap / channel base of k-tile T (Cin % 32 == 0: a k-tile never straddles two taps)
+#define CS_TAP(T)                                                                                                 \
+    const int k0_ = (T) * CS_BK;                                                                                  \
+    const int tap_ = k0_ / c.Cin;                                                                                 \
+    const int cb_ = k0_ - tap_ * c.Cin;                                                                           \
+    const int ky_ = tap_ / 3, kx_ = tap_ - 3 * (tap_ / 3);
+#define CS_TILE(BUF, T)                                                                                           \
+    do {                                                                                                          \
+        const bool has1 = (T) + 1 < nk;                                                                           \
+        CS_TAP((T) + 1)                                                                                           \
+        CS_READ_W(BUF)                                                                                            \
+        CS_READ_A(BUF, 0)                                                                                         \
+        if (has1) {                                                                                               \
+            CS_DMA_W((BUF) ^ 1, k0_);                                                                             \
+            CS_DMA_A((BUF) ^ 1, a_lo_row, rlo, ky_, kx_, cb_);                                                    \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                      \
+        } else {                                                                                                  \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        }                                                                                                         \
+        bar_raw_fn();                                                                                             \
+        CS_MFMA(0);                                                                                               \
+        bar_raw_fn();                                                                                             \
+        CS_READ_A(BUF, 2)                                                                                         \
+        if (has1) {                                                                                               \
+            CS_DMA_A((BUF) ^ 1, a_lo_row + 32, rhi, ky_, kx_, cb_);                                               \
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                      \
+        } else {                                                                                                  \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        }                                                                                                         \
+        bar_raw_fn();                                                                                             \
+        CS_MFMA(2);                                                                                               \
+        bar_raw_fn();                                                                                             \
+    } while (0)
+
+    {   // prologue: all of tile 0
+        CS_TAP(0)
+        CS_DMA_W(0, k0_);
+        CS_DMA_A(0, a_lo_row, rlo, ky_, kx_, cb_);
+        CS_DMA_A(0, a_lo_row + 32, rhi, ky_, kx_, cb_);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar_raw_fn();
+    if (grp == 1) bar_raw_fn();
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        CS_TILE(0, t);
+        CS_TILE(1, t + 1);
+    }
+    if (t < nk) CS_TILE(0, t);
+    if (grp == 0) bar_raw_fn();
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fg * 4;
+        float bn[4];
+        load_bias4(g, n, bn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn);
+    }
+#undef CS_TILE
+#undef CS_TAP
+#undef CS_MFMA
+#undef CS_READ_A
+#undef CS_READ_W
+#undef CS_DMA_A
+#undef CS_DMA_W
+}
+
+template <int EPI>
+int launch_conv2p_split(const GemmArgs& g, const ConvArgs& c, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = conv2p_split_kernel<EPI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, CS_SMEM);
+        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(conv2p_split)", __FILE__, __LINE__);
+        attr_set = true;
+    }
+    const int tilesM = (g.M + CS_AROWS - 1) / CS_AROWS, tilesN = (g.N + CS_WROWS - 1) / CS_WROWS;
+    kfn<<<dim3(tilesM * tilesN), dim3(512), CS_SMEM, s>>>(g, c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "conv2p_split launch", __FILE__, __LINE__);
+    return 0;
+}
+
+int g_conv_split_impl = -1;  // SHOWO_CONV_SPLIT_IMPL: 1 = 128^2 register-staged kernel, 2 = phase-split kernel (default for M >= 2048)
+
 // ---- split-precision entry points (operands as hi/lo bf16 pairs, fp32 output) -----------------------------
 extern "C" int showo_gemm_bf16x3(const uint16_t* A, const uint16_t* Alo, int lda, const uint16_t* W, const uint16_t* Wlo, int ldw,
                                  const float* bias, int bias_per_row, float* out, int ldo, const float* resid, int ldr, int M,
@@ -1349,5 +1578,11 @@ extern "C" int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, cons
     ConvLoader ld;
     ld.c = c; ld.M = g.M;
     ProfScope prof(PROF_CONV, 2.0 * g.M * Cout * 9.0 * Cin, (hipStream_t)stream);
+    if (g_conv_split_impl < 0) { const char* e = getenv("SHOWO_CONV_SPLIT_IMPL"); g_conv_split_impl = e ? atoi(e) : 0; }
+    const bool phase_split = g_conv_split_impl == 2 || (g_conv_split_impl != 1 && g.M >= 2048);
+    if (phase_split && (int64_t)Cout * g.ldw * 2 < ((int64_t)1 << 32)) {
+        if (resid) return launch_conv2p_split<SHOWO_EPI_RESID_F32>(g, c, (hipStream_t)stream);
+        return launch_conv2p_split<SHOWO_EPI_F32>(g, c, (hipStream_t)stream);
+    }
     return dispatch_split(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
 }

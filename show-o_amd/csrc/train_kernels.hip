@@ -74,27 +74,32 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         if (tid < 64 && c0 + tid < C) colpart[(int64_t)blockIdx.y * C + c0 + tid] = (cs[0][tid] + cs[1][tid]) + (cs[2][tid] + cs[3][tid]);
     }
 }
-// out[c] (+)= sum over blocks of part[blk][c].  Fixed order: 8 interleaved subsets (block k belongs to subset k % 8, summed in
-// block order), combined as ((0+1)+(2+3))+((4+5)+(6+7)) -- bit-reproducible.  A block covers 64 columns: wave w sums
-// subsets w and w + 4 with lane = column (coalesced rows).
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C,
-                                                              int accumulate) {
-    __shared__ float sub[8][64];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// out[c] (+)= sum over blocks of part[blk][c], bit-reproducible: block k belongs to subset k % 8; inside a subset wave w of
+// the reducing block sums its blocks k = j + 8 (w + 4 i) in order and the four waves combine as (0+1)+(2+3); the 8 subset
+// sums are written to scratch[8][C] (the tail of the partial buffer) and combined as ((0+1)+(2+3))+((4+5)+(6+7)).
+__global__ __launch_bounds__(256) void colsum_subset_kernel(const float* __restrict__ part, float* __restrict__ sub8, int nblk, int C) {
+    __shared__ float red[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.y;
     const int c = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-        for (int k = w; k < nblk; k += 8) s0 += part[(int64_t)k * C + c];
-        for (int k = w + 4; k < nblk; k += 8) s1 += part[(int64_t)k * C + c];
-    }
-    sub[w][lane] = s0;
-    sub[w + 4][lane] = s1;
+    float s = 0.f;
+    if (c < C)
+        for (int k = j + 8 * w; k < nblk; k += 32) s += part[(int64_t)k * C + c];
+    red[w][lane] = s;
     __syncthreads();
-    if (w == 0 && c < C) {
-        const float s = ((sub[0][lane] + sub[1][lane]) + (sub[2][lane] + sub[3][lane])) +
-                        ((sub[4][lane] + sub[5][lane]) + (sub[6][lane] + sub[7][lane]));
-        out[c] = accumulate ? out[c] + s : s;
-    }
+    if (w == 0 && c < C) sub8[(int64_t)j * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ void colsum_combine_kernel(const float* __restrict__ sub8, float* __restrict__ out, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = ((sub8[c] + sub8[(int64_t)C + c]) + (sub8[2 * (int64_t)C + c] + sub8[3 * (int64_t)C + c])) +
+                    ((sub8[4 * (int64_t)C + c] + sub8[5 * (int64_t)C + c]) + (sub8[6 * (int64_t)C + c] + sub8[7 * (int64_t)C + c]));
+    out[c] = accumulate ? out[c] + s : s;
+}
+// part: [nblk][C] partials followed by 8*C floats of scratch
+static inline void colsum_reduce(const float* part, float* out, int nblk, int C, int accumulate, hipStream_t s) {
+    float* sub8 = const_cast<float*>(part) + (int64_t)nblk * C;
+    colsum_subset_kernel<<<dim3((C + 63) / 64, 8), dim3(256), 0, s>>>(part, sub8, nblk, C);
+    colsum_combine_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sub8, out, C, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -475,7 +480,7 @@ extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int
     if (colsum && !colpart) return set_error_msg(1, "transpose: column sums need the partial buffer [Tp/64, C]");
     hipStream_t s = (hipStream_t)stream;
     transpose_kernel<<<dim3((C + 63) / 64, Tp / 64), dim3(256), 0, s>>>(x, xt, colsum ? colpart : nullptr, T, C, ld, Tp, mode);
-    if (colsum) colsum_finalize_kernel<<<dim3((C + 63) / 64), dim3(256), 0, s>>>(colpart, colsum, Tp / 64, C, accumulate);
+    if (colsum) colsum_reduce(colpart, colsum, Tp / 64, C, accumulate, s);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -485,7 +490,7 @@ extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh,
     if (T <= 0) return 0;
     if ((H % 4) || H > 2048) return set_error_msg(1, "ln_bwd: H must be a multiple of 4 and <= 2048");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (T + LNB_ROWS - 1) / LNB_ROWS;
+    const int nblk = (T + LNB_ROWS - 1) / LNB_ROWS;  // the partial buffer holds nblk + 8 rows (showo_ln_bwd_blocks)
     static bool attr_set = false;
     if (!attr_set) {
         SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -493,11 +498,11 @@ extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh,
     }
     ln_bwd_kernel<<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, T, H, eps);
     // part is [nblk][2][H]: reduce it as a [nblk, 2H] matrix -> dgb = (dgamma[H], dbeta[H])
-    colsum_finalize_kernel<<<dim3((2 * H + 63) / 64), dim3(256), 0, s>>>(part, dgb, nblk, 2 * H, 0);
+    colsum_reduce(part, dgb, nblk, 2 * H, 0, s);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int showo_ln_bwd_blocks(int T) { return (T + LNB_ROWS - 1) / LNB_ROWS; }
+extern "C" int showo_ln_bwd_blocks(int T) { return (T + LNB_ROWS - 1) / LNB_ROWS + 8; }  // + 8 rows of reduction scratch
 
 extern "C" int showo_qkln_rope_bwd(const uint16_t* dq, const uint16_t* dk, int ldg, const uint16_t* qkv, const float* qw,
                                    const float* kw, const float* cos_tab, const float* sin_tab, uint16_t* dqkv, float* part,
@@ -508,11 +513,11 @@ extern "C" int showo_qkln_rope_bwd(const uint16_t* dq, const uint16_t* dk, int l
     const int64_t rows = (int64_t)T * nH;
     const int nblk = (int)((rows + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS));
     qkln_rope_bwd_kernel<<<dim3(nblk), dim3(256), 0, s>>>(dq, dk, ldg, qkv, qw, kw, cos_tab, sin_tab, dqkv, part, T, L, nH, eps);
-    colsum_finalize_kernel<<<dim3(4), dim3(256), 0, s>>>(part, dparams, nblk, 256, 0);  // (dqw, dqb, dkw, dkb) x 64
+    colsum_reduce(part, dparams, nblk, 256, 0, s);  // (dqw, dqb, dkw, dkb) x 64
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
-extern "C" int showo_qkln_rope_bwd_blocks(int T, int nH) { return (int)(((int64_t)T * nH + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS)); }
+extern "C" int showo_qkln_rope_bwd_blocks(int T, int nH) { return (int)(((int64_t)T * nH + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS)) + 8; }
 
 extern "C" int showo_ce_loss(const float* logits, int ldl, const int64_t* labels, int B, int L, int V, int b_t2i, int b_lm,
                              int b_mmu, int max_seq_len, float g_t2i, float g_lm, float g_mmu, void* rows_ws, int* counts,

@@ -558,23 +558,27 @@ def test_split_gemm_and_conv_track_fp32():
         ref = A.double() @ W.double().T + bias.double() + resid.double()
         err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
         assert err < 3e-5, (M, N, K, err)
-    B, H, Wd, Cin, Cout = 2, 9, 7, 128, 128
-    x = torch.randn(B, Cin, H, Wd)
-    wgt = torch.randn(Cout, Cin, 3, 3) * 0.03
-    bias = torch.randn(Cout)
-    xh, xl = _split(x.permute(0, 2, 3, 1).contiguous())
-    wh, wl = _split(wgt.permute(0, 2, 3, 1).contiguous())
-    for mode, (Ho, Wo) in ((0, (H, Wd)), (1, (2 * H, 2 * Wd)), (2, (H // 2, Wd // 2))):
-        out = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
-        L().call("showo_conv3x3_bf16x3", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), None, L().ptr(out), B, H, Wd,
-                 Cin, Cout, mode, S())
-        xd, wd_, bd = x.double(), wgt.double(), bias.double()
-        if mode == 0:
-            ref = F.conv2d(xd, wd_, bd, padding=1)
-        elif mode == 1:
-            ref = F.conv2d(xd.repeat_interleave(2, 2).repeat_interleave(2, 3), wd_, bd, padding=1)
-        else:
-            ref = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wd_, bd, stride=2)
-        ref = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)
-        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
-        assert err < 3e-5, (mode, err)
+    # small M -> 128^2 register-staged kernel; M >= 2048 -> phase-split DMA kernel (ragged pixel / channel edges, thin Cout)
+    for (B, H, Wd, Cin, Cout) in [(2, 9, 7, 128, 128), (2, 50, 46, 128, 192), (1, 64, 40, 64, 3), (3, 31, 33, 256, 128)]:
+        x = torch.randn(B, Cin, H, Wd)
+        wgt = torch.randn(Cout, Cin, 3, 3) * 0.03
+        bias = torch.randn(Cout)
+        xh, xl = _split(x.permute(0, 2, 3, 1).contiguous())
+        wh, wl = _split(wgt.permute(0, 2, 3, 1).contiguous())
+        for mode, (Ho, Wo) in ((0, (H, Wd)), (1, (2 * H, 2 * Wd)), (2, (H // 2, Wd // 2))):
+            out = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
+            res = torch.randn(B, Ho * Wo, Cout) if mode == 0 else None
+            L().call("showo_conv3x3_bf16x3", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)),
+                     None if res is None else L().ptr(dev(res)), L().ptr(out), B, H, Wd, Cin, Cout, mode, S())
+            xd, wd_, bd = x.double(), wgt.double(), bias.double()
+            if mode == 0:
+                ref = F.conv2d(xd, wd_, bd, padding=1)
+            elif mode == 1:
+                ref = F.conv2d(xd.repeat_interleave(2, 2).repeat_interleave(2, 3), wd_, bd, padding=1)
+            else:
+                ref = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wd_, bd, stride=2)
+            ref = ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)
+            if res is not None:
+                ref = ref + res.double()
+            err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+            assert err < 3e-5, (B, H, Wd, Cin, Cout, mode, err)

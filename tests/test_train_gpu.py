@@ -104,7 +104,7 @@ def test_transpose_colsum_and_gelu_mode():
     T, C, Tp = 150, 200, 192
     x = bf16_round(torch.randn(T, C))
     xt = torch.full((C, Tp), 7, dtype=torch.int16, device="cuda")
-    part = torch.zeros((Tp // 64, C), dtype=torch.float32, device="cuda")
+    part = torch.zeros((Tp // 64 + 8, C), dtype=torch.float32, device="cuda")
     cs = torch.zeros(C, dtype=torch.float32, device="cuda")
     L().call("showo_transpose_bf16", L().ptr(_bits(x)), C, L().ptr(xt), T, C, Tp, 0, L().ptr(part), L().ptr(cs), 0, S())
     got = from_bf16_bits(xt).cpu()
