@@ -209,7 +209,7 @@ def main():
                                    "18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M",
                        "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
                        "algorithmic_tflop_per_image": 38.4, "end_to_end_algorithmic_tflops": value * 38.4},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA GEMM: qkv/dense/fc1/fc2/lm_head)",
+            "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM, all epilogues: fused-QKV / dense / fc1+GELU / fc2 / lm_head rows)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "launches": int(n_gemm.value), "avg_launch_ms": ms_gemm.value / max(1, n_gemm.value),
                          "time_share_of_step": ms_gemm.value * 1e-3 / dt,
