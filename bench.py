@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (A/B of their overhead)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the denoise step as a hipGraph (no per-launch events: roofline leg reports null)")
     ap.add_argument("--workload", default="t2i", help="t2i (default, the headline metric) | train (bench_train.py: stage-1 step time)")
     a = ap.parse_args()
     import faulthandler
@@ -158,7 +160,7 @@ def main():
     def step():
         ids = ic_d.clone()
         toks = model.t2i_generate(input_ids=ids, uncond_input_ids=iu_d, attention_mask=mask_d, temperature=1.0, timesteps=18,
-                                  guidance_scale=5.0, generator=gen, config=cfg)
+                                  guidance_scale=5.0, generator=gen, config=cfg, use_graph=a.graph)
         toks = torch.clamp(toks, max=d.codebook - 1, min=0)
         return vq.decode_code(toks)
 
@@ -179,7 +181,7 @@ def main():
             torch.cuda.synchronize()
 
     L.call("showo_prof_reset")
-    L.call("showo_prof_enable", 1)
+    L.call("showo_prof_enable", 0 if (a.graph or a.no_events) else 1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):

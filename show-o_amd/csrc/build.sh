@@ -14,7 +14,7 @@ for f in basic gemm attention attention_bwd train_kernels sampler vq_kernels eng
 done
 if [ ! -f _build/errors.o ] || [ errors.cpp -nt _build/errors.o ]; then
   mkdir -p _build
-  hipcc -O2 -std=c++17 -fPIC -c errors.cpp -o _build/errors.o &
+  hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -c errors.cpp -o _build/errors.o &
 fi
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS _build/errors.o -o $OUT

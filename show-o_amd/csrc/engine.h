@@ -14,6 +14,12 @@ struct Layer {
 };
 }  // namespace showo
 
+namespace showo {
+void sampler_set_device_step(const int* step_dev, const float* sched, int steps);
+int sampler_step_inc(int* step_dev, hipStream_t s);
+extern bool g_prof_on_query();
+}  // namespace showo
+
 using showo::bf16_t;
 using showo::set_error_hip;
 using showo::set_error_msg;
@@ -44,6 +50,10 @@ struct showo_engine {
     int last_iv[4] = {0, 0, 0, 0};
     int32_t* iv1 = nullptr;
     int64_t* tok1 = nullptr;
+    // hipGraph replay of the denoise step
+    int* step_dev = nullptr;
+    float* sched_dev = nullptr;
+    int sched_cap = 0;
 
     template <class T>
     int alloc(T** p, int64_t n) {

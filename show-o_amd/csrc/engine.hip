@@ -15,6 +15,7 @@
 //   K-contiguous, exactly what the MFMA GEMM's operand loader wants); biases / LayerNorm params fp32.
 #include "engine.h"
 #include <cstdio>
+#include <vector>
 #include <cstring>
 #include <set>
 #include <string>
@@ -273,18 +274,63 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
         TRY(showo_mask_compress(mask, e->iv, e->flag, nseq, L, L, s));  // the mask is step-invariant: compress once
         iv = e->iv; flag = e->flag;
     }
-    (void)use_graph;  // graph capture of the step lands with the device-side step constants
-    for (int step = 0; step < steps; ++step) {
+    // one denoise step (modeling_showo.py:135-179).  dev_step: the step index / schedule constants are read on the device
+    auto denoise_step = [&](int step) -> int {
         TRY(showo_embed_f32(e->ids_all, e->embed, e->x, nseq * L, e->H, e->V, s));
         TRY(run_layers(e, nseq, L, 0, false, iv, flag, mask, s));
         TRY(head_rows(e, e->rows, nrows, id_offset, codebook, e->row_logits, s));
         const float* lu = cfg ? e->row_logits + (int64_t)B * N * codebook : nullptr;
+        const bool dev = step < 0;  // device-step mode: noise offsets are applied inside the kernels
         TRY(showo_cfg_softmax_sample(e->row_logits, lu, codebook, guidance, e->cur, mask_id,
-                                     exp_noise ? exp_noise + (int64_t)step * B * N * codebook : nullptr, seed, (uint32_t)step,
-                                     e->sampled, e->sel, B, N, codebook, s));
+                                     exp_noise ? exp_noise + (dev ? 0 : (int64_t)step * B * N * codebook) : nullptr, seed,
+                                     (uint32_t)(dev ? 0 : step), e->sampled, e->sel, B, N, codebook, s));
         TRY(showo_mask_by_topk(e->sel, e->sampled, e->cur, e->ids_all, cfg ? e->ids_all + (int64_t)B * L : nullptr, L, img_start,
-                               mask_id, id_offset, mask_len_host[step], temps_host[step],
-                               uniform ? uniform + (int64_t)step * B * N : nullptr, seed, (uint32_t)step, nullptr, B, N, s));
+                               mask_id, id_offset, dev ? 0.f : mask_len_host[step], dev ? 0.f : temps_host[step],
+                               uniform ? uniform + (dev ? 0 : (int64_t)step * B * N) : nullptr, seed, (uint32_t)(dev ? 0 : step), nullptr,
+                               B, N, s));
+        return 0;
+    };
+    // hipGraph path: step 0 runs eagerly (first-use kernel attributes are set outside a capture), then ONE step is captured
+    // with the step index in device memory and replayed for the remaining steps.  Not combined with per-launch event timing.
+    const bool graph = use_graph && steps > 1 && !showo::g_prof_on_query();
+    if (!graph) {
+        for (int step = 0; step < steps; ++step) TRY(denoise_step(step));
+    } else {
+        if (!e->step_dev) TRY(e->alloc(&e->step_dev, 4));
+        if (e->sched_cap < 2 * steps) { TRY(e->alloc(&e->sched_dev, 2 * steps)); e->sched_cap = 2 * steps; }
+        std::vector<float> sched(2 * steps);
+        for (int i = 0; i < steps; ++i) { sched[i] = mask_len_host[i]; sched[steps + i] = temps_host[i]; }
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->sched_dev, sched.data(), sizeof(float) * 2 * steps, hipMemcpyHostToDevice, s));
+        SHOWO_CHECK_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
+        SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // `sched` is a host temporary
+        showo::sampler_set_device_step(e->step_dev, e->sched_dev, steps);
+        int rc = denoise_step(-1);
+        if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        if (!rc) {
+            hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (he == hipSuccess) {
+                rc = denoise_step(-1);
+                if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
+                hipError_t he2 = hipStreamEndCapture(s, &g);
+                if (!rc && he2 != hipSuccess) rc = set_error_hip(he2, "hipStreamEndCapture", __FILE__, __LINE__);
+            } else {
+                rc = set_error_hip(he, "hipStreamBeginCapture", __FILE__, __LINE__);
+            }
+        }
+        if (!rc) {
+            hipError_t he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            if (he != hipSuccess) rc = set_error_hip(he, "hipGraphInstantiate", __FILE__, __LINE__);
+        }
+        for (int step = 1; !rc && step < steps; ++step) {
+            hipError_t he = hipGraphLaunch(ge, s);
+            if (he != hipSuccess) rc = set_error_hip(he, "hipGraphLaunch", __FILE__, __LINE__);
+        }
+        showo::sampler_set_device_step(nullptr, nullptr, 0);
+        if (ge) { hipStreamSynchronize(s); hipGraphExecDestroy(ge); }
+        if (g) hipGraphDestroy(g);
+        if (rc) return rc;
     }
     copy_i64_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(e->ids_all, ids_cond, B * L);  // in-place update like the reference
     copy_i64_kernel<<<dim3((B * N + thr - 1) / thr), dim3(thr), 0, s>>>(e->sampled, sampled_out, B * N);

@@ -50,6 +50,7 @@ ProfScope::ProfScope(int kind, double work, hipStream_t stream) : idx(-1), s(str
     g_prof.push_back(r);
     idx = (int)g_prof.size() - 1;
 }
+bool g_prof_on_query() { return g_prof_on; }
 ProfScope::~ProfScope() {
     if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, s);
 }

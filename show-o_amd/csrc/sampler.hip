@@ -24,6 +24,9 @@ struct SampleArgs {
     int64_t* sampled;
     float* sel;
     int N, V;
+    // graph replay: the step index lives in device memory (the captured launch is identical for every step)
+    const int* step_dev;
+    int64_t noise_stride;  // elements of injected noise per step
 };
 
 // one block per image token row; z staged in LDS (V*4 bytes, 32 KB at V=8192)
@@ -32,6 +35,10 @@ __global__ __launch_bounds__(256) void cfg_softmax_sample_kernel(SampleArgs a) {
     __shared__ float red_f[4];
     __shared__ int red_i[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.step_dev) {
+        a.step = (uint32_t)*a.step_dev;
+        if (a.exp_noise) a.exp_noise += (int64_t)a.step * a.noise_stride;
+    }
     const int64_t c = a.cur[row];
     if (c != a.mask_id) {  // known token: keeps its id, confidence = finfo.max (modeling_showo.py:154,164)
         if (tid == 0) { a.sampled[row] = c; a.sel[row] = FLT_MAX; }
@@ -113,6 +120,10 @@ struct TopkArgs {
     uint32_t step;
     uint8_t* masking_out;
     int N;
+    const int* step_dev;   // graph replay: step index, schedule constants sched[0..steps) = mask_len, [steps..2 steps) = temperature
+    const float* sched;
+    int steps;
+    int64_t noise_stride;
 };
 
 // one block per sample; confidences in LDS; k-th smallest by rank counting (N <= 4096)
@@ -121,6 +132,12 @@ __global__ __launch_bounds__(256) void mask_by_topk_kernel(TopkArgs a) {
     __shared__ int cnt_unknown;
     __shared__ float cut_s;
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.step_dev) {
+        a.step = (uint32_t)*a.step_dev;
+        a.mask_len_f = a.sched[a.step];
+        a.temp = a.sched[a.steps + a.step];
+        if (a.uniform) a.uniform += (int64_t)a.step * a.noise_stride;
+    }
     if (tid == 0) { cnt_unknown = 0; cut_s = INFINITY; }
     __syncthreads();
     Philox ph(a.seed);
@@ -170,7 +187,26 @@ __global__ __launch_bounds__(256) void mask_by_topk_kernel(TopkArgs a) {
     }
 }
 
+__global__ void step_inc_kernel(int* step) {
+    if (threadIdx.x == 0) *step += 1;
+}
+
 }  // namespace
+
+// Device-side step mode (engine-internal, used while a denoise step is captured into a hipGraph): when set, both sampler
+// kernels take the step index from *step_dev, the schedule constants from sched and offset injected noise themselves.
+static const int* g_sampler_step_dev = nullptr;
+static const float* g_sampler_sched = nullptr;
+static int g_sampler_steps = 0;
+namespace showo {
+void sampler_set_device_step(const int* step_dev, const float* sched, int steps) {
+    g_sampler_step_dev = step_dev; g_sampler_sched = sched; g_sampler_steps = steps;
+}
+int sampler_step_inc(int* step_dev, hipStream_t s) {
+    step_inc_kernel<<<1, 64, 0, s>>>(step_dev);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}  // namespace showo
 
 extern "C" int showo_cfg_softmax_sample(const float* logits_c, const float* logits_u, int ld, float guidance,
                                         const int64_t* cur, int64_t mask_id, const float* exp_noise, uint64_t seed,
@@ -183,6 +219,7 @@ extern "C" int showo_cfg_softmax_sample(const float* logits_c, const float* logi
     a.lc = logits_c; a.lu = logits_u; a.ld = ld;
     a.a1 = (float)(1.0 + (double)guidance); a.a2 = guidance;
     a.cur = cur; a.mask_id = mask_id; a.exp_noise = exp_noise; a.seed = seed; a.step = step;
+    a.step_dev = g_sampler_step_dev; a.noise_stride = (int64_t)rows * V;
     a.sampled = sampled; a.sel = sel_prob; a.N = N; a.V = V;
     size_t smem = (size_t)V * sizeof(float);
     static bool attr_set = false;
@@ -206,6 +243,7 @@ extern "C" int showo_mask_by_topk(const float* sel_prob, const int64_t* sampled,
     a.sel = sel_prob; a.sampled = sampled; a.cur = cur; a.ids_c = ids_cond; a.ids_u = ids_uncond;
     a.ld_ids = ld_ids; a.img_start = img_start; a.mask_id = mask_id; a.id_offset = id_offset;
     a.mask_len_f = mask_len_f; a.temp = temperature; a.uniform = uniform; a.seed = seed; a.step = step;
+    a.step_dev = g_sampler_step_dev; a.sched = g_sampler_sched; a.steps = g_sampler_steps; a.noise_stride = (int64_t)B * N;
     a.masking_out = masking_out; a.N = N;
     mask_by_topk_kernel<<<dim3(B), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());

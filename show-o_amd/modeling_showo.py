@@ -342,10 +342,25 @@ class Showo(nn.Module):
         else:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         out = torch.empty((B, N), dtype=torch.int64, device=input_ids.device)
-        _lib.call("showo_engine_t2i_generate", eng, _lib.ptr(input_ids), _lib.ptr(unc), _lib.ptr(mask), B, L, N, text_len,
-                  self.config.mask_token_id, offset, codebook, float(guidance_scale), timesteps,
-                  C.cast(ml_a, C.c_void_p), C.cast(tp_a, C.c_void_p), seed, _lib.ptr(_exp_noise), _lib.ptr(_uniform),
-                  int(kwargs.get("use_graph", 0)), _lib.ptr(out), _lib.stream())
+        use_graph = int(kwargs.get("use_graph", 0))
+
+        def run():
+            _lib.call("showo_engine_t2i_generate", eng, _lib.ptr(input_ids), _lib.ptr(unc), _lib.ptr(mask), B, L, N, text_len,
+                      self.config.mask_token_id, offset, codebook, float(guidance_scale), timesteps,
+                      C.cast(ml_a, C.c_void_p), C.cast(tp_a, C.c_void_p), seed, _lib.ptr(_exp_noise), _lib.ptr(_uniform),
+                      use_graph, _lib.ptr(out), _lib.stream())
+
+        if use_graph:
+            # hipGraph replay of the denoise step: stream capture needs a non-default stream
+            if getattr(self, "_graph_stream", None) is None:
+                self._graph_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._graph_stream.wait_stream(cur)
+            with torch.cuda.stream(self._graph_stream):
+                run()
+            cur.wait_stream(self._graph_stream)
+        else:
+            run()
         return out
 
     # ---- Showo.mmu_generate (reference models/modeling_showo.py:183-240) -----------------------------------

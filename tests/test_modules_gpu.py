@@ -83,6 +83,21 @@ def test_tiny_t2i_generate_noise_injected():
     assert agree >= 0.9
     if agree == 1.0:
         assert torch.equal(ids.cpu(), torch.from_numpy(g["final_input_ids"]))
+    # hipGraph replay of the denoise step (step index + schedule constants in device memory): identical trajectory
+    ids_g = dev(g["ids_cond"]).clone()
+    out_g = m.t2i_generate(input_ids=ids_g, uncond_input_ids=dev(g["ids_uncond"]), attention_mask=dev(g["mask"]), temperature=1.0,
+                           timesteps=steps, guidance_scale=float(g["guidance"]), config=util.gen_config(d), _exp_noise=en, _uniform=un,
+                           use_graph=1)
+    assert torch.equal(out_g, out) and torch.equal(ids_g, ids)
+    # ... and with the on-device Philox noise: same seed -> same tokens, eager vs graph
+    outs = []
+    for ug in (0, 1):
+        ids_p = dev(g["ids_cond"]).clone()
+        gen = torch.Generator(device="cuda").manual_seed(123)
+        outs.append(m.t2i_generate(input_ids=ids_p, uncond_input_ids=dev(g["ids_uncond"]), attention_mask=dev(g["mask"]),
+                                   timesteps=steps, guidance_scale=float(g["guidance"]), config=util.gen_config(d), generator=gen,
+                                   use_graph=ug))
+    assert torch.equal(outs[0], outs[1])
     # teacher-forced logits: per step, feed the reference's ids and compare the sliced logits
     Lseq = ids.shape[1]
     off = d.image_offset
