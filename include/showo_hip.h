@@ -31,6 +31,10 @@ int showo_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_n
 int showo_prof_enable(int on);
 int showo_prof_reset(void);
 int showo_prof_read(int kind, double* total_ms, int64_t* launches, double* work);
+/* time only every stride-th launch of a kind (systematic sample: keeps the instrumentation overhead of a timed region small) */
+int showo_prof_set_stride(int stride);
+/* launches seen and work submitted per kind since the last reset, timed or not */
+int showo_prof_totals(int kind, int64_t* launches, double* work);
 
 /* ---------------------------------------------------------------------------------------------
  * MAGVIT-v2 lookup-free quantizer (reference models/modeling_magvitv2.py:201-206, 208-221, 239-241)
@@ -111,6 +115,15 @@ int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ld
  * flag int32[1] is set to 1 if some row is not representable (more than two runs, or a value that is
  * neither 0 nor <= -1e9); the attention kernel then adds the dense mask instead. */
 int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag, int B, int Lq, int Lk, void* stream);
+
+/* On-device mask construction from token ids (reference training/prompting_utils.py:466-511, 591-624).
+ * Each call writes the per-row visibility intervals iv int32 [B,L,4] the attention kernels consume and/or the dense
+ * additive mask fp32 [B,1,L,L] with the reference's values (0 / float(iinfo(int64).min)); either pointer may be NULL
+ * (mmu forms always need iv).  predict_next: flag int32[1] is set if a row needs more than two runs (non-contiguous pads). */
+int showo_mask_predict_next(const int64_t* ids, int B, int L, int64_t pad_id, int64_t soi_id, int64_t eoi_id, int rm_pad_in_image,
+                            int32_t* iv, int32_t* flag, float* dense, void* stream);
+int showo_mask_mmu(const int64_t* ids, int B, int L, int64_t eoi_id, int32_t* iv, float* dense, void* stream);
+int showo_mask_mmu_vit(int B, int L, int system_prompt_len, int num_image_tokens, int32_t* iv, float* dense, void* stream);
 
 /* Fused omni-attention forward (replaces SDPA + dense additive mask, phi.py:715-722):
  * O[b, l, h*64 + d] bf16 = softmax(Q K^T + M) V.  Q,K,Vt as produced by showo_qk_prep (Q already scaled).
@@ -260,6 +273,9 @@ int showo_engine_missing(const showo_engine* e);
 /* Showo.forward without labels (modeling_showo.py:76-79 -> phi.py:953-1183):
  * ids int64 [B,L] or embeds fp32 [B,L,H] (exactly one non-NULL); mask fp32 [B,1,L,L] or NULL (causal);
  * logits fp32 [B,L,vocab]. */
+/* attend with caller-built visibility intervals (showo_mask_predict_next etc.) in the following calls that pass
+ * mask == NULL; iv == NULL restores the default (no mask = causal).  flag may be NULL (= known representable). */
+int showo_engine_use_intervals(showo_engine* e, const int32_t* iv, const int32_t* flag);
 int showo_engine_forward(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B, int L,
                          float* logits, void* stream);
 /* Final-LN'ed hidden rows + restricted lm_head: logits fp32 [nrows, ncols] for token rows `rows`

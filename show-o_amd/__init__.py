@@ -10,3 +10,4 @@ from .modeling_showo import Showo, gen_config  # noqa: F401
 from .modeling_magvitv2 import MAGVITv2  # noqa: F401
 from . import _lib  # noqa: F401
 from .training import Trainer  # noqa: F401
+from . import prompting_utils  # noqa: F401

@@ -34,6 +34,9 @@ _PROTOS = {
     "showo_gemm_set_impl": [c_i],
     "showo_gemm_tune": [c_i, c_i, c_p],
     "showo_attn_set_impl": [c_i],
+    "showo_mask_predict_next": [c_p, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_p, c_p, c_p, c_p],
+    "showo_mask_mmu": [c_p, c_i, c_i, c_i64, c_p, c_p, c_p],
+    "showo_mask_mmu_vit": [c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "showo_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "showo_ln_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "showo_ln_bwd_blocks": [c_i],
@@ -87,6 +90,7 @@ _PROTOS = {
     "showo_engine_create": [c_p, C.POINTER(c_p)],
     "showo_engine_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_engine_missing": [c_p],
+    "showo_engine_use_intervals": [c_p, c_p, c_p],
     "showo_engine_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "showo_engine_forward_rows": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p],
     "showo_engine_t2i_generate": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_i, c_i, c_f, c_i, c_p, c_p, c_u64,
@@ -101,6 +105,8 @@ _PROTOS = {
     "showo_prof_enable": [c_i],
     "showo_prof_reset": [],
     "showo_prof_read": [c_i, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)],
+    "showo_prof_set_stride": [c_i],
+    "showo_prof_totals": [c_i, c_p, c_p],
 }
 _VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p], "showo_train_destroy": [c_p]}
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + ["showo_last_error"])

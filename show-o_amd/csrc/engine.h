@@ -50,6 +50,9 @@ struct showo_engine {
     int last_iv[4] = {0, 0, 0, 0};
     int32_t* iv1 = nullptr;
     int64_t* tok1 = nullptr;
+    // caller-provided visibility intervals (showo_engine_use_intervals): used when a call passes no dense mask
+    const int32_t* ext_iv = nullptr;
+    const int32_t* ext_flag = nullptr;
     // hipGraph replay of the denoise step
     int* step_dev = nullptr;
     float* sched_dev = nullptr;

@@ -219,6 +219,8 @@ static int hidden(showo_engine* e, const int64_t* ids, const float* embeds, cons
     if (mask) {
         TRY(showo_mask_compress(mask, e->iv, e->flag, B, L, L, s));
         iv = e->iv; flag = e->flag;
+    } else if (e->ext_iv) {
+        iv = e->ext_iv; flag = e->ext_flag;
     }
     return run_layers(e, B, L, 0, false, iv, flag, mask, s);
 }
@@ -273,6 +275,8 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     if (mask) {
         TRY(showo_mask_compress(mask, e->iv, e->flag, nseq, L, L, s));  // the mask is step-invariant: compress once
         iv = e->iv; flag = e->flag;
+    } else if (e->ext_iv) {
+        iv = e->ext_iv; flag = e->ext_flag;
     }
     // one denoise step (modeling_showo.py:135-179).  dev_step: the step index / schedule constants are read on the device
     auto denoise_step = [&](int step) -> int {
@@ -402,4 +406,13 @@ extern "C" int showo_engine_decode_step(showo_engine* e, const int64_t* id, cons
     TRY(run_layers(e, 1, 1, P, true, e->iv1, e->flag, nullptr, s));
     e->cache_len = P + 1;
     return head_rows(e, nullptr, 1, 0, e->V, logits_last, s);
+}
+
+// Visibility intervals built on the device (showo_mask_predict_next / _mmu / _mmu_vit) instead of a dense mask: the next
+// forward / forward_rows / t2i_generate calls that pass mask == NULL attend with iv int32 [B,L,4] (NULL restores causal).
+extern "C" int showo_engine_use_intervals(showo_engine* e, const int32_t* iv, const int32_t* flag) {
+    if (!e) return set_error_msg(1, "engine: null handle");
+    e->ext_iv = iv;
+    e->ext_flag = iv ? flag : nullptr;
+    return 0;
 }

@@ -40,9 +40,14 @@ extern "C" int showo_device_info(int* cu_count, int* wave_size, char* arch_name,
 namespace showo {
 struct ProfRec { int kind; double work; hipEvent_t a, b; };
 static bool g_prof_on = false;
+static int g_prof_stride = 1;            // time every stride-th launch of a kind (systematic sample; 1 = all)
+static int64_t g_prof_seen[PROF_KINDS] = {0, 0, 0};
+static double g_prof_work_all[PROF_KINDS] = {0, 0, 0};
 static std::vector<ProfRec> g_prof;
 ProfScope::ProfScope(int kind, double work, hipStream_t stream) : idx(-1), s(stream) {
     if (!g_prof_on) return;
+    g_prof_work_all[kind] += work;
+    if ((g_prof_seen[kind]++ % g_prof_stride) != 0) return;
     ProfRec r;
     r.kind = kind; r.work = work;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -63,6 +68,19 @@ extern "C" int showo_prof_enable(int on) {
 extern "C" int showo_prof_reset(void) {
     for (auto& r : showo::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     showo::g_prof.clear();
+    for (int k = 0; k < showo::PROF_KINDS; ++k) { showo::g_prof_seen[k] = 0; showo::g_prof_work_all[k] = 0; }
+    return 0;
+}
+// time only every stride-th launch of each kind (a stride coprime to the per-layer launch pattern samples every shape)
+extern "C" int showo_prof_set_stride(int stride) {
+    showo::g_prof_stride = stride > 0 ? stride : 1;
+    return 0;
+}
+// launches seen / work submitted (timed or not) since the last reset
+extern "C" int showo_prof_totals(int kind, int64_t* launches, double* work) {
+    if (kind < 0 || kind >= showo::PROF_KINDS) return showo::set_error_msg(1, "prof_totals: bad kind");
+    if (launches) *launches = showo::g_prof_seen[kind];
+    if (work) *work = showo::g_prof_work_all[kind];
     return 0;
 }
 // kind: 0 gemm, 1 attention, 2 conv.  Returns summed elapsed ms, launch count and summed work (flops).

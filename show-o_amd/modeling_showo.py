@@ -284,6 +284,16 @@ class Showo(nn.Module):
             raise RuntimeError(f"engine is missing {missing} tensors")
         return self._engine
 
+    def _use_mask(self, eng, attention_mask):
+        """dense additive mask -> contiguous fp32 tensor; IntervalMask (prompting_utils.intervals_*) -> registered with the
+        engine, returns None (the call then passes no dense mask)"""
+        from .prompting_utils import IntervalMask
+        if isinstance(attention_mask, IntervalMask):
+            attention_mask.check()
+            _lib.call("showo_engine_use_intervals", eng, _lib.ptr(attention_mask.iv), _lib.ptr(attention_mask.flag))
+            return None
+        return attention_mask.detach().float().contiguous()
+
     # ---- Showo.forward (reference models/modeling_showo.py:59-102) -------------------------------------
     def forward(self, input_ids, input_embeddings=None, attention_mask=None, labels=None, label_smoothing=0.0,
                 batch_size_t2i=0, batch_size_lm=0, batch_size_mmu=0, max_seq_length=128, labels_mask_text=None,
@@ -309,10 +319,13 @@ class Showo(nn.Module):
         if attention_mask is not None:
             if tuple(attention_mask.shape) != (B, 1, L, L):  # same check as the eager path, reference models/phi.py:368-372
                 raise ValueError(f"Attention mask should be of size {(B, 1, L, L)}, but is {tuple(attention_mask.shape)}")
-            mask = attention_mask.detach().float().contiguous()
+            mask = self._use_mask(eng, attention_mask)
         logits = torch.empty((B, L, self.vocab_size), dtype=torch.float32, device=dev)
-        _lib.call("showo_engine_forward", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), B, L, _lib.ptr(logits),
-                  _lib.stream())
+        try:
+            _lib.call("showo_engine_forward", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), B, L, _lib.ptr(logits),
+                      _lib.stream())
+        finally:
+            _lib.call("showo_engine_use_intervals", eng, None, None)
         if labels is None:
             return logits
         raise AssertionError("unreachable")
@@ -332,7 +345,7 @@ class Showo(nn.Module):
         unc = None
         if uncond_input_ids is not None and guidance_scale > 0:
             unc = uncond_input_ids.to(torch.int64).contiguous()
-        mask = None if attention_mask is None else attention_mask.detach().float().contiguous()
+        mask = None if attention_mask is None else self._use_mask(eng, attention_mask)
         import ctypes as C
         ml, tp = t2i_step_constants(timesteps, N, temperature, noise_schedule)
         ml_a = (C.c_float * timesteps)(*ml)
@@ -361,6 +374,7 @@ class Showo(nn.Module):
             cur.wait_stream(self._graph_stream)
         else:
             run()
+        _lib.call("showo_engine_use_intervals", eng, None, None)
         return out
 
     # ---- Showo.mmu_generate (reference models/modeling_showo.py:183-240) -----------------------------------

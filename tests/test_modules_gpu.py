@@ -225,3 +225,53 @@ def test_magvit_get_code_vs_reference_golden(precision):
     # round trip property: decode(get_code(x)) has the image shape and is finite
     rec = v.decode_code(ids)
     assert tuple(rec.shape) == tuple(g["x"].shape) and torch.isfinite(rec).all()
+
+
+def test_on_device_mask_builders_match_reference_masks():
+    """show-o_amd/prompting_utils.py (HIP kernels) vs the masks the REFERENCE built for the golden batches, bit for bit;
+    the interval form gives the same logits as the dense form without materialising [N,1,L,L]"""
+    P = util.pkg().prompting_utils
+    g = util.golden("showo_tiny_forward.npz")
+    d, sd = util.tiny_state()
+    kw = dict(pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id)
+    ids = dev(g["t2i_ids"])
+    m_t = P.create_attention_mask_predict_next(ids, rm_pad_in_image=True, **kw)
+    assert m_t.dtype == torch.float32 and torch.equal(m_t.cpu(), torch.from_numpy(g["t2i_mask"]))
+    assert torch.equal(P.create_attention_mask_predict_next(ids, rm_pad_in_image=True, return_inverse_mask=False, **kw).cpu(),
+                       torch.from_numpy(g["t2i_mask"]) == 0)
+    m_u = P.create_attention_mask_for_mmu(dev(g["mmu_ids"]), eoi_id=d.eoi_id)
+    assert torch.equal(m_u.cpu(), torch.from_numpy(g["mmu_mask"]))
+    # mixed training batch: 2 t2i rows (rm_pad_in_image), 1 lm row (plain), 2 mmu rows
+    tr = dev(g["train_ids"])
+    parts = [P.create_attention_mask_predict_next(tr[:2], rm_pad_in_image=True, **kw),
+             P.create_attention_mask_predict_next(tr[2:3], **kw), P.create_attention_mask_for_mmu(tr[3:], eoi_id=d.eoi_id)]
+    assert torch.equal(torch.cat(parts).cpu(), torch.from_numpy(g["train_mask"]))
+    # scattered pads (not interval-representable): the dense form is still exact, the interval form refuses
+    rs = np.random.RandomState(5)
+    odd = torch.from_numpy(rs.randint(10, 200, size=(3, 40)))
+    odd[:, 20] = d.soi_id; odd[:, 37] = d.eoi_id
+    odd[0, [1, 5, 9]] = d.pad_id; odd[1, :4] = d.pad_id; odd[2, [0, 1, 30]] = d.pad_id
+    for rm in (False, True):
+        got = P.create_attention_mask_predict_next(dev(odd), rm_pad_in_image=rm, **kw)
+        assert torch.equal(got.cpu(), O.mask_t2i(odd, d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=rm)), rm
+    with pytest.raises(ValueError):
+        P.intervals_predict_next(dev(odd), rm_pad_in_image=True, **kw).check()
+    vit = P.create_attention_mask_for_mmu_vit(torch.zeros(2, 700, 8, device="cuda"), system_prompt_len=28)
+    assert torch.equal(vit.cpu(), O.mask_mmu_vit(2, 700, system_prompt_len=28))
+    # interval masks straight into the model: identical logits, identical t2i trajectory
+    m = util.build_showo(d, sd)
+    iv = P.intervals_predict_next(ids, rm_pad_in_image=True, **kw)
+    assert torch.equal(m(ids, attention_mask=iv), m(ids, attention_mask=m_t))
+    assert torch.equal(m(dev(g["mmu_ids"]), attention_mask=P.intervals_for_mmu(dev(g["mmu_ids"]), eoi_id=d.eoi_id)),
+                       m(dev(g["mmu_ids"]), attention_mask=m_u))
+    g2 = util.golden("showo_tiny_t2i.npz")
+    steps, B = int(g2["steps"]), g2["ids_cond"].shape[0]
+    N, V = d.num_vq_tokens, d.codebook
+    en, un = dev(g2["exp_noise"].reshape(steps, B * N, V)), dev(g2["uniform"].reshape(steps, B, N))
+    both = torch.cat([dev(g2["ids_cond"]), dev(g2["ids_uncond"])])
+    outs = []
+    for am in (dev(g2["mask"]), P.intervals_predict_next(both, rm_pad_in_image=True, **kw)):
+        outs.append(m.t2i_generate(input_ids=dev(g2["ids_cond"]).clone(), uncond_input_ids=dev(g2["ids_uncond"]), attention_mask=am,
+                                   timesteps=steps, guidance_scale=float(g2["guidance"]), config=util.gen_config(d), _exp_noise=en,
+                                   _uniform=un))
+    assert torch.equal(outs[0], outs[1])
