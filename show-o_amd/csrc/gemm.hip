@@ -1199,6 +1199,99 @@ int dispatch2p(GemmArgs g, int epilogue, hipStream_t s) {
     return set_error_msg(1, "gemm: unknown epilogue");
 }
 
+// =====================================================================================================
+// GEMV form for decode steps (M <= 8 token rows): the weight matrix is streamed ONCE straight into VGPRs (no LDS round
+// trip: nothing is shared between waves), a wave owns GV_COLS output columns and splits K over its lanes (16-B loads,
+// 4 loads in flight per column), the activation rows come from L1/L2; fp32 accumulate, wave-level reduction, the same
+// epilogues as the tile kernels.  HBM-bound: N*K*2 bytes per launch (2.9 GB per decoded token over the whole model).
+// =====================================================================================================
+constexpr int GV_COLS = 2;  // output columns per wave
+template <int EPI, int MR>
+__global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * GV_COLS;
+    if (n0 >= g.N) return;
+    float acc[MR][GV_COLS];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int c = 0; c < GV_COLS; ++c) acc[m][c] = 0.f;
+    const bf16_t* wr[GV_COLS];
+#pragma unroll
+    for (int c = 0; c < GV_COLS; ++c) wr[c] = g.W + (int64_t)min(n0 + c, g.N - 1) * g.ldw;
+    for (int k0 = lane * 8; k0 < g.K; k0 += 4 * 512) {
+        uint4 wv[4][GV_COLS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < GV_COLS; ++c) {
+                const int k = k0 + u * 512;
+                wv[u][c] = k < g.K ? *reinterpret_cast<const uint4*>(wr[c] + k) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 512;
+            if (k >= g.K) break;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m >= g.M) break;
+                const uint4 av = *reinterpret_cast<const uint4*>(g.A + (int64_t)m * g.lda + k);
+                const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
+#pragma unroll
+                for (int c = 0; c < GV_COLS; ++c) {
+                    const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u][c]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(bf2f(ea[j]), bf2f(ew[j]), acc[m][c]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int c = 0; c < GV_COLS; ++c) acc[m][c] = wave_sum(acc[m][c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= g.M) break;
+#pragma unroll
+            for (int c = 0; c < GV_COLS; ++c) {
+                const int n = n0 + c;
+                if (n >= g.N) break;
+                float v = acc[m][c];
+                if (g.bias) v += g.bias_per_row ? g.bias[m] : g.bias[n];
+                if (EPI == SHOWO_EPI_GELU_BF16) v = gelu_new_fast(v);
+                if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
+                    reinterpret_cast<bf16_t*>(g.out)[(int64_t)m * g.ldo + n] = f2bf(v);
+                } else {
+                    if (EPI == SHOWO_EPI_RESID_F32) v += g.resid[(int64_t)m * g.ldr + n];
+                    reinterpret_cast<float*>(g.out)[(int64_t)m * g.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_gemv(const GemmArgs& g, hipStream_t s) {
+    const int blocks = (g.N + 4 * GV_COLS - 1) / (4 * GV_COLS);
+    if (g.M <= 1) gemv_kernel<EPI, 1><<<dim3(blocks), dim3(256), 0, s>>>(g);
+    else if (g.M <= 4) gemv_kernel<EPI, 4><<<dim3(blocks), dim3(256), 0, s>>>(g);
+    else gemv_kernel<EPI, 8><<<dim3(blocks), dim3(256), 0, s>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "gemv launch", __FILE__, __LINE__);
+    return 0;
+}
+int dispatch_gemv(const GemmArgs& g, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case SHOWO_EPI_BF16: return launch_gemv<SHOWO_EPI_BF16>(g, s);
+        case SHOWO_EPI_GELU_BF16: return launch_gemv<SHOWO_EPI_GELU_BF16>(g, s);
+        case SHOWO_EPI_F32: return launch_gemv<SHOWO_EPI_F32>(g, s);
+        case SHOWO_EPI_RESID_F32: return launch_gemv<SHOWO_EPI_RESID_F32>(g, s);
+    }
+    return set_error_msg(1, "gemm: unknown epilogue");
+}
+
 // 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel, 0 = pick by shape
 int g_gemm_forced = -1;
 int gemm_impl_choice(int M, int N) {
@@ -1206,7 +1299,8 @@ int gemm_impl_choice(int M, int N) {
         const char* e = getenv("SHOWO_GEMM_IMPL");
         g_gemm_forced = e ? atoi(e) : 0;
     }
-    if (g_gemm_forced >= 1 && g_gemm_forced <= 5) return g_gemm_forced;
+    if (g_gemm_forced >= 1 && g_gemm_forced <= 6) return g_gemm_forced;
+    if (M <= 8) return 6;  // decode step: weight-streaming GEMV
     return (M >= 1024 && N >= 256) ? 5 : 1;
 }
 
@@ -1214,7 +1308,7 @@ int gemm_impl_choice(int M, int N) {
 
 // 0 = choose by shape (default), 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel
 extern "C" int showo_gemm_set_impl(int impl) {
-    g_gemm_forced = (impl >= 1 && impl <= 5) ? impl : 0;
+    g_gemm_forced = (impl >= 1 && impl <= 6) ? impl : 0;
     return 0;
 }
 
@@ -1250,6 +1344,8 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     if (impl >= 3 && ((int64_t)M * lda * 2 >= ((int64_t)1 << 32) || (int64_t)N * ldw * 2 >= ((int64_t)1 << 32))) impl = 2;
     if (impl == 3) return dispatch3<4>(g, epilogue, (hipStream_t)stream);
     if (impl == 4) return dispatch3<2>(g, epilogue, (hipStream_t)stream);
+    if (impl == 6 && M <= 8 && (K % 8) == 0) return dispatch_gemv(g, epilogue, (hipStream_t)stream);
+    if (impl == 6) impl = 1;
     if (impl == 5) return dispatch2p(g, epilogue, (hipStream_t)stream);
     if (impl == 2) {
         LinearPtr lp;
