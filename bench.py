@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-stride", type=int, default=7, help="time every n-th launch of a kernel kind with HIP events (7 is coprime to the 4 GEMMs per layer)")
+    ap.add_argument("--no-prefix-reuse", action="store_true", help="recompute the step-invariant text rows in every denoise step (A/B)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (A/B of their overhead)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the denoise step as a hipGraph (no per-launch events: roofline leg reports null)")
     ap.add_argument("--workload", default="t2i", help="t2i (default, the headline metric) | train (bench_train.py: stage-1 step time)")
@@ -161,7 +162,7 @@ def main():
     def step():
         ids = ic_d.clone()
         toks = model.t2i_generate(input_ids=ids, uncond_input_ids=iu_d, attention_mask=mask_d, temperature=1.0, timesteps=18,
-                                  guidance_scale=5.0, generator=gen, config=cfg, use_graph=a.graph)
+                                  guidance_scale=5.0, generator=gen, config=cfg, use_graph=a.graph, reuse_prefix=not a.no_prefix_reuse)
         toks = torch.clamp(toks, max=d.codebook - 1, min=0)
         return vq.decode_code(toks)
 

@@ -285,8 +285,9 @@ int showo_engine_forward_rows(showo_engine* e, const int64_t* ids, const float* 
                               const int32_t* rows, int nrows, int col0, int ncols, float* logits, void* stream);
 /* Showo.t2i_generate (modeling_showo.py:104-181).  ids_cond int64 [B,L] is updated in place like the
  * reference; ids_uncond may be NULL (no CFG).  mask fp32 [(2)B,1,L,L].  mask_len_host/temps_host: per-step
- * host constants (floor(N*schedule((k+1)/T)) and the compounding temperature).  use_graph: capture one
- * denoise step into a hipGraph and replay it.  Optional injected noise (tests): exp_noise [steps,B*N,V],
+ * host constants (floor(N*schedule((k+1)/T)) and the compounding temperature).  use_graph: bit 0 = capture one
+ * denoise step into a hipGraph and replay it; bit 1 = do NOT reuse the step-invariant text rows (by default step 0 runs
+ * the whole sequence and leaves every layer's K / V^T in a cache, later steps run only the rows from <soi> on).  Optional injected noise (tests): exp_noise [steps,B*N,V],
  * uniform [steps,B,N].  out sampled int64 [B,N]. */
 int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int64_t* ids_uncond, const float* mask, int B, int L,
                               int num_vq_tokens, int text_len, int64_t mask_id, int id_offset, int codebook,

@@ -50,6 +50,11 @@ struct showo_engine {
     int last_iv[4] = {0, 0, 0, 0};
     int32_t* iv1 = nullptr;
     int64_t* tok1 = nullptr;
+    // t2i prefix reuse: per-layer K / V^T of the whole batch (text rows are written once, image rows every step)
+    bf16_t *tk = nullptr, *tvt = nullptr;
+    int64_t tk_cap = 0, tvt_cap = 0;
+    int64_t* ids_act = nullptr;
+    int32_t *iv_act = nullptr, *rows_act = nullptr, *pfx_flag = nullptr;
     // caller-provided visibility intervals (showo_engine_use_intervals): used when a call passes no dense mask
     const int32_t* ext_iv = nullptr;
     const int32_t* ext_flag = nullptr;

@@ -51,6 +51,34 @@ __global__ void rows_index_kernel(int32_t* rows, int nseq, int L, int img_start,
 __global__ void set_iv_kernel(int32_t* iv, int a, int b, int c, int d) {
     if (threadIdx.x == 0) { iv[0] = a; iv[1] = b; iv[2] = c; iv[3] = d; }
 }
+// ---- t2i prefix reuse: rows [0, prefix) of every sequence (pads + text; causal, never see an image column) are step-invariant
+__global__ void gather_ids_kernel(const int64_t* __restrict__ all, int64_t* __restrict__ act, int nseq, int L, int prefix) {
+    const int La = L - prefix;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseq * La) return;
+    int b = i / La, j = i - b * La;
+    act[i] = all[(int64_t)b * L + prefix + j];
+}
+__global__ void gather_iv_kernel(const int32_t* __restrict__ iv, int32_t* __restrict__ act, int nseq, int L, int prefix) {
+    const int La = L - prefix;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseq * La) return;
+    int b = i / La, j = i - b * La;
+    reinterpret_cast<int4*>(act)[i] = reinterpret_cast<const int4*>(iv)[(int64_t)b * L + prefix + j];
+}
+// out |= 1 if a prefix row can see a column >= prefix (then the prefix is not step-invariant), out |= 2 if *mask_flag is set
+__global__ void prefix_check_kernel(const int32_t* __restrict__ iv, const int32_t* __restrict__ mask_flag, int32_t* __restrict__ out,
+                                    int nseq, int L, int prefix) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && mask_flag && *mask_flag) atomicOr(out, 2);
+    if (i >= nseq * prefix) return;
+    int b = i / prefix, r = i - b * prefix;
+    const int4 v = reinterpret_cast<const int4*>(iv)[(int64_t)b * L + r];
+    int hi = 0;
+    if (v.x < v.y) hi = max(hi, v.y);
+    if (v.z < v.w) hi = max(hi, v.w);
+    if (hi > prefix) atomicOr(out, 1);
+}
 __global__ void copy_i64_kernel(const int64_t* s, int64_t* d, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = s[i];
@@ -167,18 +195,28 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     return rc;
 }
 
-// ---- the 24-layer stack.  K/V destination is either the per-call workspace or a layer slice of the cache.
-static int run_layers(showo_engine* e, int B, int L, int pos0, bool use_cache, const int32_t* iv, const int32_t* flag,
+// ---- the 24-layer stack.  K / V^T go to the per-call workspace (layer stride 0) or to a per-layer cache:
+//      the AR decode cache (one sequence) or the t2i prefix-reuse cache (whole batch).
+struct KVDest {
+    bf16_t *k, *vt;
+    int64_t k_lstride, v_lstride;  // elements between consecutive layers
+    int Lcap, Lp;                  // key rows per head in k, columns per row in vt
+};
+static KVDest kv_workspace(showo_engine* e, int L) { return KVDest{e->K, e->Vt, 0, 0, L, ((L + 63) / 64) * 64}; }
+static KVDest kv_decode_cache(showo_engine* e) {
+    return KVDest{e->kcache, e->vtcache, (int64_t)e->nH * e->cache_cap * 64, (int64_t)e->nH * 64 * e->cache_cap, e->cache_cap, e->cache_cap};
+}
+
+static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
                       const float* dense, hipStream_t s) {
     const int H = e->H, F = e->F, nH = e->nH;
     const int T = B * L;
     const int Lk = pos0 + L;
-    const int Lcap = use_cache ? e->cache_cap : L;
-    const int Lp = use_cache ? e->cache_cap : ((L + 63) / 64) * 64;
+    const int Lcap = kv.Lcap, Lp = kv.Lp;
     for (int li = 0; li < e->nL; ++li) {
         showo::Layer& l = e->layers[li];
-        bf16_t* Kd = use_cache ? e->kcache + (int64_t)li * nH * e->cache_cap * 64 : e->K;
-        bf16_t* Vd = use_cache ? e->vtcache + (int64_t)li * nH * 64 * e->cache_cap : e->Vt;
+        bf16_t* Kd = kv.k + li * kv.k_lstride;
+        bf16_t* Vd = kv.vt + li * kv.v_lstride;
         TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
         if (T >= 256 && e->cfg.rotary_dim == 32) {
             // prefill / t2i: one kernel (the projection's epilogue normalises, rotates and relayouts the fp32 accumulators)
@@ -222,7 +260,7 @@ static int hidden(showo_engine* e, const int64_t* ids, const float* embeds, cons
     } else if (e->ext_iv) {
         iv = e->ext_iv; flag = e->ext_flag;
     }
-    return run_layers(e, B, L, 0, false, iv, flag, mask, s);
+    return run_layers(e, B, L, 0, kv_workspace(e, L), iv, flag, mask, s);
 }
 
 static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
@@ -278,11 +316,52 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     } else if (e->ext_iv) {
         iv = e->ext_iv; flag = e->ext_flag;
     }
-    // one denoise step (modeling_showo.py:135-179).  dev_step: the step index / schedule constants are read on the device
-    auto denoise_step = [&](int step) -> int {
-        TRY(showo_embed_f32(e->ids_all, e->embed, e->x, nseq * L, e->H, e->V, s));
-        TRY(run_layers(e, nseq, L, 0, false, iv, flag, mask, s));
-        TRY(head_rows(e, e->rows, nrows, id_offset, codebook, e->row_logits, s));
+    // ---- prefix reuse.  Rows [0, prefix) of every sequence (pads + text, prefix = position of <soi>) are causal: they never see
+    // an image column, and their ids never change, so their hidden states -- hence their K / V in every layer -- are the same
+    // in all steps.  Step 0 runs the whole sequence and leaves K / V^T of every layer in a batch-wide cache; the later steps run
+    // only the rows [prefix, L) (soi, image tokens, eoi: 258 of 387 at 256x256) against the cached text keys.  Exact up to the
+    // grouping of rows into tiles (same arithmetic per row); checked on the device: interval masks only, no prefix row may see
+    // a column >= prefix.  use_graph bit 1 disables it.
+    const int prefix = text_len + 1;
+    const int La = L - prefix;
+    bool reuse = !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
+    if (reuse && !e->pfx_flag) {
+        TRY(e->alloc(&e->pfx_flag, 4));
+    }
+    if (reuse && iv) {
+        int32_t hflag = 0;
+        SHOWO_CHECK_HIP(hipMemsetAsync(e->pfx_flag, 0, sizeof(int32_t), s));
+        prefix_check_kernel<<<dim3((nseq * prefix + thr - 1) / thr), dim3(thr), 0, s>>>(iv, flag, e->pfx_flag, nseq, L, prefix);
+        SHOWO_CHECK_HIP(hipMemcpyAsync(&hflag, e->pfx_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SHOWO_CHECK_HIP(hipStreamSynchronize(s));
+        if (hflag) reuse = false;
+    }
+    const int LpC = ((L + 63) / 64) * 64;
+    KVDest kvc = kv_workspace(e, L);
+    if (reuse) {
+        const int64_t kn = (int64_t)e->nL * nseq * e->nH * L * 64, vn = (int64_t)e->nL * nseq * e->nH * 64 * LpC;
+        if (kn > e->tk_cap) { TRY(e->alloc(&e->tk, kn)); e->tk_cap = kn; }
+        if (vn > e->tvt_cap) { TRY(e->alloc(&e->tvt, vn)); e->tvt_cap = vn; }
+        SHOWO_CHECK_HIP(hipMemsetAsync(e->tvt, 0, (size_t)vn * sizeof(bf16_t), s));  // pad key columns must stay finite
+        if (!e->ids_act) { TRY(e->alloc(&e->ids_act, e->maxT)); TRY(e->alloc(&e->iv_act, e->maxT * 4)); TRY(e->alloc(&e->rows_act, e->maxT)); }
+        kvc = KVDest{e->tk, e->tvt, (int64_t)nseq * e->nH * L * 64, (int64_t)nseq * e->nH * 64 * LpC, L, LpC};
+        if (iv) gather_iv_kernel<<<dim3((nseq * La + thr - 1) / thr), dim3(thr), 0, s>>>(iv, e->iv_act, nseq, L, prefix);
+        rows_index_kernel<<<dim3((nrows + thr - 1) / thr), dim3(thr), 0, s>>>(e->rows_act, nseq, La, img_start - prefix, N);
+        SHOWO_CHECK_HIP(hipGetLastError());
+    }
+    // one denoise step (modeling_showo.py:135-179).  step < 0: the step index / schedule constants are read on the device.
+    // full: run every row (always in step 0); otherwise only the rows [prefix, L) against the cached prefix keys.
+    auto denoise_step = [&](int step, bool full) -> int {
+        if (full) {
+            TRY(showo_embed_f32(e->ids_all, e->embed, e->x, nseq * L, e->H, e->V, s));
+            TRY(run_layers(e, nseq, L, 0, kvc, iv, flag, mask, s));
+            TRY(head_rows(e, e->rows, nrows, id_offset, codebook, e->row_logits, s));
+        } else {
+            gather_ids_kernel<<<dim3((nseq * La + thr - 1) / thr), dim3(thr), 0, s>>>(e->ids_all, e->ids_act, nseq, L, prefix);
+            TRY(showo_embed_f32(e->ids_act, e->embed, e->x, nseq * La, e->H, e->V, s));
+            TRY(run_layers(e, nseq, La, prefix, kvc, iv ? e->iv_act : nullptr, nullptr, nullptr, s));
+            TRY(head_rows(e, e->rows_act, nrows, id_offset, codebook, e->row_logits, s));
+        }
         const float* lu = cfg ? e->row_logits + (int64_t)B * N * codebook : nullptr;
         const bool dev = step < 0;  // device-step mode: noise offsets are applied inside the kernels
         TRY(showo_cfg_softmax_sample(e->row_logits, lu, codebook, guidance, e->cur, mask_id,
@@ -296,9 +375,10 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     };
     // hipGraph path: step 0 runs eagerly (first-use kernel attributes are set outside a capture), then ONE step is captured
     // with the step index in device memory and replayed for the remaining steps.  Not combined with per-launch event timing.
-    const bool graph = use_graph && steps > 1 && !showo::g_prof_on_query();
+    const int n_eager = reuse ? 2 : 1;  // eager steps before a capture: every kernel variant has been launched once
+    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query();
     if (!graph) {
-        for (int step = 0; step < steps; ++step) TRY(denoise_step(step));
+        for (int step = 0; step < steps; ++step) TRY(denoise_step(step, step == 0 || !reuse));
     } else {
         if (!e->step_dev) TRY(e->alloc(&e->step_dev, 4));
         if (e->sched_cap < 2 * steps) { TRY(e->alloc(&e->sched_dev, 2 * steps)); e->sched_cap = 2 * steps; }
@@ -308,14 +388,17 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
         SHOWO_CHECK_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
         SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // `sched` is a host temporary
         showo::sampler_set_device_step(e->step_dev, e->sched_dev, steps);
-        int rc = denoise_step(-1);
-        if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
+        int rc = 0;
+        for (int i = 0; i < n_eager && !rc; ++i) {
+            rc = denoise_step(-1, i == 0 || !reuse);
+            if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
+        }
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         if (!rc) {
             hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (he == hipSuccess) {
-                rc = denoise_step(-1);
+                rc = denoise_step(-1, !reuse);
                 if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
                 hipError_t he2 = hipStreamEndCapture(s, &g);
                 if (!rc && he2 != hipSuccess) rc = set_error_hip(he2, "hipStreamEndCapture", __FILE__, __LINE__);
@@ -327,7 +410,7 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
             hipError_t he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             if (he != hipSuccess) rc = set_error_hip(he, "hipGraphInstantiate", __FILE__, __LINE__);
         }
-        for (int step = 1; !rc && step < steps; ++step) {
+        for (int step = n_eager; !rc && step < steps; ++step) {
             hipError_t he = hipGraphLaunch(ge, s);
             if (he != hipSuccess) rc = set_error_hip(he, "hipGraphLaunch", __FILE__, __LINE__);
         }
@@ -371,7 +454,7 @@ extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const f
         TRY(showo_mask_compress(mask, e->iv, e->flag, 1, L, L, s));
         iv = e->iv; flag = e->flag;
     }
-    TRY(run_layers(e, 1, L, 0, true, iv, flag, mask, s));
+    TRY(run_layers(e, 1, L, 0, kv_decode_cache(e), iv, flag, mask, s));
     e->prompt_len = L;
     e->cache_len = L;
     if (mask) {
@@ -403,7 +486,7 @@ extern "C" int showo_engine_decode_step(showo_engine* e, const int64_t* id, cons
     else return set_error_msg(6, "decode_step: mask row needs more than two intervals");
     set_iv_kernel<<<1, 64, 0, s>>>(e->iv1, a, b, c, d);
     hipMemsetAsync(e->flag, 0, 4, s);
-    TRY(run_layers(e, 1, 1, P, true, e->iv1, e->flag, nullptr, s));
+    TRY(run_layers(e, 1, 1, P, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
     e->cache_len = P + 1;
     return head_rows(e, nullptr, 1, 0, e->V, logits_last, s);
 }

@@ -356,12 +356,14 @@ class Showo(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         out = torch.empty((B, N), dtype=torch.int64, device=input_ids.device)
         use_graph = int(kwargs.get("use_graph", 0))
+        # bit 0: hipGraph replay of the denoise step; bit 1: recompute the step-invariant text rows every step (A/B switch)
+        flags = (1 if use_graph else 0) | (0 if kwargs.get("reuse_prefix", True) else 2)
 
         def run():
             _lib.call("showo_engine_t2i_generate", eng, _lib.ptr(input_ids), _lib.ptr(unc), _lib.ptr(mask), B, L, N, text_len,
                       self.config.mask_token_id, offset, codebook, float(guidance_scale), timesteps,
                       C.cast(ml_a, C.c_void_p), C.cast(tp_a, C.c_void_p), seed, _lib.ptr(_exp_noise), _lib.ptr(_uniform),
-                      use_graph, _lib.ptr(out), _lib.stream())
+                      flags, _lib.ptr(out), _lib.stream())
 
         if use_graph:
             # hipGraph replay of the denoise step: stream capture needs a non-default stream
