@@ -301,6 +301,12 @@ int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int64_t* ids_u
 int showo_engine_prefill(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L,
                          float* logits_last, void* stream);
 int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* embed, float* logits_last, void* stream);
+/* n_steps greedy (top_k = 1: the reference caller's setting, inference_mmu.py:81) continuation steps without host round trips:
+ * { embed(tok) -> layers against the KV cache -> lm_head -> arg-max -> tok }.  tok int64[1] (device) holds the token to feed
+ * first and the last produced one afterwards; out_tokens int64 [n_steps] (device); logits_ws fp32 [vocab] scratch.
+ * use_graph: capture one step (position and mask row live in device memory) into a hipGraph and replay it. */
+int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws, int use_graph,
+                               void* stream);
 /* greedy/top-k=1 pick on device: out int64[1] = argmax(logits) (first maximal index, like torch.topk/multinomial on a one-hot). */
 int showo_argmax_f32(const float* x, int n, int64_t* out, void* stream);
 

@@ -34,6 +34,7 @@ struct PrepArgs {
     bf16_t *Q, *K, *Vt;
     int B, L, nH, rot, pos0, Lcap, Lp;
     float eps;
+    const int* pos_dev;  // graph replay of a decode step: position of the first new token read on the device
 };
 
 __device__ inline float ln_rope_lane(float x, float w, float b, float eps, const float* cosr, const float* sinr, int rot, int d) {
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(PrepArgs a) {
     __shared__ bf16_t sV[64][66];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
+    if (a.pos_dev) a.pos0 = *a.pos_dev;
     const int H3 = 3 * a.nH * 64, Hq = a.nH * 64;
     const float qw = a.qw[lane], qb = a.qb[lane], kw = a.kw[lane], kb = a.kb[lane];
     for (int i = 0; i < 16; ++i) {
@@ -156,6 +158,7 @@ struct AttnArgs {
     bf16_t* O;
     int B, nH, Lq, Lk, Lcap, Lp, ldo;
     float* lse;  // optional (training): log-sum-exp of every score row, fp32 [B, nH, Lq]
+    const int* pos_dev;  // graph replay of a decode step (Lq = 1): Lk = *pos_dev + 1 read on the device
 };
 
 __device__ inline bf16x8 pack8(const float* p) {
@@ -168,6 +171,7 @@ __device__ inline bf16x8 pack8(const float* p) {
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    if (a.pos_dev) a.Lk = *a.pos_dev + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qblk = blockIdx.x * 4 + wave;
     if (qblk * 32 >= a.Lq) return;
@@ -485,6 +489,11 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
 
 }  // namespace
 
+// decode-step graph replay (engine-internal): when set, single-token qk_prep / attention launches take the position from
+// device memory, so the captured launch sequence is the same for every token
+static const int* g_decode_pos_dev = nullptr;
+namespace showo { void attn_set_decode_pos(const int* p) { g_decode_pos_dev = p; } }
+
 extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
                              const float* kln_b, const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K,
                              uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
@@ -496,6 +505,7 @@ extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const floa
     a.qkv = qkv; a.qw = qln_w; a.qb = qln_b; a.kw = kln_w; a.kb = kln_b; a.cosT = cos_tab; a.sinT = sin_tab;
     a.Q = Q; a.K = K; a.Vt = Vt; a.B = B; a.L = L; a.nH = nH; a.rot = rot; a.pos0 = pos0; a.Lcap = Lcap; a.Lp = Lp;
     a.eps = eps;
+    a.pos_dev = (L == 1 && B == 1) ? g_decode_pos_dev : nullptr;
     qk_prep_kernel<<<dim3((L + 63) / 64, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
@@ -510,6 +520,7 @@ extern "C" int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag
     return 0;
 }
 static int g_attn_forced = -1;
+
 extern "C" int showo_attn_set_impl(int impl) {
     g_attn_forced = (impl >= 1 && impl <= 3) ? impl : 0;
     return 0;
@@ -523,6 +534,7 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
     AttnArgs a;
     a.Q = Q; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = flag; a.dense = dense_mask; a.O = O;
     a.B = B; a.nH = nH; a.Lq = Lq; a.Lk = Lk; a.Lcap = Lcap; a.Lp = Lp; a.ldo = ldo; a.lse = lse;
+    a.pos_dev = (Lq == 1) ? g_decode_pos_dev : nullptr;
     int qblocks = (Lq + 31) / 32;
     ProfScope prof(PROF_ATTN, 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // dense QK^T + PV flops
     if (g_attn_forced < 0) { const char* e = getenv("SHOWO_ATTN_IMPL"); g_attn_forced = e ? atoi(e) : 0; }

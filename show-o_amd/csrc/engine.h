@@ -17,6 +17,7 @@ struct Layer {
 namespace showo {
 void sampler_set_device_step(const int* step_dev, const float* sched, int steps);
 int sampler_step_inc(int* step_dev, hipStream_t s);
+void attn_set_decode_pos(const int* p);
 extern bool g_prof_on_query();
 }  // namespace showo
 
@@ -58,6 +59,9 @@ struct showo_engine {
     // caller-provided visibility intervals (showo_engine_use_intervals): used when a call passes no dense mask
     const int32_t* ext_iv = nullptr;
     const int32_t* ext_flag = nullptr;
+    // hipGraph replay of the decode step: position and last-prompt-row intervals in device memory
+    int* pos_dev = nullptr;
+    int32_t* last_iv_dev = nullptr;
     // hipGraph replay of the denoise step
     int* step_dev = nullptr;
     float* sched_dev = nullptr;

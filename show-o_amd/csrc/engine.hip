@@ -79,6 +79,20 @@ __global__ void prefix_check_kernel(const int32_t* __restrict__ iv, const int32_
     if (v.z < v.w) hi = max(hi, v.w);
     if (hi > prefix) atomicOr(out, 1);
 }
+// mask row of the token at position *pos: the last prompt row extended by the columns [L0, pos] (modeling_showo.py:203-217)
+__global__ void decode_iv_kernel(const int32_t* __restrict__ last_iv, int L0, const int* __restrict__ pos, int32_t* __restrict__ iv) {
+    if (threadIdx.x != 0) return;
+    int a = last_iv[0], b = last_iv[1], c = last_iv[2], d = last_iv[3];
+    const int P = *pos;
+    if (b == L0 && a < b) b = P + 1;
+    else if (d == L0 && c < d) d = P + 1;
+    else if (!(c < d)) { c = L0; d = P + 1; }
+    else if (!(a < b)) { a = L0; b = P + 1; }
+    iv[0] = a; iv[1] = b; iv[2] = c; iv[3] = d;
+}
+__global__ void store_token_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ out, const int* __restrict__ pos, int base) {
+    if (threadIdx.x == 0) out[*pos - base] = *tok;
+}
 __global__ void copy_i64_kernel(const int64_t* s, int64_t* d, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = s[i];
@@ -497,5 +511,69 @@ extern "C" int showo_engine_use_intervals(showo_engine* e, const int32_t* iv, co
     if (!e) return set_error_msg(1, "engine: null handle");
     e->ext_iv = iv;
     e->ext_flag = iv ? flag : nullptr;
+    return 0;
+}
+
+// Greedy (top_k = 1) continuation: n_steps times { embed(tok) -> 24 layers against the KV cache -> lm_head -> arg-max -> tok },
+// the position and the mask row living in device memory so that ONE step can be captured into a hipGraph and replayed.
+// tok int64[1] (device): in = the token to feed first, out = the last token produced; out_tokens int64 [n_steps] (device).
+extern "C" int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws,
+                                          int use_graph, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!e || e->cache_len <= 0) return set_error_msg(1, "decode_greedy: prefill first");
+    if (!tok || !out_tokens || !logits_ws || n_steps < 1) return set_error_msg(1, "decode_greedy: bad arguments");
+    const int P0 = e->cache_len;
+    if (P0 + n_steps > e->cache_cap || P0 + n_steps > e->cfg.max_pos) return set_error_msg(5, "decode_greedy: cache full");
+    {   // the decode_step precondition: the mask row must stay a two-interval row
+        int a = e->last_iv[0], b = e->last_iv[1], c = e->last_iv[2], d = e->last_iv[3];
+        const int L0 = e->prompt_len;
+        if (!((b == L0 && a < b) || (d == L0 && c < d) || !(c < d) || !(a < b)))
+            return set_error_msg(6, "decode_greedy: mask row needs more than two intervals");
+    }
+    if (!e->pos_dev) { TRY(e->alloc(&e->pos_dev, 4)); TRY(e->alloc(&e->last_iv_dev, 4)); }
+    SHOWO_CHECK_HIP(hipMemcpyAsync(e->pos_dev, &P0, sizeof(int), hipMemcpyHostToDevice, s));
+    SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv_dev, e->last_iv, 4 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, 4, s));
+    SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // P0 / last_iv are host temporaries of this call
+    showo::attn_set_decode_pos(e->pos_dev);
+    auto one = [&]() -> int {
+        TRY(showo_embed_f32(tok, e->embed, e->x, 1, e->H, e->V, s));
+        decode_iv_kernel<<<1, 64, 0, s>>>(e->last_iv_dev, e->prompt_len, e->pos_dev, e->iv1);
+        // host-side P only sizes nothing here (grids depend on L = 1); the kernels read the position from pos_dev
+        TRY(run_layers(e, 1, 1, P0, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
+        TRY(head_rows(e, nullptr, 1, 0, e->V, logits_ws, s));
+        TRY(showo_argmax_f32(logits_ws, e->V, tok, s));
+        store_token_kernel<<<1, 64, 0, s>>>(tok, out_tokens, e->pos_dev, P0);
+        return showo::sampler_step_inc(e->pos_dev, s);
+    };
+    int rc = one();  // eager first step (kernel attributes, GEMV variants)
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    const bool graph = use_graph && n_steps > 1 && !showo::g_prof_on_query();
+    if (!rc && graph) {
+        hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (he == hipSuccess) {
+            rc = one();
+            hipError_t he2 = hipStreamEndCapture(s, &g);
+            if (!rc && he2 != hipSuccess) rc = set_error_hip(he2, "hipStreamEndCapture", __FILE__, __LINE__);
+        } else {
+            rc = set_error_hip(he, "hipStreamBeginCapture", __FILE__, __LINE__);
+        }
+        if (!rc) {
+            hipError_t he3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            if (he3 != hipSuccess) rc = set_error_hip(he3, "hipGraphInstantiate", __FILE__, __LINE__);
+        }
+        for (int i = 1; !rc && i < n_steps; ++i) {
+            hipError_t he4 = hipGraphLaunch(ge, s);
+            if (he4 != hipSuccess) rc = set_error_hip(he4, "hipGraphLaunch", __FILE__, __LINE__);
+        }
+    } else {
+        for (int i = 1; !rc && i < n_steps; ++i) rc = one();
+    }
+    showo::attn_set_decode_pos(nullptr);
+    if (ge) { hipStreamSynchronize(s); hipGraphExecDestroy(ge); }
+    if (g) hipGraphDestroy(g);
+    if (rc) return rc;
+    e->cache_len = P0 + n_steps;
     return 0;
 }

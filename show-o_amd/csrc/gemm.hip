@@ -1256,7 +1256,7 @@ int dispatch2p(GemmArgs g, int epilogue, hipStream_t s) {
 // 4 loads in flight per column), the activation rows come from L1/L2; fp32 accumulate, wave-level reduction, the same
 // epilogues as the tile kernels.  HBM-bound: N*K*2 bytes per launch (2.9 GB per decoded token over the whole model).
 // =====================================================================================================
-constexpr int GV_COLS = 2;  // output columns per wave
+constexpr int GV_COLS = 1;  // output columns per wave (1: most waves in flight -- the kernel is latency x concurrency bound)
 template <int EPI, int MR>
 __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -404,19 +404,33 @@ class Showo(nn.Module):
         logits = torch.empty((self.vocab_size,), dtype=torch.float32, device=dev)
         tok = torch.empty((1,), dtype=torch.int64, device=dev)
         _lib.call("showo_engine_prefill", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), L, _lib.ptr(logits), _lib.stream())
-        result = []
-        for _ in range(max_new_tokens):
-            # logits / temperature does not change the arg-max for temperature > 0; top_k=1 makes the reference's
-            # multinomial a deterministic arg-max
-            _lib.call("showo_argmax_f32", _lib.ptr(logits), self.vocab_size, _lib.ptr(tok), _lib.stream())
-            result.append(tok[0].clone())
-            if eot_token is not None and int(tok.item()) == eot_token:
-                break
-            if len(result) == max_new_tokens:
-                break
-            # the next input is embed_tokens(token) in both reference branches (modeling_showo.py:231-235); the engine
-            # gathers that row from its own copy of the table
-            _lib.call("showo_engine_decode_step", eng, _lib.ptr(tok), None, _lib.ptr(logits), _lib.stream())
+        # logits / temperature does not change the arg-max for temperature > 0; top_k=1 makes the reference's multinomial a
+        # deterministic arg-max.  The first token comes from the prefill logits; the continuation runs in
+        # chunks of `chunk` steps entirely on the device (embed -> 24 layers on the KV cache -> lm_head -> arg-max), one
+        # hipGraph replay per step, and the host looks at the tokens (for <eot>) once per chunk.
+        _lib.call("showo_argmax_f32", _lib.ptr(logits), self.vocab_size, _lib.ptr(tok), _lib.stream())
+        first = int(tok.item())
+        result = [torch.tensor(first, device=dev)]
+        if (eot_token is not None and first == eot_token) or max_new_tokens <= 1:
+            return result[:max_new_tokens]
+        use_graph, chunk = int(getattr(self, "decode_graph", 1)), 16
+        if getattr(self, "_graph_stream", None) is None:
+            self._graph_stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        remaining = max_new_tokens - 1
+        while remaining > 0:
+            n = min(chunk, remaining)
+            outc = torch.empty((n,), dtype=torch.int64, device=dev)
+            self._graph_stream.wait_stream(cur)
+            with torch.cuda.stream(self._graph_stream):
+                _lib.call("showo_engine_decode_greedy", eng, _lib.ptr(tok), n, _lib.ptr(outc), _lib.ptr(logits), use_graph, _lib.stream())
+            cur.wait_stream(self._graph_stream)
+            toks = outc.tolist()
+            for t in toks:
+                result.append(torch.tensor(t, device=dev))
+                if eot_token is not None and t == eot_token:
+                    return result
+            remaining -= n
         return result
 
 

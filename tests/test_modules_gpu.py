@@ -129,6 +129,19 @@ def test_tiny_mmu_generate_matches_reference_tokens():
     big = O.mask_mmu(seq.cpu(), d.eoi_id)
     lg = m(seq, attention_mask=big.cuda())
     assert int(lg[0, -1].argmax()) == got[2]
+    # the device-side continuation loop: eager steps == hipGraph replay == the reference, also across chunk boundaries
+    for graph in (0, 1):
+        m.decode_graph = graph
+        toks2 = m.mmu_generate(dev(g["ids"]), attention_mask=dev(g["mask"]), max_new_tokens=40, top_k=1)
+        assert [int(t) for t in toks2][:len(g["tokens"])] == [int(t) for t in g["tokens"]]
+        if graph == 0:
+            long_ref = [int(t) for t in toks2]
+        else:
+            assert [int(t) for t in toks2] == long_ref and len(long_ref) == 40
+    first = long_ref[3]
+    stopped = m.mmu_generate(dev(g["ids"]), attention_mask=dev(g["mask"]), max_new_tokens=40, top_k=1, eot_token=first)
+    assert [int(t) for t in stopped] == long_ref[:long_ref.index(first) + 1]  # stops right after <eot> like the reference
+
 
 
 def test_full_size_logits_vs_reference_subset():

@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
         {300, 256, 64, 2, "edge-small"}, {1100, 520, 192, 2, "edge-ragged"}, {1548, 2048, 256, 3, "ragged-resid"},
         {6192, 6144, 2048, 0, "qkv"}, {6192, 2048, 2048, 3, "dense"}, {6192, 8192, 2048, 1, "fc1+gelu"},
         {6192, 2048, 8192, 3, "fc2"}, {4096, 8192, 2048, 2, "lm_head rows"}, {6192, 14336, 2048, 0, "qkv|fc1 fused"},
-        {6192, 2048, 10240, 3, "dense|fc2 fused"}, {4128, 6144, 2048, 0, "qkv act258"}, {4128, 2048, 2048, 3, "dense act258"}, {4128, 8192, 2048, 1, "fc1 act258"}, {4128, 2048, 8192, 3, "fc2 act258"}, {9240, 6144, 2048, 0, "qkv L1155"}, {9240, 2048, 8192, 3, "fc2 L1155"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
+        {6192, 2048, 10240, 3, "dense|fc2 fused"}, {4128, 6144, 2048, 0, "qkv act258"}, {4128, 2048, 2048, 3, "dense act258"}, {4128, 8192, 2048, 1, "fc1 act258"}, {4128, 2048, 8192, 3, "fc2 act258"}, {4128, 2048, 10240, 3, "dense|fc2 act258"}, {4128, 14336, 2048, 0, "qkv|fc1 act258"}, {9240, 6144, 2048, 0, "qkv L1155"}, {9240, 2048, 8192, 3, "fc2 L1155"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
     };
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
