@@ -489,6 +489,178 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Single-query form (AR decode step, Lq = 1): one 1024-thread block per (head, batch).  The 32x32 MFMA tiles of the
+// prefill kernels would run one query row through ~20 dependent key tiles on ONE wave (51 us per layer); here every
+// thread scores one key (q . K[k], fp32 FMAs over the 128-B key row), the soft-max is a block reduction, and wave w then
+// accumulates head dimensions 4w..4w+3: the key-contiguous V^T rows are read coalesced (lane -> 8 consecutive keys) and
+// reduced across the wave.  FUSED additionally does qk_prep's work for the new token of its head first (q/k LayerNorm +
+// partial RoPE, K row and V^T column appended to the cache) so a decode layer needs no separate prep launch; the new
+// key / value are taken from LDS, never re-read from global memory inside the launch.
+// ------------------------------------------------------------------------------------------------
+struct DecPrep {
+    const bf16_t* qkv;  // [3 * nH * 64] projection row of the new token (B = 1)
+    const float *qw, *qb, *kw, *kb, *cosT, *sinT;
+    int rot, pos;
+    float eps;
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f) {
+    extern __shared__ float sp[];  // probabilities, zero padded to a multiple of 512 keys
+    __shared__ float red[32];
+    __shared__ float sq[64], sk[64], sv[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int64_t bh = (int64_t)b * a.nH + head;
+    int pos = -1;  // FUSED: index of the key that lives in LDS
+    if (FUSED) {
+        pos = a.pos_dev ? *a.pos_dev : f.pos;
+        a.Lk = pos + 1;
+    } else if (a.pos_dev) {
+        a.Lk = *a.pos_dev + 1;
+    }
+    // Everything the cache contributes is requested up front (the first 1024 key rows: one per thread; the first 1024
+    // keys of this wave's four V^T rows), so the launch costs one HBM round trip, not one per phase.
+    const bf16_t* Kb = a.K + bh * a.Lcap * 64;
+    const int d0 = wave * 4;
+    const bf16_t* vr = a.Vt + (bh * 64 + d0) * a.Lp;
+    // key rows are read coalesced: a wave instruction covers 8 whole rows (lane -> row lane>>3, 16-B chunk lane&7), wave w of
+    // the block takes row group it*16 + w; the first 8 groups per wave (1024 keys) are requested before anything else.
+    const int r8 = lane >> 3, ch = lane & 7;
+    uint4 ku[8], vu[2][4];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int k = (it * 16 + wave) * 8 + r8;
+        ku[it] = (k < a.Lk && k != pos) ? *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            vu[cc][i] = (cc * 512 + 8 * lane < a.Lk) ? *reinterpret_cast<const uint4*>(vr + (int64_t)i * a.Lp + cc * 512 + 8 * lane)
+                                                     : make_uint4(0, 0, 0, 0);
+    float qv[8];  // this lane's 8 query dimensions (chunk ch)
+    if (FUSED) {
+        const int Hq = a.nH * 64;
+        if (wave < 2) {
+            const float* cosr = f.cosT + (int64_t)pos * f.rot;
+            const float* sinr = f.sinT + (int64_t)pos * f.rot;
+            if (wave == 0) {
+                const float y = ln_rope_lane(bf2f(f.qkv[head * 64 + lane]), f.qw[lane], f.qb[lane], f.eps, cosr, sinr, f.rot, lane);
+                sq[lane] = bf2f(f2bf(y * 0.125f));
+            } else {
+                const float y = ln_rope_lane(bf2f(f.qkv[Hq + head * 64 + lane]), f.kw[lane], f.kb[lane], f.eps, cosr, sinr, f.rot, lane);
+                const bf16_t kb = f2bf(y);
+                sk[lane] = bf2f(kb);
+                const_cast<bf16_t*>(a.K)[(bh * a.Lcap + pos) * 64 + lane] = kb;
+            }
+        } else if (wave == 2) {
+            const bf16_t vb = f.qkv[2 * Hq + head * 64 + lane];
+            sv[lane] = bf2f(vb);
+            const_cast<bf16_t*>(a.Vt)[(bh * 64 + lane) * a.Lp + pos] = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = sq[ch * 8 + j];
+    } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(a.Q + bh * 64 + ch * 8);  // Lq = 1
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = bf2f(e[j]);
+    }
+    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);
+    int lo1, hi1, lo2, hi2;
+    if (dense) { lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0; }
+    else if (a.iv) {
+        const int4 v = *reinterpret_cast<const int4*>(a.iv + (int64_t)b * 4);
+        lo1 = v.x; hi1 = v.y; lo2 = v.z; hi2 = v.w;
+    } else { lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0; }  // causal: the newest token sees every key
+    hi1 = min(hi1, a.Lk); hi2 = min(hi2, a.Lk);
+    const float* drow = dense ? a.dense + (int64_t)b * a.Lk : nullptr;
+    const int Lkp = (a.Lk + 511) & ~511;
+    float mx = -INFINITY;
+    auto score = [&](int k, const uint4& kr) {  // all 8 lanes of a row end with the row's score
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&kr);
+        float sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc = fmaf(qv[j], (FUSED && k == pos) ? sk[ch * 8 + j] : bf2f(e[j]), sc);
+        sc += __shfl_xor(sc, 1, 64);
+        sc += __shfl_xor(sc, 2, 64);
+        sc += __shfl_xor(sc, 4, 64);
+        if (k < a.Lk) {
+            const bool vis = ((k >= lo1) & (k < hi1)) | ((k >= lo2) & (k < hi2));
+            if (dense) sc += drow[k];
+            sc = vis ? sc : -INFINITY;
+            if (ch == 0) sp[k] = sc;
+            mx = fmaxf(mx, sc);
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+        if ((it * 16 + wave) * 8 < a.Lk) score((it * 16 + wave) * 8 + r8, ku[it]);
+    for (int g = 128 + wave; g * 8 < a.Lk; g += 16) {
+        const int k = g * 8 + r8;
+        const uint4 kr = (k < a.Lk && k != pos) ? *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+        score(k, kr);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+    const float mu = (mx == -INFINITY) ? 0.f : mx;
+    float sum = 0.f;
+    for (int k = tid; k < Lkp; k += 1024) {
+        float p = 0.f;
+        if (k < a.Lk) {
+            p = __builtin_amdgcn_exp2f((sp[k] - mu) * LOG2E);
+            sum += p;
+            p = bf2f(f2bf(p));  // P is rounded to bf16 like the MFMA paths before it multiplies V
+        }
+        sp[k] = p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[16 + wave] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[16 + w];
+    const float inv = 1.0f / tot;
+    // o[d] = sum_k p[k] V^T[d][k]
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    auto accum = [&](int c, const uint4 (&u)[4]) {
+        const int kk = c + 8 * lane;
+        const float4 p0 = *reinterpret_cast<const float4*>(sp + kk);
+        const float4 p1 = *reinterpret_cast<const float4*>(sp + kk + 4);
+        const float pr[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        const int nvalid = a.Lk - kk;  // cache slots beyond Lk hold stale or uninitialised bits: never multiply them
+        const int jn = FUSED ? pos - kk : -1;  // the new token's value comes from LDS (same summation slot as the cached form)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&u[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[i] = fmaf(pr[j], j == jn ? sv[d0 + i] : (j < nvalid ? bf2f(e[j]) : 0.f), o[i]);
+        }
+    };
+    accum(0, vu[0]);
+    if (Lkp > 512) accum(512, vu[1]);
+    for (int c = 1024; c < Lkp; c += 512) {
+        const int kk = c + 8 * lane;
+        uint4 u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = kk < a.Lk ? *reinterpret_cast<const uint4*>(vr + (int64_t)i * a.Lp + kk) : make_uint4(0, 0, 0, 0);
+        accum(c, u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = wave_sum(o[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a.O[(int64_t)b * a.ldo + head * 64 + d0 + i] = f2bf(o[i] * inv);
+    }
+}
+
 // decode-step graph replay (engine-internal): when set, single-token qk_prep / attention launches take the position from
 // device memory, so the captured launch sequence is the same for every token
 static const int* g_decode_pos_dev = nullptr;
@@ -540,6 +712,15 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
     if (g_attn_forced < 0) { const char* e = getenv("SHOWO_ATTN_IMPL"); g_attn_forced = e ? atoi(e) : 0; }
     const int forced = g_attn_forced;  // 1 = gather form, 2 = LDS-tiled form, else by shape
     const bool tiled = lse != nullptr || forced >= 2 || (forced != 1 && Lq >= 64);  // only the tiled form writes lse  // decode steps (a few query rows) keep the gather form
+    if (Lq == 1 && forced != 1 && !lse) {  // AR decode step
+        a.pos_dev = g_decode_pos_dev;
+        const size_t smem = (size_t)(((g_decode_pos_dev ? Lcap : Lk) + 511) & ~511) * sizeof(float);  // graph replay: Lk grows
+        if (smem <= 60000) {
+            attn_decode_kernel<false><<<dim3(nH, B), dim3(1024), smem, (hipStream_t)stream>>>(a, DecPrep{});
+            SHOWO_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (tiled && forced == 3) attn_fwd_lds_kernel<3><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     else if (tiled) attn_fwd_lds_kernel<4><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     else attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
@@ -560,3 +741,23 @@ extern "C" int showo_attn_fwd_lse(const uint16_t* Q, const uint16_t* K, const ui
     if (!lse) return set_error_msg(1, "attn_fwd_lse: lse is required");
     return attn_fwd_impl(Q, K, Vt, iv, flag, dense_mask, O, lse, B, nH, Lq, Lk, Lcap, Lp, ldo, stream);
 }
+
+// Engine-internal: decode-layer attention with the prep of the new token fused in (B = 1).  qkv = the new token's
+// projection row [3 * nH * 64]; K / Vt = this layer's cache (appended at pos); iv int32[4] = the token's mask row.
+namespace showo {
+int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
+                      const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
+                      int Lcap, int Lp, hipStream_t s) {
+    if ((Lp % 64) || Lp <= pos || Lcap <= pos) return set_error_msg(1, "decode attention: bad Lp/Lcap");
+    AttnArgs a;
+    a.Q = nullptr; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = nullptr; a.dense = nullptr; a.O = O;
+    a.B = 1; a.nH = nH; a.Lq = 1; a.Lk = pos + 1; a.Lcap = Lcap; a.Lp = Lp; a.ldo = nH * 64; a.lse = nullptr;
+    a.pos_dev = g_decode_pos_dev;
+    DecPrep f{qkv, qw, qb, kw, kb, cosT, sinT, rot, pos, eps};
+    const size_t smem = (size_t)(((g_decode_pos_dev ? Lcap : pos + 1) + 511) & ~511) * sizeof(float);
+    if (smem > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
+    attn_decode_kernel<true><<<dim3(nH, 1), dim3(1024), smem, s>>>(a, f);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace showo

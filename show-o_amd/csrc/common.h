@@ -54,6 +54,12 @@ __device__ inline int wave_max_i(int v) {
     return v;
 }
 
+__device__ inline float gelu_new_fast(float x) {
+    // gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+
 // direct HBM -> LDS copy, 16 B per lane; the LDS destination is wave-uniform base + lane * 16 (lane-linear image)
 __device__ inline void glds16(const bf16_t* src, bf16_t* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

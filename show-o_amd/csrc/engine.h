@@ -18,6 +18,16 @@ namespace showo {
 void sampler_set_device_step(const int* step_dev, const float* sched, int steps);
 int sampler_step_inc(int* step_dev, hipStream_t s);
 void attn_set_decode_pos(const int* p);
+// fused decode layer (decode.hip, attention.hip)
+bool decode_fused_shapes_ok(int H, int F);
+int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
+                    bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s);
+int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* b0, int K0, const bf16_t* W1, const bf16_t* a1,
+                     const float* b1, int K1, int N, hipStream_t s);
+int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
+                      const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
+                      int Lcap, int Lp, hipStream_t s);
+extern int g_decode_impl;  // 0 = fused decode layer (default), 1 = the seven-launch path (showo_decode_set_impl)
 extern bool g_prof_on_query();
 }  // namespace showo
 

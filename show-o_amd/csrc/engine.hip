@@ -217,6 +217,13 @@ struct KVDest {
     int Lcap, Lp;                  // key rows per head in k, columns per row in vt
 };
 static KVDest kv_workspace(showo_engine* e, int L) { return KVDest{e->K, e->Vt, 0, 0, L, ((L + 63) / 64) * 64}; }
+namespace showo { int g_decode_impl = 0; }
+extern "C" int showo_decode_set_impl(int impl) {
+    if (impl < 0 || impl > 1) return set_error_msg(1, "decode_set_impl: 0 = fused layer, 1 = unfused");
+    showo::g_decode_impl = impl;
+    return 0;
+}
+
 static KVDest kv_decode_cache(showo_engine* e) {
     return KVDest{e->kcache, e->vtcache, (int64_t)e->nH * e->cache_cap * 64, (int64_t)e->nH * 64 * e->cache_cap, e->cache_cap, e->cache_cap};
 }
@@ -227,6 +234,20 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
     const int T = B * L;
     const int Lk = pos0 + L;
     const int Lcap = kv.Lcap, Lp = kv.Lp;
+    if (T == 1 && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
+        // AR decode step: three launches per layer (decode.hip)
+        for (int li = 0; li < e->nL; ++li) {
+            showo::Layer& l = e->layers[li];
+            bf16_t* Kd = kv.k + li * kv.k_lstride;
+            bf16_t* Vd = kv.vt + li * kv.v_lstride;
+            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
+                                       e->ffn, F, s));
+            TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
+                                         e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s));
+        }
+        return 0;
+    }
     for (int li = 0; li < e->nL; ++li) {
         showo::Layer& l = e->layers[li];
         bf16_t* Kd = kv.k + li * kv.k_lstride;
@@ -279,6 +300,9 @@ static int hidden(showo_engine* e, const int64_t* ids, const float* embeds, cons
 
 static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
     if (col0 < 0 || ncols <= 0 || col0 + ncols > e->V) return set_error_msg(1, "engine: bad vocabulary slice");
+    if (nrows == 1 && !rows && showo::g_decode_impl == 0 && showo::decode_fused_shapes_ok(e->H, e->F))  // decode step: LN + lm_head in one launch
+        return showo::decode_ln_gemv2(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, e->H, e->wlm + (int64_t)col0 * e->H, e->blm + col0,
+                                      nullptr, logits, ncols, nullptr, nullptr, nullptr, 0, s);
     TRY(showo_layernorm_f32_bf16(e->x, e->fln_w, e->fln_b, e->hf, rows, nrows, e->H, e->cfg.ln_eps, s));
     return showo_gemm_bf16(e->hf, e->H, e->wlm + (int64_t)col0 * e->H, e->H, e->blm + col0, 0, logits, ncols, nullptr, 0,
                            nrows, ncols, e->H, SHOWO_EPI_F32, s);

@@ -115,11 +115,6 @@ struct ConvLoader {
     __device__ inline uint4 load_lo(int i, int k) const { return load_t<true>(i, k); }
 };
 
-__device__ inline float gelu_new_fast(float x) {
-    // gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
-    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
-}
 
 __device__ inline void load_bias4(const GemmArgs& g, int n, float (&bn)[4]) {
 #pragma unroll

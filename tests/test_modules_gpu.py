@@ -144,6 +144,38 @@ def test_tiny_mmu_generate_matches_reference_tokens():
 
 
 
+def test_fused_decode_layer_equals_unfused_bits():
+    """showo_decode_set_impl: the three-launch decode layer gives the same logits bits and the same KV cache as the general
+    seven-launch layer, step after step (prefill -> 6 decode steps), and so the same greedy tokens"""
+    g = util.golden("showo_tiny_mmu.npz")
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd)
+    lib = util.pkg()._lib
+    eng = m.engine()
+    ids = dev(g["ids"]).to(torch.int64).contiguous()
+    mask = dev(g["mask"]).float().reshape(1, 1, ids.shape[1], ids.shape[1]).contiguous()
+    runs = []
+    try:
+        for impl in (1, 0):
+            lib.call("showo_decode_set_impl", impl)
+            logits = torch.empty((d.vocab,), dtype=torch.float32, device="cuda")
+            lib.call("showo_engine_prefill", eng, lib.ptr(ids), None, lib.ptr(mask), ids.shape[1], lib.ptr(logits), lib.stream())
+            seq = []
+            for _ in range(6):
+                tok = logits.argmax().reshape(1).to(torch.int64)
+                lib.call("showo_engine_decode_step", eng, lib.ptr(tok), None, lib.ptr(logits), lib.stream())
+                torch.cuda.synchronize()
+                seq.append((int(tok), logits.clone()))
+            runs.append(seq)
+    finally:
+        lib.call("showo_decode_set_impl", 0)
+    for (t1, l1), (t0, l0) in zip(*runs):
+        assert t1 == t0
+        assert torch.isfinite(l0).all()
+        assert torch.equal(l1, l0), float((l1 - l0).abs().max())
+    assert [t for t, _ in runs[0]][:len(g["tokens"])] == [int(t) for t in g["tokens"]][:6]
+
+
 def test_full_size_logits_vs_reference_subset():
     """1.45 B-parameter model, [2,387] t2i batch: compare with the reference's own logits (committed subset)."""
     g = util.golden("showo_full_logits_subset.npz")
