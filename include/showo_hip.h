@@ -125,6 +125,16 @@ int showo_mask_predict_next(const int64_t* ids, int B, int L, int64_t pad_id, in
 int showo_mask_mmu(const int64_t* ids, int B, int L, int64_t eoi_id, int32_t* iv, float* dense, void* stream);
 int showo_mask_mmu_vit(int B, int L, int system_prompt_len, int num_image_tokens, int32_t* iv, float* dense, void* stream);
 
+/* MLM corruption of a training batch's image tokens on the device (reference training/utils.py:77-154
+ * mask_or_random_replace_tokens).  Random form: position j of row b is masked iff argsort(noise[b])[j] < num_masked[b]
+ * (the reference's `batch_randperm < num_token_masked`, :101-102).  Contiguous form (rect != NULL, :104-129): rows
+ * [y0,y1) x columns [x0,x1) of the res x res token grid, rect int32 [B,4] = y0,y1,x0,x1.
+ * input_ids = mask_id where masked else the token (:133); labels = the token where masked else ignore_id, or the token
+ * everywhere when predict_all != 0 (:143-151); mask uint8 [B,N] is optional. */
+int showo_mask_tokens(const int64_t* tokens, const float* noise, const int32_t* num_masked, const int32_t* rect, int res, int B, int N,
+                      int64_t mask_id, int64_t ignore_id, int predict_all, int64_t* input_ids, int64_t* labels, uint8_t* mask,
+                      void* stream);
+
 /* Fused omni-attention forward (replaces SDPA + dense additive mask, phi.py:715-722):
  * O[b, l, h*64 + d] bf16 = softmax(Q K^T + M) V.  Q,K,Vt as produced by showo_qk_prep (Q already scaled).
  * iv/flag from showo_mask_compress; dense_mask may be NULL iff *flag is known to be 0.
@@ -344,6 +354,11 @@ int showo_train_create(showo_engine* e, int max_batch, int max_seq, showo_traine
 void showo_train_destroy(showo_trainer* t);
 /* call after showo_engine_load changed weights (optimizer step): the transposed images are rebuilt lazily */
 int showo_train_invalidate_weights(showo_trainer* t);
+/* Training with visibility intervals built on the device (showo_mask_predict_next / showo_mask_mmu; reference
+ * training/train.py:522-577 builds and concatenates dense [B,1,L,L] masks instead): the next showo_train_forward call with
+ * mask == NULL uses iv int32 [B,L,4] for the forward and the backward; iv == NULL restores the causal default. */
+int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv);
+
 /* forward with saved activations.  ids int64 [B,L]; mask [B,1,L,L] fp32 or NULL (causal); labels int64 [B,L] or NULL.
  * logits_out (optional) fp32 [B,L,V]; losses_out (optional, needs labels) fp32 [3] = (loss_t2i, loss_lm, loss_mmu). */
 int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L, int b_t2i,

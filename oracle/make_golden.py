@@ -309,6 +309,87 @@ def make_full_showo():
                         cols=cols, logits=sub, logit_absmax=float(lg.abs().max()), logit_std=float(lg.std()))
 
 
+def make_prompting():
+    """UniversalPrompting layouts + mask_or_random_replace_tokens: the real reference on a stub tokenizer / seeded RNGs."""
+    import json
+    import random
+    from stub_tokenizer import StubTokenizer
+    ref = R.load_reference()
+    tu = R.load_reference_training_utils()
+    out = {}
+    texts = ["a photo of a cat", "", "<bos> already has bos", " ".join(f"w{i}" for i in range(40)), "two words",
+             "x " * 11 + "exactly"]
+    N = 16
+    rs = np.random.RandomState(5)
+    up = ref.prompting.UniversalPrompting(StubTokenizer(), max_text_len=12, max_seq_len=12 + N + 3, cond_dropout_prob=0.5)
+    img = torch.from_numpy(rs.randint(310, 310 + 128, size=(len(texts), N)))
+    lab = torch.where(torch.from_numpy(rs.rand(len(texts), N) < 0.5), img, torch.full_like(img, -100))
+    out["texts"] = np.array(json.dumps(texts))
+    out["image_ids"], out["labels"] = img.numpy(), lab.numpy()
+    out["sptids"] = np.array(json.dumps({k: int(v) for k, v in up.sptids_dict.items()}))
+    out["pad_id"], out["max_text_len"] = up.pad_id, up.max_text_len
+    cfg = ns(training=ns(batch_size=4))
+
+    def put(name, tup):
+        for k, t in zip(("seq", "mask", "lab"), tup):
+            out[f"{name}_{k}"] = t.numpy()
+
+    for task in ("t2i", "t2v", "lvg"):
+        torch.manual_seed(21)
+        put(task, up((list(texts), img, lab), task))
+        out[f"{task}_rng_after"] = torch.rand(3).numpy()  # position of the host generator after the call
+    for task in ("t2i_gen", "t2v_gen", "lvg_gen"):
+        put(task, up((list(texts), img), task))
+    put("lm", up((list(texts), 12 + N + 3), "lm"))
+    put("lm_short", up((list(texts), 9), "lm"))
+    put("mmu", up((img, list(texts)), "mmu"))
+    torch.manual_seed(22)
+    a, b = up((list(texts), img[:4], lab[:4], 31), "t2i_plus_lm", config=cfg)
+    put("plus_t2i", a)
+    put("plus_lm", b)
+
+    # ---- mask_or_random_replace_tokens -------------------------------------------------------------------------
+    class Sec(dict):
+        __getattr__ = dict.__getitem__
+    sched = ref.sampling.cosine_schedule
+    tokens = torch.from_numpy(rs.randint(310, 310 + 128, size=(5, 64)))
+    mask_id = 438
+    real_rand = torch.rand
+    for name, tr, is_train in (("mlm", dict(min_masking_rate=0.0), True),
+                               ("mlm_minrate", dict(min_masking_rate=0.6), True),
+                               ("mlm_all", dict(min_masking_rate=0.0, predict_all_tokens=True), True),
+                               ("mlm_rr", dict(min_masking_rate=0.0, noise_type="random_replace"), True),
+                               ("mlm_rect", dict(min_masking_rate=0.1, mask_contiguous_region_prob=1.0), True),
+                               ("mlm_eval", dict(min_masking_rate=0.0, eval_mask_ratios=[0.25, 0.5, 0.9]), False)):
+        draws = []
+
+        def rec(*a, **k):
+            t = real_rand(*a, **k)
+            draws.append(t.clone())
+            return t
+        torch.manual_seed(31)
+        random.seed(32)
+        torch.rand = rec
+        try:
+            inp, labels, lw, mp = tu.mask_or_random_replace_tokens(tokens, mask_id, ns(training=Sec(tr), model=ns(codebook_size=128)),
+                                                                   sched, is_train=is_train)
+        finally:
+            torch.rand = real_rand
+        out[f"{name}_in"], out[f"{name}_lab"], out[f"{name}_prob"] = inp.numpy(), labels.numpy(), mp.numpy()
+        if lw is not None:
+            out[f"{name}_lw"] = lw.numpy()
+        for i, dr in enumerate(draws):
+            out[f"{name}_draw{i}"] = dr.numpy()
+        if name in ("mlm", "mlm_minrate", "mlm_all", "mlm_rr"):
+            i2, l2, m2 = O.mask_tokens_np(tokens.numpy(), draws[1].numpy(), mp.numpy(), mask_id, predict_all=lw is not None)
+            assert np.array_equal(i2, inp.numpy()) and np.array_equal(l2, labels.numpy()), name
+            if lw is not None:
+                assert np.allclose(O.loss_weight_np(mp.numpy(), m2), lw.numpy(), atol=1e-7)
+    out["mlm_tokens"], out["mlm_mask_id"] = tokens.numpy(), mask_id
+    np.savez_compressed(os.path.join(GOLD, "prompting.npz"), **out)
+    print("prompting.npz:", len(out), "arrays; oracle restatement == reference on the 4 random-permutation cases")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
@@ -320,6 +401,8 @@ if __name__ == "__main__":
         make_tiny_showo()
     if a.only in ("", "magvit"):
         make_magvit()
+    if a.only in ("", "prompting"):
+        make_prompting()
     if a.full or a.only == "full":
         make_full_showo()
     print("done")

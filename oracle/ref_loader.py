@@ -149,6 +149,24 @@ def load_reference():
     return types.SimpleNamespace(**_REF)
 
 
+def load_reference_training_utils():
+    """the reference's training/utils.py (mask_or_random_replace_tokens, get_loss_weight); torchvision is absent offline and
+    only used by its image transforms, so it is stubbed"""
+    load_reference()
+    if "train_utils" in _REF:
+        return _REF["train_utils"]
+    for name in ("torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = _mod(name)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    import importlib.util as _ilu
+    spec = _ilu.spec_from_file_location("ref_training_utils", os.path.join(REF_ROOT, "training", "utils.py"))
+    tu = _ilu.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    _REF["train_utils"] = tu
+    return tu
+
+
 def build_reference_showo(phi_overrides=None, vocab_size=58498, llm_vocab_size=50295, codebook_size=8192,
                           num_vq_tokens=256, w_clip_vit=False, seed=0):
     """Seeded random-init reference Showo (no pretrained weights are available offline)."""

@@ -240,6 +240,27 @@ class RecordedNoise:
         return u.reshape(like.shape)
 
 
+# MLM corruption of the image tokens of a training batch (training/utils.py:77-154, random-permutation branch)
+def mask_tokens_np(tokens, noise, mask_prob, mask_id, predict_all=False, ignore_id=-100):
+    """tokens int64 [B,N]; noise fp32 [B,N] (= the reference's torch.rand(B, N)); mask_prob fp32 [B] (after the schedule and
+    the min_masking_rate clip).  num_masked = round_half_even(N * p) clamped to >= 1 (:92); perm = argsort(noise) (:101);
+    mask = perm < num_masked (:102); input = mask_id where masked (:133); labels = token where masked else -100 (:150)."""
+    tokens = np.asarray(tokens)
+    B, N = tokens.shape
+    num = np.maximum(np.rint(np.float32(N) * np.asarray(mask_prob, np.float32)), 1).astype(np.int64)
+    perm = np.argsort(np.asarray(noise, np.float32), axis=-1, kind="stable")
+    mask = perm < num[:, None]
+    inp = np.where(mask, mask_id, tokens)
+    lab = tokens.copy() if predict_all else np.where(mask, tokens, ignore_id)
+    return inp, lab, mask
+
+
+def loss_weight_np(t, mask, min_val=0.3):
+    """get_loss_weight (training/utils.py:73-74)"""
+    t = np.asarray(t, np.float32)
+    return 1 - (1 - mask.astype(np.int64)) * ((1 - t) * np.float32(1 - min_val))[:, None]
+
+
 def mask_by_random_topk(mask_len, probs, temperature, uniform):
     """models/sampling.py:31-36 with the uniform draw made explicit."""
     g = -torch.log((-torch.log(uniform.clamp(min=1e-20))).clamp(min=1e-20))

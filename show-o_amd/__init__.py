@@ -11,3 +11,6 @@ from .modeling_magvitv2 import MAGVITv2  # noqa: F401
 from . import _lib  # noqa: F401
 from .training import Trainer  # noqa: F401
 from . import prompting_utils  # noqa: F401
+from . import training_utils  # noqa: F401
+from .prompting_utils import UniversalPrompting  # noqa: F401
+from .training_utils import mask_or_random_replace_tokens  # noqa: F401

@@ -152,6 +152,54 @@ __global__ void dense_from_intervals_kernel(const int32_t* __restrict__ iv, floa
     mask[i] = ((c >= v.x && c < v.y) || (c >= v.z && c < v.w)) ? 0.0f : neg;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MLM corruption of the image tokens of a training batch (training/utils.py:77-154 mask_or_random_replace_tokens).
+// The reference draws noise = rand(B, N), takes perm = argsort(noise) and masks position j iff perm[j] < n_b: position
+// rank(i) is masked for every i < n_b, where rank(i) = #{j : noise[j] < noise[i]} (ties by index).  One block per row;
+// only the first n_b elements need their rank, so the work is n_b * N compares out of LDS.
+// rect != NULL selects the contiguous-region form instead (rows [y0,y1) x cols [x0,x1) of the res x res grid).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ noise,
+                                                          const int32_t* __restrict__ num_masked, const int32_t* __restrict__ rect,
+                                                          int res, int N, int64_t mask_id, int64_t ignore_id, int predict_all,
+                                                          int64_t* __restrict__ input_ids, int64_t* __restrict__ labels,
+                                                          uint8_t* __restrict__ mask) {
+    extern __shared__ float sn[];                            // [N] noise row
+    uint8_t* flags = reinterpret_cast<uint8_t*>(sn + N);     // [N]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < N; j += 256) flags[j] = 0;
+    if (rect) {
+        __syncthreads();
+        const int y0 = rect[b * 4 + 0], y1 = rect[b * 4 + 1], x0 = rect[b * 4 + 2], x1 = rect[b * 4 + 3];
+        for (int j = tid; j < N; j += 256) {
+            const int y = j / res, x = j - y * res;
+            flags[j] = (y >= y0 && y < y1 && x >= x0 && x < x1) ? 1 : 0;
+        }
+    } else {
+        for (int j = tid; j < N; j += 256) sn[j] = noise[(int64_t)b * N + j];
+        __syncthreads();
+        const int n = min(num_masked[b], N);
+        for (int i = tid; i < n; i += 256) {
+            const float v = sn[i];
+            int rank = 0;
+            for (int j = 0; j < N; ++j) {
+                const float w = sn[j];
+                rank += (w < v) | ((w == v) & (j < i));
+            }
+            flags[rank] = 1;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {
+        const int64_t t = tokens[(int64_t)b * N + j];
+        const bool m = flags[j] != 0;
+        input_ids[(int64_t)b * N + j] = m ? mask_id : t;
+        labels[(int64_t)b * N + j] = (m || predict_all) ? t : ignore_id;
+        if (mask) mask[(int64_t)b * N + j] = m ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 static const float NEG_MASK = -9223372036854775808.0f;  // float(torch.iinfo(torch.int64).min), prompting_utils.py:505-509
@@ -198,6 +246,23 @@ extern "C" int showo_mask_mmu_vit(int B, int L, int system_prompt_len, int num_i
         const int64_t n = (int64_t)total * L;
         dense_from_intervals_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(iv, dense, L, n, NEG_MASK);
     }
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// tokens int64 [B,N]; noise fp32 [B,N] and num_masked int32 [B] (random form) or rect int32 [B,4] = y0,y1,x0,x1 on the
+// res x res grid (contiguous form; noise / num_masked unused); out: input_ids, labels int64 [B,N], mask uint8 [B,N] (optional)
+extern "C" int showo_mask_tokens(const int64_t* tokens, const float* noise, const int32_t* num_masked, const int32_t* rect, int res,
+                                 int B, int N, int64_t mask_id, int64_t ignore_id, int predict_all, int64_t* input_ids,
+                                 int64_t* labels, uint8_t* mask, void* stream) {
+    if (B <= 0 || N <= 0) return 0;
+    if (!tokens || !input_ids || !labels) return set_error_msg(1, "mask_tokens: tokens, input_ids and labels are required");
+    if (!rect && (!noise || !num_masked)) return set_error_msg(1, "mask_tokens: noise and num_masked (or rect) are required");
+    if (rect && (res <= 0 || res * res != N)) return set_error_msg(1, "mask_tokens: contiguous form needs N = res * res");
+    if (N > 12000) return set_error_msg(5, "mask_tokens: row longer than the LDS-resident kernel supports");
+    const size_t smem = (size_t)N * sizeof(float) + (size_t)N;
+    mask_tokens_kernel<<<dim3(B), dim3(256), smem, (hipStream_t)stream>>>(tokens, noise, num_masked, rect, res, N, mask_id, ignore_id,
+                                                                         predict_all, input_ids, labels, mask);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

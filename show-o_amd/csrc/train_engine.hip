@@ -215,6 +215,15 @@ static int sync_weights(showo_trainer* t, hipStream_t s) {
     return 0;
 }
 
+// Visibility intervals built on the device (showo_mask_predict_next / _mmu) instead of a dense mask: the next
+// showo_train_forward call that passes mask == NULL attends (forward and backward) with iv int32 [B,L,4]; NULL restores causal.
+extern "C" int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv) {
+    if (!t) return set_error_msg(1, "trainer: null handle");
+    t->e->ext_iv = iv;
+    t->e->ext_flag = nullptr;
+    return 0;
+}
+
 extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L,
                                    int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out,
                                    void* stream) {
@@ -232,6 +241,11 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
     const int32_t *iv = nullptr, *flag = nullptr;
     if (mask) {
         TRY(showo_mask_compress(mask, e->iv, e->flag, B, L, L, s));
+        iv = e->iv; flag = e->flag;
+    } else if (e->ext_iv) {
+        // caller-built visibility intervals (showo_trainer_use_intervals): kept in the engine's own buffer for the backward
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->iv, e->ext_iv, (size_t)T * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, sizeof(int32_t), s));
         iv = e->iv; flag = e->flag;
     }
     for (int i = 0; i < e->nL; ++i) {
@@ -253,7 +267,7 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
     if (logits_out) SHOWO_CHECK_HIP(hipMemcpyAsync(logits_out, t->logits, (size_t)T * V * sizeof(float), hipMemcpyDeviceToDevice, s));
     t->B = B; t->Lq = L;
     t->have_fwd = true;
-    t->has_mask = mask != nullptr;
+    t->has_mask = iv != nullptr;
     if (labels) {
         TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, 0.f, 0.f, 0.f, t->ce_rows, t->counts,
                           t->rowloss, nullptr, 0, t->losses, s));

@@ -119,15 +119,17 @@ class _ShowoTrainFn(torch.autograd.Function):
         B, L = input_ids.shape
         ids = input_ids.to(torch.int64).contiguous()
         lab = labels.to(torch.int64).contiguous()
-        mask = None
-        if attention_mask is not None:
-            if tuple(attention_mask.shape) != (B, 1, L, L):
-                raise ValueError(f"Attention mask should be of size {(B, 1, L, L)}, but is {tuple(attention_mask.shape)}")
-            mask = attention_mask.detach().float().contiguous()
+        if attention_mask is not None and tuple(attention_mask.shape) != (B, 1, L, L):
+            raise ValueError(f"Attention mask should be of size {(B, 1, L, L)}, but is {tuple(attention_mask.shape)}")
+        from .training import train_mask
+        mask = train_mask(tr, attention_mask)  # dense fp32 mask, or an IntervalMask registered with the trainer
         logits = torch.empty((B, L, model.vocab_size), dtype=torch.float32, device=ids.device)
         losses = torch.empty(3, dtype=torch.float32, device=ids.device)
-        _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
-                  max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
+        try:
+            _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
+                      max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
+        finally:
+            _lib.call("showo_trainer_use_intervals", tr, None)
         ctx.model, ctx.lab, ctx.meta = model, lab, (b_t2i, b_lm, b_mmu, max_seq_length)
         ctx.names = ["showo." + n for n, _ in model.showo.named_parameters()]
         ctx.shapes = [tuple(p.shape) for p in params]

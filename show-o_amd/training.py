@@ -42,6 +42,19 @@ def average_buckets(buckets, group=None, async_op=True):
     return buckets
 
 
+def train_mask(tr, attention_mask):
+    """dense additive [B,1,L,L] mask -> contiguous fp32 tensor; IntervalMask (prompting_utils.intervals_* /
+    training_utils.build_training_batch) -> registered with the trainer, returns None (no dense mask is passed)"""
+    from .prompting_utils import IntervalMask
+    if attention_mask is None:
+        return None
+    if isinstance(attention_mask, IntervalMask):
+        attention_mask.check()
+        _lib.call("showo_trainer_use_intervals", tr, _lib.ptr(attention_mask.iv.contiguous()))
+        return None
+    return attention_mask.detach().float().contiguous()
+
+
 class Trainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0), group=None):
         self.model, self.lr, self.betas, self.eps, self.wd, self.coeffs, self.group = model, lr, betas, eps, weight_decay, coeffs, group
@@ -73,10 +86,13 @@ class Trainer:
         B, L = input_ids.shape
         ids = input_ids.to(torch.int64).contiguous()
         lab = labels.to(torch.int64).contiguous()
-        mask = None if attention_mask is None else attention_mask.detach().float().contiguous()
+        mask = train_mask(tr, attention_mask)
         losses = torch.empty(3, dtype=torch.float32, device=ids.device)
-        _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
-                  batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
+        try:
+            _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
+                      batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
+        finally:
+            _lib.call("showo_trainer_use_intervals", tr, None)
         works = []
         nL = m.arch["num_hidden_layers"]
         _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,

@@ -81,3 +81,70 @@ def test_schedule_constants_match_reference_golden():
     for name in ("linear", "pow2", "sigmoid"):
         f = S.get_mask_chedule(name)
         assert 0.0 <= float(f(torch.tensor(0.3))) <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# UniversalPrompting: sequence layouts against the real reference (fixture made by oracle/make_golden.py with the stub
+# tokenizer of oracle/stub_tokenizer.py)
+# ---------------------------------------------------------------------------------------------------------------
+def _prompting_fixture():
+    import json
+    from stub_tokenizer import StubTokenizer
+    g = util.golden("prompting.npz")
+    N = g["image_ids"].shape[1]
+    up = util.pkg().UniversalPrompting(StubTokenizer(), max_text_len=12, max_seq_len=12 + N + 3, cond_dropout_prob=0.5)
+    texts = json.loads(str(g["texts"]))
+    return g, up, texts, torch.from_numpy(g["image_ids"]), torch.from_numpy(g["labels"])
+
+
+def _same(g, name, tup):
+    for k, t in zip(("seq", "mask", "lab"), tup):
+        ref = g[f"{name}_{k}"]
+        assert tuple(t.shape) == ref.shape, (name, k, tuple(t.shape), ref.shape)
+        assert t.dtype == torch.int64 and np.array_equal(t.numpy(), ref), (name, k)
+
+
+def test_universal_prompting_special_ids_and_attributes():
+    import json
+    g, up, *_ = _prompting_fixture()
+    assert {k: int(v) for k, v in up.sptids_dict.items()} == json.loads(str(g["sptids"]))
+    assert up.pad_id == int(g["pad_id"]) and up.max_text_len == int(g["max_text_len"]) == 13
+    assert up.ignore_id == -100 and up.cond_dropout_prob == 0.5
+
+
+@pytest.mark.parametrize("task", ["t2i", "t2v", "lvg"])
+def test_universal_prompting_training_layouts_with_condition_dropout(task):
+    g, up, texts, img, lab = _prompting_fixture()
+    torch.manual_seed(21)
+    _same(g, task, up((list(texts), img, lab), task))
+    # the host generator is left exactly where the reference leaves it (one rand(B) per call, two for lvg)
+    assert np.array_equal(torch.rand(3).numpy(), g[f"{task}_rng_after"])
+
+
+def test_universal_prompting_generation_lm_mmu_layouts():
+    g, up, texts, img, lab = _prompting_fixture()
+    N = img.shape[1]
+    for task in ("t2i_gen", "t2v_gen", "lvg_gen"):
+        _same(g, task, up((list(texts), img), task))
+    _same(g, "lm", up((list(texts), 12 + N + 3), "lm"))
+    _same(g, "lm_short", up((list(texts), 9), "lm"))  # longer texts are cut WITHOUT re-adding <eos>
+    _same(g, "mmu", up((img, list(texts)), "mmu"))
+    torch.manual_seed(22)
+    cfg = type("C", (), {"training": type("T", (), {"batch_size": 4})})
+    a, b = up((list(texts), img[:4], lab[:4], 31), "t2i_plus_lm", config=cfg)
+    _same(g, "plus_t2i", a)
+    _same(g, "plus_lm", b)
+    with pytest.raises(NotImplementedError):
+        up((texts, img), "no_such_task")
+
+
+def test_universal_prompting_edge_cases():
+    g, up, texts, img, lab = _prompting_fixture()
+    bos, eos = up.text_tokenizer.bos_token_id, up.text_tokenizer.eos_token_id
+    seq, _ = up.t2i_gen_prompt([[]], img[:1])           # empty prompt -> [pad.. t2i bos eos]
+    assert seq[0, :13].tolist() == [up.pad_id] * 10 + [int(up.sptids_dict['<|t2i|>']), bos, eos]
+    ids = [[5] * 40]
+    seq, _ = up.t2i_gen_prompt(ids, img[:1])            # too long -> first window-1 ids, then <eos>; bos added in place
+    assert ids[0][0] == bos and seq[0, 12] == eos and seq[0, 0] == int(up.sptids_dict['<|t2i|>'])
+    assert seq.shape[1] == 13 + 1 + img.shape[1] + 1
+    assert seq[0, 13] == int(up.sptids_dict['<|soi|>']) and seq[0, -1] == int(up.sptids_dict['<|eoi|>'])
