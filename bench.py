@@ -28,6 +28,7 @@ def log(msg):
 
 
 def build_inputs(d, B, O):
+    """inputs of the CPU-baseline leg only (oracle mask builder; the measured GPU leg builds its own through the product)"""
     rs = np.random.RandomState(0)
     rows_c, rows_u = [], []
     for i in range(B):
@@ -64,10 +65,13 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(d, O, budget_s=30.0):
+def cpu_baseline(budget_s=30.0):
     """oracle (CPU restatement of the reference, fp32) on a bounded sample: denoise steps of ONE prompt with CFG
-    ([2,387] forward + sampling per step) are timed until ~budget_s of CPU work is spent, then scaled to 18 steps."""
+    ([2,387] forward + sampling per step) are timed until ~budget_s of CPU work is spent, then scaled to 18 steps.
+    The ONLY place in this file that touches oracle/."""
+    import showo_oracle as O
     import weights as Wt
+    d = Wt.ShowoDims()
     threads = _pick_threads()
     # same architecture, random init on the host (timing does not depend on the values); ~5.8 GB fp32
     g = torch.Generator().manual_seed(0)
@@ -131,31 +135,20 @@ def main():
 
     log(f"rank {rank}/{world} start")
     import showo_amd
-    import showo_oracle as O
-    import weights as Wt
+    from showo_amd import synthetic
     L = showo_amd._lib
-    d = Wt.ShowoDims()
     B = a.batch
+    N, codebook = synthetic.SHOWO_DEMO["num_vq_tokens"], synthetic.SHOWO_DEMO["codebook_size"]
     # random-init weights of the true architecture (no checkpoints offline): generated on the GPU, N(0, 0.02)
     torch.manual_seed(0)
-    with torch.device("meta"):
-        model = showo_amd.Showo(False, d.vocab, d.llm_vocab, codebook_size=d.codebook, num_vq_tokens=d.num_vq_tokens,
-                                max_batch=2 * B, max_seq=387)
-    model = model.to_empty(device="cuda").eval()
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if "layernorm" in n and n.endswith("weight"):
-                p.normal_(1.0, 0.1)
-            elif "layernorm" in n or n.endswith("bias"):
-                p.normal_(0.0, 0.02)
-            else:
-                p.normal_(0.0, 0.02)  # Phi init (reference models/phi.py:833-842)
+    model = synthetic.random_init_showo(max_batch=2 * B, max_seq=387, ln_jitter=True).eval()
     log("showo params on GPU")
     vq = showo_amd.MAGVITv2(max_batch=B, max_res=256).cuda().eval()
     log("vq params on GPU")
     cfg = showo_amd.gen_config()
-    ic, iu, mask = build_inputs(d, B, O)
-    ic_d, iu_d, mask_d = ic.cuda(), iu.cuda(), mask.cuda()
+    uni = synthetic.prompting(max_text_len=128)
+    ic_d, iu_d, mask_d = synthetic.t2i_inputs(uni, B, N, model.mask_token_id)  # prompts -> ids -> omni mask, as inference_t2i.py does
+    assert tuple(ic_d.shape) == (B, 387) and tuple(mask_d.shape) == (2 * B, 1, 387, 387)
     log("inputs built")
     gen = torch.Generator(device="cuda").manual_seed(1 + rank)
 
@@ -163,7 +156,7 @@ def main():
         ids = ic_d.clone()
         toks = model.t2i_generate(input_ids=ids, uncond_input_ids=iu_d, attention_mask=mask_d, temperature=1.0, timesteps=18,
                                   guidance_scale=5.0, generator=gen, config=cfg, use_graph=a.graph, reuse_prefix=not a.no_prefix_reuse)
-        toks = torch.clamp(toks, max=d.codebook - 1, min=0)
+        toks = torch.clamp(toks, max=codebook - 1, min=0)
         return vq.decode_code(toks)
 
     img = None
@@ -207,6 +200,15 @@ def main():
     if rank == 0:
         value = images / dt
         peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+        # HBM bytes per GEMM launch: PMC counters cannot be read from inside this process; they come from the separate
+        # rocprofv3 --pmc passes over this same command (scripts/gpu_pmc.sh -> profiles/pmc/bench_traffic.json)
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc", "bench_traffic.json")))
+            traffic = tj["gemm2p_kernel"]["bytes_per_launch"]
+            traffic_src = f"profiles/pmc/bench_traffic.json ({tj['tag']}: {tj['corrections']})"
+        except (OSError, KeyError, TypeError, ValueError):
+            pass
         ach = fl_gemm.value / (ms_gemm.value * 1e-3) / 1e12 if ms_gemm.value > 0 else 0.0
         out = {
             "metric": "t2i images/sec @256x256 (18 denoise steps)", "value": value, "unit": "images/s", "n_gpus": world,
@@ -217,7 +219,8 @@ def main():
                        "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
                        "algorithmic_tflop_per_image": 38.4, "end_to_end_algorithmic_tflops": value * 38.4},
             "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM, all epilogues: fused-QKV / dense / fc1+GELU / fc2 / lm_head rows)",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic_src,
                          "launches": int(n_all.value), "timed_launches": int(n_gemm.value),
                          "avg_launch_ms": ms_gemm.value / max(1, n_gemm.value),
                          "time_share_of_step": (fl_all.value / max(1e-9, ach * 1e12)) / dt if ach > 0 else None,
@@ -227,7 +230,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             del model, vq
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(d, O)
+            out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

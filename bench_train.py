@@ -1,54 +1,30 @@
 """bench_train.py — stage-1 training step time (BASELINE.json configs[4]: configs/showo_pretraining_stage1.yaml): per GPU
 15 t2i + 4 lm + 10 mmu sequences of 387 tokens, forward + backward + gradient exchange + AdamW on the HIP path, plus
-the frozen MAGVIT-v2 encode of the 25 images of the batch.  One process per GPU (torchrun); data parallel, weak scaling.
+the frozen MAGVIT-v2 encode of the 25 images of the batch and the on-device batch construction (MLM corruption, sequence
+layouts, omni-mask intervals).  One process per GPU (torchrun); data parallel, weak scaling.
 Prints ONE JSON line (rank 0).  `python bench.py --workload train ...` forwards here."""
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def build_batch(d, O, rs, b_t2i=15, b_lm=4, b_mmu=10):
-    """synthetic stage-1 batch: ids, labels, mask; image tokens are random codes here (the VQ encode of
-    the synthetic images is timed separately in the step, its ids do not change the arithmetic)"""
-    N, off = d.num_vq_tokens, d.image_offset
-    L = 129 + 1 + N + 1
-    ids, labels = [], []
-    for i in range(b_t2i):
-        k = 5 + (i * 5) % 36
-        text = [d.t2i_id, 50256] + rs.randint(0, 50256, size=k - 3).tolist() + [50256]
-        if rs.rand() < 0.1:
-            text = [d.t2i_id, 50256, 50256]  # condition dropout (prompting_utils.py:56-57)
-            k = 3
-        gt = rs.randint(0, d.codebook, size=N) + off
-        ratio = max(np.cos(np.pi / 2 * rs.rand()), 1.0 / N)
-        masked = rs.rand(N) < ratio
-        img = np.where(masked, d.mask_token_id, gt)
-        row = [d.pad_id] * (129 - k) + text + [d.soi_id] + img.tolist() + [d.eoi_id]
-        lab = [-100] * 130 + np.where(masked, gt, -100).tolist() + [-100]
-        ids.append(row); labels.append(lab)
-    for i in range(b_lm):
-        row = rs.randint(0, 50256, size=L).tolist()
-        ids.append(row); labels.append(list(row))
-    for i in range(b_mmu):
-        q = rs.randint(0, 50256, size=127).tolist()
-        row = [d.mmu_id, d.soi_id] + (rs.randint(0, d.codebook, size=N) + off).tolist() + [d.eoi_id, 50256] + q
-        lab = [-100] * (N + 3) + [50256] + q
-        ids.append(row[:L]); labels.append(lab[:L])
-    ids, labels = torch.tensor(ids), torch.tensor(labels)
-    m_t = O.mask_t2i(ids[:b_t2i], d.pad_id, d.soi_id, d.eoi_id)
-    m_l = O.mask_t2i(ids[b_t2i:b_t2i + b_lm], d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False)
-    m_u = O.mask_mmu(ids[b_t2i + b_lm:], d.eoi_id)
-    return ids, labels, torch.cat([m_t, m_l, m_u])
+def synthetic_texts(rs, b_t2i, b_lm, b_mmu):
+    """captions of 2..37 words, LM documents longer than the sequence (cut to 387 ids by lm_prompt), 126-word answers"""
+    from showo_amd.synthetic import random_text
+    t2i = [random_text(rs, 2 + (i * 5) % 36) for i in range(b_t2i)]
+    lm = [random_text(rs, 400) for _ in range(b_lm)]
+    mmu = [random_text(rs, 126) for _ in range(b_mmu)]
+    return t2i, lm, mmu
 
 
 def main(argv=None):
@@ -66,34 +42,33 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import showo_amd
-    import showo_oracle as O
-    import weights as Wt
-    d = Wt.ShowoDims()
+    from showo_amd import synthetic
+    from showo_amd.training_utils import build_training_batch
     bt, bl, bm = 15, 4, 10
     torch.manual_seed(0)  # same initial weights on every rank (data parallel replicas)
-    with torch.device("meta"):
-        model = showo_amd.Showo(False, d.vocab, d.llm_vocab, codebook_size=d.codebook, num_vq_tokens=d.num_vq_tokens,
-                                max_batch=bt + bl + bm, max_seq=387)
-    model = model.to_empty(device="cuda").train()
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if "layernorm" in n and n.endswith("weight"):
-                p.fill_(1.0)
-            elif n.endswith("bias"):
-                p.zero_()
-            else:
-                p.normal_(0.0, 0.02)
+    model = synthetic.random_init_showo(max_batch=bt + bl + bm, max_seq=387).train()
     trainer = showo_amd.Trainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0))
     vq = None if a.no_vq else showo_amd.MAGVITv2(max_batch=bt + bm, max_res=256).cuda().eval()
+    uni = synthetic.prompting(max_text_len=128, cond_dropout_prob=0.1)
+    off = len(uni.text_tokenizer)  # image-token offset (training/train.py:476)
+    N, codebook = synthetic.SHOWO_DEMO["num_vq_tokens"], synthetic.SHOWO_DEMO["codebook_size"]
+    cfg = type("Cfg", (), {"training": type("Training", (dict,), {"__getattr__": dict.__getitem__})(min_masking_rate=0.0)})
     rs = np.random.RandomState(4 + rank)  # every rank draws its own batch
-    ids, labels, mask = build_batch(d, O, rs, bt, bl, bm)
-    ids, labels, mask = ids.cuda(), labels.cuda(), mask.cuda()
+    torch.manual_seed(4 + rank)
+    random.seed(4 + rank)
+    texts_t2i, texts_lm, texts_mmu = synthetic_texts(rs, bt, bl, bm)
     images = torch.rand(bt + bm, 3, 256, 256, device="cuda") * 2 - 1
+    fixed_codes = torch.randint(0, codebook, (bt + bm, N), device="cuda")  # --no-vq: the tokenizer is left out of the step
 
     def step():
-        if vq is not None:
-            vq.get_code(images)  # frozen tokenizer: 25 images per step (training/train.py:547,573)
-        return trainer.step(ids, mask, labels, bt, bl, bm, 128)
+        # the body of training/train.py:510-628: frozen tokenizer on the 25 images, MLM corruption + sequence layout + omni
+        # mask intervals on the device, forward, backward with overlapped gradient exchange, AdamW
+        codes = vq.get_code(images) if vq is not None else fixed_codes
+        tokens = codes + off
+        ids, labels, mask, _, (b1, b2, b3) = build_training_batch(uni, cfg, model.mask_token_id, showo_amd.cosine_schedule,
+                                                                  tokens[:bt], list(texts_t2i), list(texts_lm), tokens[bt:],
+                                                                  list(texts_mmu))
+        return trainer.step(ids, mask, labels, b1, b2, b3, 128)
 
     def barrier():
         torch.cuda.synchronize()

@@ -356,11 +356,15 @@ void showo_train_destroy(showo_trainer* t);
 int showo_train_invalidate_weights(showo_trainer* t);
 /* Training with visibility intervals built on the device (showo_mask_predict_next / showo_mask_mmu; reference
  * training/train.py:522-577 builds and concatenates dense [B,1,L,L] masks instead): the next showo_train_forward call with
- * mask == NULL uses iv int32 [B,L,4] for the forward and the backward; iv == NULL restores the causal default. */
-int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv);
+ * mask == NULL uses iv int32 [B,L,4] for the forward and the backward; iv == NULL restores the causal default.
+ * flag (optional int32[1], as written by showo_mask_predict_next): when non-zero the intervals cannot represent the mask
+ * and the three losses of that forward are returned as NaN (device-side check, no host synchronisation). */
+int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv, const int32_t* flag);
 
 /* forward with saved activations.  ids int64 [B,L]; mask [B,1,L,L] fp32 or NULL (causal); labels int64 [B,L] or NULL.
- * logits_out (optional) fp32 [B,L,V]; losses_out (optional, needs labels) fp32 [3] = (loss_t2i, loss_lm, loss_mmu). */
+ * logits_out (optional) fp32 [B,L,V]; losses_out (optional, needs labels) fp32 [3] = (loss_t2i, loss_lm, loss_mmu).
+ * Masks must be interval-representable (at most two visibility runs per row: every mask the reference builds with
+ * contiguous padding is); otherwise the three losses come back as NaN. */
 int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L, int b_t2i,
                         int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out, void* stream);
 /* gradients of g_t2i*loss_t2i + g_lm*loss_lm + g_mmu*loss_mmu of the last forward w.r.t. every parameter */

@@ -52,7 +52,7 @@ _PROTOS = {
     "showo_gelu_bf16": [c_p, c_p, c_i64, c_p],
     "showo_train_create": [c_p, c_i, c_i, c_p],
     "showo_train_invalidate_weights": [c_p],
-    "showo_trainer_use_intervals": [c_p, c_p],
+    "showo_trainer_use_intervals": [c_p, c_p, c_p],
     "showo_train_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "showo_train_backward": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
     "showo_train_backward_head": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],

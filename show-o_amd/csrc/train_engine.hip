@@ -217,12 +217,20 @@ static int sync_weights(showo_trainer* t, hipStream_t s) {
 
 // Visibility intervals built on the device (showo_mask_predict_next / _mmu) instead of a dense mask: the next
 // showo_train_forward call that passes mask == NULL attends (forward and backward) with iv int32 [B,L,4]; NULL restores causal.
-extern "C" int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv) {
+// flag (optional, int32[1] written by the interval builders): non-zero = some row needs more than two visibility runs, the
+// intervals do not describe the mask; checked on the device, without a host sync: the three losses come back as NaN.
+extern "C" int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv, const int32_t* flag) {
     if (!t) return set_error_msg(1, "trainer: null handle");
     t->e->ext_iv = iv;
-    t->e->ext_flag = nullptr;
+    t->e->ext_flag = iv ? flag : nullptr;
     return 0;
 }
+
+namespace {
+__global__ void poison_losses_kernel(float* __restrict__ losses, const int32_t* __restrict__ flag) {
+    if (threadIdx.x < 3 && *flag != 0) losses[threadIdx.x] = __builtin_nanf("");
+}
+}  // namespace
 
 extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L,
                                    int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out,
@@ -245,7 +253,8 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
     } else if (e->ext_iv) {
         // caller-built visibility intervals (showo_trainer_use_intervals): kept in the engine's own buffer for the backward
         SHOWO_CHECK_HIP(hipMemcpyAsync(e->iv, e->ext_iv, (size_t)T * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, sizeof(int32_t), s));
+        if (e->ext_flag) SHOWO_CHECK_HIP(hipMemcpyAsync(e->flag, e->ext_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        else SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, sizeof(int32_t), s));
         iv = e->iv; flag = e->flag;
     }
     for (int i = 0; i < e->nL; ++i) {
@@ -271,6 +280,9 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
     if (labels) {
         TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, 0.f, 0.f, 0.f, t->ce_rows, t->counts,
                           t->rowloss, nullptr, 0, t->losses, s));
+        // the backward works on the interval form only: a mask with more than two visibility runs in a row (never produced by
+        // the reference's builders with contiguous padding) must not train silently wrong -> NaN losses, no host sync
+        if (iv) poison_losses_kernel<<<1, 64, 0, s>>>(t->losses, e->flag);
         if (losses_out) SHOWO_CHECK_HIP(hipMemcpyAsync(losses_out, t->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return 0;

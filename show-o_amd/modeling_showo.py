@@ -129,7 +129,7 @@ class _ShowoTrainFn(torch.autograd.Function):
             _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
                       max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
         finally:
-            _lib.call("showo_trainer_use_intervals", tr, None)
+            _lib.call("showo_trainer_use_intervals", tr, None, None)
         ctx.model, ctx.lab, ctx.meta = model, lab, (b_t2i, b_lm, b_mmu, max_seq_length)
         ctx.names = ["showo." + n for n, _ in model.showo.named_parameters()]
         ctx.shapes = [tuple(p.shape) for p in params]

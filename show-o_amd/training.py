@@ -49,8 +49,8 @@ def train_mask(tr, attention_mask):
     if attention_mask is None:
         return None
     if isinstance(attention_mask, IntervalMask):
-        attention_mask.check()
-        _lib.call("showo_trainer_use_intervals", tr, _lib.ptr(attention_mask.iv.contiguous()))
+        # no host-side check(): a mask the intervals cannot represent turns the losses into NaN on the device
+        _lib.call("showo_trainer_use_intervals", tr, _lib.ptr(attention_mask.iv.contiguous()), _lib.ptr(attention_mask.flag))
         return None
     return attention_mask.detach().float().contiguous()
 
@@ -92,7 +92,7 @@ class Trainer:
             _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
                       batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
         finally:
-            _lib.call("showo_trainer_use_intervals", tr, None)
+            _lib.call("showo_trainer_use_intervals", tr, None, None)
         works = []
         nL = m.arch["num_hidden_layers"]
         _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,

@@ -142,3 +142,37 @@ def test_build_training_batch_intervals_drive_the_training_step_like_dense_refer
     tr = P.Trainer(m)
     losses = tr.step(ids, mask, labels, b1, b2, b3, d.max_text_len)
     assert torch.isfinite(losses).all()
+
+
+def test_trainer_poisons_losses_when_intervals_cannot_represent_the_mask():
+    """pads scattered inside the caption need three visibility runs per row: the builder raises its flag, and a training
+    forward driven by those intervals returns NaN losses (device-side check, no host sync) instead of silently wrong ones"""
+    P = util.pkg()
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd).train()
+    L = d.max_text_len + 1 + 1 + d.num_vq_tokens + 1
+    ids = torch.randint(0, 200, (2, L), device="cuda")
+    ids[:, d.max_text_len + 1] = d.soi_id
+    ids[:, -1] = d.eoi_id
+    ids[0, 1] = d.pad_id
+    ids[0, 3] = d.pad_id
+    labels = ids.clone()
+    mask = P.prompting_utils.intervals_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id, rm_pad_in_image=True)
+    assert int(mask.flag[0]) != 0
+    with pytest.raises(ValueError):
+        mask.check()
+    _, l1, l2, l3 = m(ids, attention_mask=mask, labels=labels, batch_size_t2i=2, batch_size_lm=0, batch_size_mmu=0,
+                      max_seq_length=d.max_text_len)
+    assert torch.isnan(l1)
+    dense = P.prompting_utils.create_attention_mask_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id,
+                                                                 rm_pad_in_image=True)
+    _, l1, l2, l3 = m(ids, attention_mask=dense, labels=labels, batch_size_t2i=2, batch_size_lm=0, batch_size_mmu=0,
+                      max_seq_length=d.max_text_len)
+    assert torch.isnan(l1)  # same for the dense form of such a mask: the interval backward could not honour it
+    ok = ids.clone()
+    ok[0, 1], ok[0, 3] = 7, 8
+    dense = P.prompting_utils.create_attention_mask_predict_next(ok, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id,
+                                                                 rm_pad_in_image=True)
+    _, l1, l2, l3 = m(ok, attention_mask=dense, labels=labels, batch_size_t2i=2, batch_size_lm=0, batch_size_mmu=0,
+                      max_seq_length=d.max_text_len)
+    assert torch.isfinite(l1)
