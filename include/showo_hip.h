@@ -321,6 +321,14 @@ int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* em
  * use_graph: capture one step (position and mask row live in device memory) into a hipGraph and replay it. */
 int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws, int use_graph,
                                void* stream);
+/* Next-token draw of the AR decode (modeling_showo.py:220-228): x = logits / temperature; values below the top_k-th largest
+ * are dropped (top_k <= 0 or >= V: none); token = multinomial(softmax(x), 1) computed as argmax_i p_i / E_i, E ~ Exp(1):
+ * E = exp_noise[step * V + i] when exp_noise != NULL (parity tests inject the reference's draws), else Philox(seed; step, i). */
+int showo_sample_topk(const float* logits, int V, int top_k, float temperature, const float* exp_noise, uint64_t seed, int step,
+                      int64_t* tok, void* stream);
+/* showo_engine_decode_greedy with that draw instead of the arg-max; draw j of the call uses noise row / stream step0 + j. */
+int showo_engine_decode_sample(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws, int top_k,
+                               float temperature, const float* exp_noise, uint64_t seed, int step0, int use_graph, void* stream);
 /* greedy/top-k=1 pick on device: out int64[1] = argmax(logits) (first maximal index, like torch.topk/multinomial on a one-hot). */
 int showo_argmax_f32(const float* x, int n, int64_t* out, void* stream);
 

@@ -237,8 +237,35 @@ def make_tiny_showo():
     toks_o = O.mmu_generate(sd, d, ids_m.clone(), attention_mask=mask_m.float().clone(), max_new_tokens=6, top_k=1)
     assert [int(t) for t in toks] == [int(t) for t in toks_o], (toks, toks_o)
     print("  tokens", [int(t) for t in toks])
+    # stochastic decode (top_k / temperature / multinomial, modeling_showo.py:220-228) with the reference's own Exp(1) draws
+    real_multinomial = torch.multinomial
+    extra = {}
+    for tag, kw in (("topk5", dict(top_k=5, temperature=0.7)), ("full", dict(top_k=None, temperature=1.3))):
+        draws = []
+
+        def rec_multinomial(p, num_samples=1, **k2):
+            st = torch.get_rng_state()
+            q = torch.empty_like(p).exponential_(1)
+            mine = torch.argmax(p / q, dim=-1, keepdim=True)
+            torch.set_rng_state(st)
+            res = real_multinomial(p, num_samples, **k2)
+            assert torch.equal(res, mine), "torch.multinomial != argmax(p/Exp(1))"
+            draws.append(q[0].clone())
+            return res
+        torch.manual_seed(41)
+        torch.multinomial = rec_multinomial
+        try:
+            toks_s = ref.mmu_generate(ids_m.clone(), attention_mask=mask_m.clone(), max_new_tokens=8, **kw)
+        finally:
+            torch.multinomial = real_multinomial
+        noise = O.RecordedNoise(list(draws), [])
+        toks_so = O.mmu_generate(sd, d, ids_m.clone(), attention_mask=mask_m.float().clone(), max_new_tokens=8, noise=noise, **kw)
+        assert [int(t) for t in toks_s] == [int(t) for t in toks_so], (tag, toks_s, toks_so)
+        print(f"  {tag} tokens", [int(t) for t in toks_s])
+        extra[f"tokens_{tag}"] = np.array([int(t) for t in toks_s])
+        extra[f"exp_noise_{tag}"] = torch.stack(draws).numpy()
     np.savez_compressed(os.path.join(GOLD, "showo_tiny_mmu.npz"), ids=ids_m.numpy(),
-                        mask=mask_m.numpy().astype(np.float32), tokens=np.array([int(t) for t in toks]))
+                        mask=mask_m.numpy().astype(np.float32), tokens=np.array([int(t) for t in toks]), **extra)
 
 
 def make_magvit():

@@ -101,6 +101,8 @@ _PROTOS = {
     "showo_engine_prefill": [c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "showo_engine_decode_step": [c_p, c_p, c_p, c_p, c_p],
     "showo_engine_decode_greedy": [c_p, c_p, c_i, c_p, c_p, c_i, c_p],
+    "showo_sample_topk": [c_p, c_i, c_i, c_f, c_p, c_u64, c_i, c_p, c_p],
+    "showo_engine_decode_sample": [c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_p, c_u64, c_i, c_i, c_p],
     "showo_vq_create": [c_p, C.POINTER(c_p)],
     "showo_vq_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_vq_missing": [c_p],

@@ -18,6 +18,8 @@ namespace showo {
 void sampler_set_device_step(const int* step_dev, const float* sched, int steps);
 int sampler_step_inc(int* step_dev, hipStream_t s);
 void attn_set_decode_pos(const int* p);
+int sample_topk_launch(const float* logits, int V, int top_k, float temperature, const float* exp_noise, int64_t noise_stride,
+                       uint64_t seed, int step, const int* pos_dev, int pos_base, int64_t* tok, hipStream_t s);
 // fused decode layer (decode.hip, attention.hip)
 bool decode_fused_shapes_ok(int H, int F);
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,

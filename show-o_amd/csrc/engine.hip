@@ -538,11 +538,13 @@ extern "C" int showo_engine_use_intervals(showo_engine* e, const int32_t* iv, co
     return 0;
 }
 
-// Greedy (top_k = 1) continuation: n_steps times { embed(tok) -> 24 layers against the KV cache -> lm_head -> arg-max -> tok },
-// the position and the mask row living in device memory so that ONE step can be captured into a hipGraph and replayed.
+// Continuation loop: n_steps times { embed(tok) -> 24 layers against the KV cache -> lm_head -> next token -> tok }, the
+// position and the mask row living in device memory so that ONE step can be captured into a hipGraph and replayed.
 // tok int64[1] (device): in = the token to feed first, out = the last token produced; out_tokens int64 [n_steps] (device).
-extern "C" int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws,
-                                          int use_graph, void* stream) {
+// top_k == 1: arg-max (the reference caller's setting); otherwise temperature / top-k / multinomial on the device
+// (showo_sample_topk semantics; draw j of this call uses noise row / Philox stream step0 + j).
+static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws, int top_k,
+                       float temperature, const float* exp_noise, uint64_t seed, int step0, int use_graph, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!e || e->cache_len <= 0) return set_error_msg(1, "decode_greedy: prefill first");
     if (!tok || !out_tokens || !logits_ws || n_steps < 1) return set_error_msg(1, "decode_greedy: bad arguments");
@@ -566,7 +568,9 @@ extern "C" int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_s
         // host-side P only sizes nothing here (grids depend on L = 1); the kernels read the position from pos_dev
         TRY(run_layers(e, 1, 1, P0, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
         TRY(head_rows(e, nullptr, 1, 0, e->V, logits_ws, s));
-        TRY(showo_argmax_f32(logits_ws, e->V, tok, s));
+        if (top_k == 1) TRY(showo_argmax_f32(logits_ws, e->V, tok, s));
+        else TRY(showo::sample_topk_launch(logits_ws, e->V, top_k, temperature, exp_noise, (int64_t)e->V, seed, step0, e->pos_dev, P0,
+                                           tok, s));
         store_token_kernel<<<1, 64, 0, s>>>(tok, out_tokens, e->pos_dev, P0);
         return showo::sampler_step_inc(e->pos_dev, s);
     };
@@ -600,4 +604,16 @@ extern "C" int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_s
     if (rc) return rc;
     e->cache_len = P0 + n_steps;
     return 0;
+}
+
+extern "C" int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws,
+                                          int use_graph, void* stream) {
+    return decode_loop(e, tok, n_steps, out_tokens, logits_ws, 1, 1.0f, nullptr, 0, 0, use_graph, stream);
+}
+
+extern "C" int showo_engine_decode_sample(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws,
+                                          int top_k, float temperature, const float* exp_noise, uint64_t seed, int step0,
+                                          int use_graph, void* stream) {
+    if (!(temperature > 0.f)) return set_error_msg(1, "decode_sample: temperature must be > 0");
+    return decode_loop(e, tok, n_steps, out_tokens, logits_ws, top_k, temperature, exp_noise, seed, step0, use_graph, stream);
 }

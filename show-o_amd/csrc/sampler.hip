@@ -249,3 +249,148 @@ extern "C" int showo_mask_by_topk(const float* sel_prob, const int64_t* sampled,
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Next-token sampling of the AR decode (modeling_showo.py:220-228): x = logits / temperature; keep x >= (top_k-th
+// largest x) (`logits[logits < v[:, [-1]]] = -inf`: ties with the k-th value stay); p = softmax(x); token =
+// multinomial(p, 1) = argmax_i p_i / E_i with E ~ Exp(1) (asserted against torch in oracle/make_golden.py).
+// One 1024-thread block; the vocabulary row (58 498 fp32 = 234 KB) stays in L2 and is re-read per pass: four 8-bit
+// radix-select passes over an order-preserving key find the exact k-th largest value, then max, sum and the arg-max.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct DecSampleArgs {
+    const float* logits;
+    int V, top_k;
+    float temperature;
+    const float* exp_noise;   // optional [*, V]: row `step` is used (parity tests); else Philox(seed; step)
+    int64_t noise_stride;
+    uint64_t seed;
+    int step;                 // index of this draw within the generation ...
+    const int* pos_dev;       // ... or step + (*pos_dev - pos_base) when the position lives on the device (graph replay)
+    int pos_base;
+    int64_t* tok;
+};
+__device__ inline uint32_t order_key(float x) {  // ascending float order -> ascending unsigned order
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(1024) void sample_topk_kernel(DecSampleArgs a) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel[2];
+    __shared__ float red_f[16];
+    __shared__ int red_i[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int step = a.step + (a.pos_dev ? *a.pos_dev - a.pos_base : 0);
+    const float T = a.temperature;
+    uint32_t thr = 0;  // keep keys >= thr
+    if (a.top_k > 0 && a.top_k < a.V) {
+        uint32_t prefix = 0, mask = 0;
+        unsigned k = (unsigned)a.top_k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < a.V; i += 1024) {
+                const uint32_t key = order_key(__fdiv_rn(a.logits[i], T));
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0;
+                int b = 255;
+                for (; b > 0; --b) {
+                    if (cum + hist[b] >= k) break;
+                    cum += hist[b];
+                }
+                sel[0] = (unsigned)b;
+                sel[1] = k - cum;  // rank of the wanted element inside bin b
+            }
+            __syncthreads();
+            prefix |= sel[0] << shift;
+            mask |= 255u << shift;
+            k = sel[1];
+            __syncthreads();
+        }
+        thr = prefix;
+    }
+    // max of the kept values
+    float mx = -INFINITY;
+    for (int i = tid; i < a.V; i += 1024) {
+        const float x = __fdiv_rn(a.logits[i], T);
+        if (order_key(x) >= thr) mx = fmaxf(mx, x);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red_f[w]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < a.V; i += 1024) {
+        const float x = __fdiv_rn(a.logits[i], T);
+        if (order_key(x) >= thr) sum += expf(x - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red_f[wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+    for (int w = 0; w < 16; ++w) sum += red_f[w];
+    __syncthreads();
+    Philox ph(a.seed);
+    const float* en = a.exp_noise ? a.exp_noise + (int64_t)step * a.noise_stride : nullptr;
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int i0 = tid * 4; i0 < a.V; i0 += 4096) {
+        float e4[4];
+        if (en) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e4[j] = (i0 + j < a.V) ? en[i0 + j] : 1.f;
+        } else {
+            uint32_t r4[4];
+            ph.gen((uint32_t)(i0 >> 2), 0u, (uint32_t)step, 0x77u, r4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e4[j] = -logf(u32_to_unit(r4[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j;
+            if (i < a.V) {
+                const float x = __fdiv_rn(a.logits[i], T);
+                if (order_key(x) >= thr) {
+                    const float sc = __fdiv_rn(__fdiv_rn(expf(x - mx), sum), e4[j]);
+                    if (sc > best || (sc == best && i < bi)) { best = sc; bi = i; }
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { red_f[wave] = best; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (red_f[w] > best || (red_f[w] == best && red_i[w] < bi)) { best = red_f[w]; bi = red_i[w]; }
+        a.tok[0] = bi;
+    }
+}
+}  // namespace
+
+namespace showo {
+int sample_topk_launch(const float* logits, int V, int top_k, float temperature, const float* exp_noise, int64_t noise_stride,
+                       uint64_t seed, int step, const int* pos_dev, int pos_base, int64_t* tok, hipStream_t s) {
+    if (!logits || !tok || V <= 0) return set_error_msg(1, "sample_topk: bad arguments");
+    if (!(temperature > 0.f)) return set_error_msg(1, "sample_topk: temperature must be > 0");
+    DecSampleArgs a{logits, V, top_k, temperature, exp_noise, noise_stride, seed, step, pos_dev, pos_base, tok};
+    sample_topk_kernel<<<dim3(1), dim3(1024), 0, s>>>(a);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+}  // namespace showo
+
+extern "C" int showo_sample_topk(const float* logits, int V, int top_k, float temperature, const float* exp_noise, uint64_t seed,
+                                 int step, int64_t* tok, void* stream) {
+    return showo::sample_topk_launch(logits, V, top_k, temperature, exp_noise, (int64_t)V, seed, step, nullptr, 0, tok,
+                                     (hipStream_t)stream);
+}

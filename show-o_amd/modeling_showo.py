@@ -384,11 +384,22 @@ class Showo(nn.Module):
     # ---- Showo.mmu_generate (reference models/modeling_showo.py:183-240) -----------------------------------
     @torch.no_grad()
     def mmu_generate(self, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, temperature=1.0,
-                     top_k=None, eot_token=None):
+                     top_k=None, eot_token=None, generator=None, _exp_noise=None):
+        """reference signature + `generator` (seeds the on-device Philox stream of the multinomial draws; default: torch's
+        global generator) and `_exp_noise` fp32 [max_new_tokens, vocab] (parity tests inject the reference's Exp(1) draws)"""
         eng = self.engine()
-        if top_k != 1:
-            raise NotImplementedError("mmu_generate on the HIP path implements the reference caller's setting top_k=1 "
-                                      "(inference_mmu.py:81); stochastic decode lands in a later round")
+        greedy = top_k == 1  # the reference caller's setting (inference_mmu.py:81): multinomial of a one-hot = arg-max
+        if not greedy:
+            if not temperature > 0:
+                raise ValueError("temperature must be > 0")
+            k = 0 if top_k is None else int(top_k)
+            if generator is not None:
+                seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
+            else:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            noise = None if _exp_noise is None else _exp_noise.detach().float().contiguous()
+            if noise is not None and tuple(noise.shape) != (max_new_tokens, self.vocab_size):
+                raise ValueError("_exp_noise must be [max_new_tokens, vocab_size]")
         dev = idx.device if idx is not None else input_embeddings.device
         if input_embeddings is not None:
             if input_embeddings.shape[0] != 1:
@@ -410,7 +421,11 @@ class Showo(nn.Module):
         # deterministic arg-max.  The first token comes from the prefill logits; the continuation runs in
         # chunks of `chunk` steps entirely on the device (embed -> 24 layers on the KV cache -> lm_head -> arg-max), one
         # hipGraph replay per step, and the host looks at the tokens (for <eot>) once per chunk.
-        _lib.call("showo_argmax_f32", _lib.ptr(logits), self.vocab_size, _lib.ptr(tok), _lib.stream())
+        if greedy:
+            _lib.call("showo_argmax_f32", _lib.ptr(logits), self.vocab_size, _lib.ptr(tok), _lib.stream())
+        else:  # logits / temperature -> top-k filter -> softmax -> multinomial (reference :220-228), one kernel
+            _lib.call("showo_sample_topk", _lib.ptr(logits), self.vocab_size, k, float(temperature), _lib.ptr(noise), seed, 0,
+                      _lib.ptr(tok), _lib.stream())
         first = int(tok.item())
         result = [torch.tensor(first, device=dev)]
         if (eot_token is not None and first == eot_token) or max_new_tokens <= 1:
@@ -425,7 +440,12 @@ class Showo(nn.Module):
             outc = torch.empty((n,), dtype=torch.int64, device=dev)
             self._graph_stream.wait_stream(cur)
             with torch.cuda.stream(self._graph_stream):
-                _lib.call("showo_engine_decode_greedy", eng, _lib.ptr(tok), n, _lib.ptr(outc), _lib.ptr(logits), use_graph, _lib.stream())
+                if greedy:
+                    _lib.call("showo_engine_decode_greedy", eng, _lib.ptr(tok), n, _lib.ptr(outc), _lib.ptr(logits), use_graph,
+                              _lib.stream())
+                else:
+                    _lib.call("showo_engine_decode_sample", eng, _lib.ptr(tok), n, _lib.ptr(outc), _lib.ptr(logits), k,
+                              float(temperature), _lib.ptr(noise), seed, max_new_tokens - remaining, use_graph, _lib.stream())
             cur.wait_stream(self._graph_stream)
             toks = outc.tolist()
             for t in toks:

@@ -612,3 +612,56 @@ def test_split_gemm_and_conv_track_fp32():
                 ref = ref + res.double()
             err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
             assert err < 3e-5, (B, H, Wd, Cin, Cout, mode, err)
+
+
+# --------------------------------------------------------------------------------------------- AR decode sampler
+def _topk_reference(logits, top_k, temperature, e):
+    """modeling_showo.py:220-228 with multinomial(p, 1) realised as argmax(p / E) (fp32, CPU)"""
+    lg = logits[None].clone() / temperature
+    if top_k is not None:
+        v, _ = torch.topk(lg, min(top_k, lg.size(-1)))
+        lg[lg < v[:, [-1]]] = -float("inf")
+    p = torch.softmax(lg, dim=-1)
+    return int(torch.argmax(p / e[None], dim=-1)), p[0]
+
+
+@pytest.mark.parametrize("V", [439, 58498])
+def test_sample_topk_with_injected_noise_equals_reference_expression(V):
+    torch.manual_seed(V)
+    tok = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for top_k, T in ((None, 1.0), (1, 1.0), (5, 0.7), (50, 1.3), (V, 0.9), (V + 7, 1.0), (3, 2.0)):
+        for rep in range(3):
+            logits = torch.randn(V) * 3
+            if rep == 2:  # ties at the k-th value: the reference keeps every entry equal to it
+                logits = (logits * 2).round() / 2
+            e = torch.empty(V).exponential_(1)
+            want, p = _topk_reference(logits, top_k, T, e)
+            L().call("showo_sample_topk", L().ptr(dev(logits)), V, 0 if top_k is None else top_k, T, L().ptr(dev(e)), 0, 0, L().ptr(tok), S())
+            got = int(tok.item())
+            if got != want:  # only acceptable as an fp32 near-tie of p/E between the two candidates
+                a, b = float(p[got] / e[got]), float(p[want] / e[want])
+                assert p[got] > 0 and abs(a - b) <= 1e-5 * abs(b), (top_k, T, rep, got, want)
+    # row `step` of a noise matrix is used
+    logits = torch.randn(V)
+    E = torch.empty(3, V).exponential_(1)
+    for step in range(3):
+        L().call("showo_sample_topk", L().ptr(dev(logits)), V, 7, 1.0, L().ptr(dev(E)), 0, step, L().ptr(tok), S())
+        assert int(tok.item()) == _topk_reference(logits, 7, 1.0, E[step])[0]
+
+
+def test_sample_topk_philox_distribution_and_support():
+    """chi-square of the on-device draws against softmax over the top-k support; nothing outside the support is ever drawn"""
+    torch.manual_seed(1)
+    V, k, n = 64, 6, 6000
+    logits = torch.randn(V) * 2
+    ld = dev(logits)
+    toks = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for i in range(n):
+        L().call("showo_sample_topk", L().ptr(ld), V, k, 0.8, None, 99, i, toks.data_ptr() + 8 * i, S())
+    lg = logits / 0.8
+    keep = lg >= torch.topk(lg, k).values[-1]
+    p = torch.where(keep, lg, torch.tensor(-float("inf"))).softmax(-1).double()
+    cnt = torch.bincount(toks.cpu(), minlength=V).double()
+    assert cnt[~keep].sum() == 0
+    chi2 = float((((cnt - n * p) ** 2)[keep] / (n * p[keep])).sum())
+    assert chi2 < 40.0, chi2  # dof = 5; P(chi2 > 40) ~ 1e-7

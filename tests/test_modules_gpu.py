@@ -144,6 +144,28 @@ def test_tiny_mmu_generate_matches_reference_tokens():
 
 
 
+def test_tiny_mmu_generate_stochastic_matches_reference_with_its_noise():
+    """top_k / temperature / multinomial decode (modeling_showo.py:220-228): with the reference's recorded Exp(1) draws injected
+    the HIP path produces the reference's tokens, eager and as hipGraph replay; without them it is reproducible per seed"""
+    g = util.golden("showo_tiny_mmu.npz")
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd)
+    for tag, kw in (("topk5", dict(top_k=5, temperature=0.7)), ("full", dict(top_k=None, temperature=1.3))):
+        for graph in (0, 1):
+            m.decode_graph = graph
+            toks = m.mmu_generate(dev(g["ids"]), attention_mask=dev(g["mask"]), max_new_tokens=8, _exp_noise=dev(g[f"exp_noise_{tag}"]), **kw)
+            got = [int(t) for t in toks]
+            print(f"[parity] tiny mmu_generate {tag} graph={graph}", got, "reference", g[f"tokens_{tag}"].tolist())
+            assert got == g[f"tokens_{tag}"].tolist()
+    runs = []
+    for seed in (5, 5, 6):
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        runs.append([int(t) for t in m.mmu_generate(dev(g["ids"]), attention_mask=dev(g["mask"]), max_new_tokens=24, top_k=20,
+                                                    temperature=1.0, generator=gen)])
+    assert runs[0] == runs[1] and runs[0] != runs[2] and len(runs[0]) == 24
+    assert all(0 <= t < d.vocab for t in runs[0])
+
+
 def test_fused_decode_layer_equals_unfused_bits():
     """showo_decode_set_impl: the three-launch decode layer gives the same logits bits and the same KV cache as the general
     seven-launch layer, step after step (prefill -> 6 decode steps), and so the same greedy tokens"""
