@@ -375,6 +375,12 @@ int showo_trainer_use_intervals(showo_trainer* t, const int32_t* iv, const int32
  * contiguous padding is); otherwise the three losses come back as NaN. */
 int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L, int b_t2i,
                         int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out, void* stream);
+/* the same from caller-provided input embeddings fp32 [B,L,H] (reference modeling_showo.py:77-78 `inputs_embeds`; the w_clip_vit
+ * training flow, training/train_w_clip_vit.py:530-613); after the backward, showo_train_input_grad returns
+ * d(weighted loss)/d(embeds) fp32 [B*L*H] so that the caller's autograd graph (embed_tokens, mm_projector) can continue. */
+int showo_train_forward_embeds(showo_trainer* t, const float* embeds, const float* mask, const int64_t* labels, int B, int L,
+                               int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out, void* stream);
+int showo_train_input_grad(showo_trainer* t, float* out, int64_t n, void* stream);
 /* gradients of g_t2i*loss_t2i + g_lm*loss_lm + g_mmu*loss_mmu of the last forward w.r.t. every parameter */
 int showo_train_backward(showo_trainer* t, const int64_t* labels, int b_t2i, int b_lm, int b_mmu, int max_seq_len, float g_t2i,
                          float g_lm, float g_mmu, void* stream);

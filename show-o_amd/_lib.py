@@ -54,6 +54,8 @@ _PROTOS = {
     "showo_train_invalidate_weights": [c_p],
     "showo_trainer_use_intervals": [c_p, c_p, c_p],
     "showo_train_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "showo_train_forward_embeds": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "showo_train_input_grad": [c_p, c_p, c_i64, c_p],
     "showo_train_backward": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
     "showo_train_backward_head": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
     "showo_train_backward_layer": [c_p, c_i, c_p],

@@ -61,6 +61,7 @@ struct showo_trainer {
     int B = 0, Lq = 0;
     bool have_fwd = false;
     bool has_mask = false;
+    bool from_embeds = false;  // last forward started from caller-provided embeddings: d(loss)/d(embeddings) = dy
     bool weights_synced = false;
 
     template <class T>
@@ -232,11 +233,11 @@ __global__ void poison_losses_kernel(float* __restrict__ losses, const int32_t* 
 }
 }  // namespace
 
-extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L,
-                                   int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out,
-                                   void* stream) {
+static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float* embeds, const float* mask, const int64_t* labels,
+                              int B, int L, int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out,
+                              void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!t || !ids) return set_error_msg(1, "train_forward: null argument");
+    if (!t || ((ids == nullptr) == (embeds == nullptr))) return set_error_msg(1, "train_forward: exactly one of ids / embeds");
     showo_engine* e = t->e;
     if (showo_engine_missing(e) != 0) return set_error_msg(4, "train: weights missing");
     if (B > t->maxB || L > t->maxL || (int64_t)B * L > t->Tmax) return set_error_msg(5, "train: batch exceeds the trainer workspace");
@@ -244,8 +245,13 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
     TRY(sync_weights(t, s));
     const int H = e->H, F = e->F, V = e->V, nH = e->nH, T = B * L;
     const int Lp = ((L + 63) / 64) * 64;
-    SHOWO_CHECK_HIP(hipMemcpyAsync(t->ids, ids, (size_t)T * 8, hipMemcpyDeviceToDevice, s));
-    TRY(showo_embed_f32(ids, e->embed, e->x, T, H, V, s));
+    if (ids) {
+        SHOWO_CHECK_HIP(hipMemcpyAsync(t->ids, ids, (size_t)T * 8, hipMemcpyDeviceToDevice, s));
+        TRY(showo_embed_f32(ids, e->embed, e->x, T, H, V, s));
+    } else {  // inputs_embeds path (modeling_showo.py:77-78, phi.py:1005-1006): the residual stream starts from the caller's rows
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->x, embeds, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    t->from_embeds = ids == nullptr;
     const int32_t *iv = nullptr, *flag = nullptr;
     if (mask) {
         TRY(showo_mask_compress(mask, e->iv, e->flag, B, L, L, s));
@@ -285,6 +291,24 @@ extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const f
         if (iv) poison_losses_kernel<<<1, 64, 0, s>>>(t->losses, e->flag);
         if (losses_out) SHOWO_CHECK_HIP(hipMemcpyAsync(losses_out, t->losses, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
+    return 0;
+}
+
+extern "C" int showo_train_forward(showo_trainer* t, const int64_t* ids, const float* mask, const int64_t* labels, int B, int L,
+                                   int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out, float* losses_out,
+                                   void* stream) {
+    return train_forward_impl(t, ids, nullptr, mask, labels, B, L, b_t2i, b_lm, b_mmu, max_seq_len, logits_out, losses_out, stream);
+}
+extern "C" int showo_train_forward_embeds(showo_trainer* t, const float* embeds, const float* mask, const int64_t* labels, int B,
+                                          int L, int b_t2i, int b_lm, int b_mmu, int max_seq_len, float* logits_out,
+                                          float* losses_out, void* stream) {
+    return train_forward_impl(t, nullptr, embeds, mask, labels, B, L, b_t2i, b_lm, b_mmu, max_seq_len, logits_out, losses_out, stream);
+}
+// d(weighted loss) / d(input embeddings) fp32 [B*L, H] of the last backward (the residual-stream gradient at block 0's input)
+extern "C" int showo_train_input_grad(showo_trainer* t, float* out, int64_t n, void* stream) {
+    if (!t || !out || !t->have_fwd) return set_error_msg(1, "train_input_grad: run forward + backward first");
+    if (n != (int64_t)t->B * t->Lq * t->e->H) return set_error_msg(1, "train_input_grad: size mismatch");
+    SHOWO_CHECK_HIP(hipMemcpyAsync(out, t->dy, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 
@@ -356,6 +380,7 @@ extern "C" int showo_train_backward_embed(showo_trainer* t, void* stream) {
     BW_PROLOGUE
     // ---- embedding
     SHOWO_CHECK_HIP(hipMemsetAsync(t->gembed, 0, (size_t)V * H * sizeof(float), s));
+    if (t->from_embeds) return 0;  // the table was not read by this forward; its caller owns d/d(embeddings) (showo_train_input_grad)
     TRY(showo_embed_bwd(t->ids, t->dy, t->gembed, t->order_ws, T, H, V, s));
     return 0;
 }

@@ -114,23 +114,31 @@ class _ShowoTrainFn(torch.autograd.Function):
     and hands the parameter gradients (reference names and shapes) back to autograd."""
 
     @staticmethod
-    def forward(ctx, model, input_ids, attention_mask, labels, b_t2i, b_lm, b_mmu, max_seq_length, *params):
+    def forward(ctx, model, input_ids, input_embeddings, attention_mask, labels, b_t2i, b_lm, b_mmu, max_seq_length, *params):
         tr = model.trainer()
-        B, L = input_ids.shape
-        ids = input_ids.to(torch.int64).contiguous()
         lab = labels.to(torch.int64).contiguous()
+        B, L = lab.shape
         if attention_mask is not None and tuple(attention_mask.shape) != (B, 1, L, L):
             raise ValueError(f"Attention mask should be of size {(B, 1, L, L)}, but is {tuple(attention_mask.shape)}")
         from .training import train_mask
         mask = train_mask(tr, attention_mask)  # dense fp32 mask, or an IntervalMask registered with the trainer
-        logits = torch.empty((B, L, model.vocab_size), dtype=torch.float32, device=ids.device)
-        losses = torch.empty(3, dtype=torch.float32, device=ids.device)
+        logits = torch.empty((B, L, model.vocab_size), dtype=torch.float32, device=lab.device)
+        losses = torch.empty(3, dtype=torch.float32, device=lab.device)
         try:
-            _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
-                      max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
+            if input_embeddings is None:
+                ids = input_ids.to(torch.int64).contiguous()
+                _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
+                          max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
+            else:  # `inputs_embeds` flow of the w_clip_vit trainer (reference modeling_showo.py:77-78)
+                emb = input_embeddings.detach().float().contiguous()
+                if tuple(emb.shape) != (B, L, model.arch["hidden_size"]):
+                    raise ValueError(f"input_embeddings should be {(B, L, model.arch['hidden_size'])}, got {tuple(emb.shape)}")
+                _lib.call("showo_train_forward_embeds", tr, _lib.ptr(emb), _lib.ptr(mask), _lib.ptr(lab), B, L, b_t2i, b_lm, b_mmu,
+                          max_seq_length, _lib.ptr(logits), _lib.ptr(losses), _lib.stream())
         finally:
             _lib.call("showo_trainer_use_intervals", tr, None, None)
         ctx.model, ctx.lab, ctx.meta = model, lab, (b_t2i, b_lm, b_mmu, max_seq_length)
+        ctx.emb_shape = None if input_embeddings is None else (tuple(input_embeddings.shape), input_embeddings.dtype)
         ctx.names = ["showo." + n for n, _ in model.showo.named_parameters()]
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.mark_non_differentiable(logits)
@@ -147,7 +155,12 @@ class _ShowoTrainFn(torch.autograd.Function):
             t = torch.empty(shape, dtype=torch.float32, device=ctx.lab.device)
             _lib.call("showo_train_grad_copy", model._trainer, name.encode(), _lib.ptr(t), t.numel(), _lib.stream())
             grads.append(t)
-        return (None,) * 8 + tuple(grads)
+        g_emb = None
+        if ctx.emb_shape is not None and ctx.needs_input_grad[2]:
+            g_emb = torch.empty(ctx.emb_shape[0], dtype=torch.float32, device=ctx.lab.device)
+            _lib.call("showo_train_input_grad", model._trainer, _lib.ptr(g_emb), g_emb.numel(), _lib.stream())
+            g_emb = g_emb.to(ctx.emb_shape[1])
+        return (None, None, g_emb) + (None,) * 6 + tuple(grads)
 
 
 class Showo(nn.Module):
@@ -301,11 +314,9 @@ class Showo(nn.Module):
                 batch_size_t2i=0, batch_size_lm=0, batch_size_mmu=0, max_seq_length=128, labels_mask_text=None,
                 labels_mask_image=None, **kwargs):
         if labels is not None:
-            if input_embeddings is not None:
-                raise NotImplementedError("training from input_embeddings (w_clip_vit) is not on the HIP path yet")
             params = [p for _, p in self.showo.named_parameters()]
-            return _ShowoTrainFn.apply(self, input_ids, attention_mask, labels, int(batch_size_t2i), int(batch_size_lm),
-                                       int(batch_size_mmu), int(max_seq_length), *params)
+            return _ShowoTrainFn.apply(self, input_ids, input_embeddings, attention_mask, labels, int(batch_size_t2i),
+                                       int(batch_size_lm), int(batch_size_mmu), int(max_seq_length), *params)
         eng = self.engine()
         if input_embeddings is None:
             B, L = input_ids.shape

@@ -324,3 +324,36 @@ def test_trainer_step_matches_autograd_plus_torch_adamw():
     for _ in range(5):
         losses = tr.step(ids, mask, labels, 2, 1, 2, d.max_text_len)
     assert float(losses.sum()) < first
+
+
+def test_training_from_input_embeddings_equals_training_from_ids():
+    """`Showo.forward(input_embeddings=..., labels=...)` (the w_clip_vit trainer's flow, reference modeling_showo.py:77-78,
+    training/train_w_clip_vit.py:599-613): same losses / logits / block gradients as the id path, bit for bit, and the gradient
+    handed back for the embeddings, pushed through torch's embedding lookup, reproduces the id path's embedding-table gradient
+    (hence the reference's, which the id path is checked against)"""
+    g = util.golden("showo_tiny_forward.npz")
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd).train()
+    ids, mask, labels = dev(g["train_ids"]), dev(g["train_mask"]), dev(g["train_labels"])
+    kw = dict(attention_mask=mask, labels=labels, batch_size_t2i=2, batch_size_lm=1, batch_size_mmu=2, max_seq_length=d.max_text_len)
+    logits0, a1, a2, a3 = m(ids, **kw)
+    (1.0 * a1 + 0.1 * a2 + 1.0 * a3).backward()
+    g0 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    emb = m.showo.model.embed_tokens(ids)  # torch lookup, as the reference script does
+    extra = torch.zeros_like(emb, requires_grad=True)  # a second consumer of the returned gradient (stands in for mm_projector rows)
+    logits1, b1, b2, b3 = m(None, input_embeddings=emb + extra, **kw)
+    assert torch.equal(logits0, logits1) and torch.equal(torch.stack([a1, a2, a3]), torch.stack([b1, b2, b3]))
+    (1.0 * b1 + 0.1 * b2 + 1.0 * b3).backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    for n in g0:
+        if "embed_tokens" in n:
+            err = (g1[n] - g0[n]).abs().max()
+            assert err <= 1e-5 * float(g0[n].abs().max()) + 1e-9, (n, float(err))  # same fp32 terms, different summation order
+        else:
+            assert torch.equal(g1[n], g0[n]), n
+    assert extra.grad is not None and tuple(extra.grad.shape) == tuple(emb.shape) and torch.isfinite(extra.grad).all()
+    # rows of the table gradient are sums of the per-token gradients
+    tab = torch.zeros_like(g0["showo.model.embed_tokens.weight"])
+    tab.index_add_(0, ids.reshape(-1), extra.grad.reshape(-1, extra.grad.shape[-1]))
+    assert (tab - g0["showo.model.embed_tokens.weight"]).abs().max() <= 1e-5 * float(tab.abs().max()) + 1e-9
