@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .persistence import PretrainedMixin
 
 
 def _norm(c):
@@ -116,7 +117,7 @@ class _LFQBuffers(nn.Module):
         self.codebook_size = 2 ** codebook_dim
 
 
-class MAGVITv2(nn.Module):
+class MAGVITv2(PretrainedMixin, nn.Module):
     ENC = dict(ch_mult=(1, 2, 2, 4, 4), num_res_blocks=(4, 3, 4, 3, 4))
     DEC = dict(ch_mult=(1, 1, 2, 2, 4), num_res_blocks=(4, 4, 3, 4, 3))
 

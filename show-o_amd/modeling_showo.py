@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .persistence import PretrainedMixin
 from .sampling import cosine_schedule, t2i_step_constants
 
 # microsoft/phi-1_5 architecture numbers (what AutoConfig.from_pretrained(llm_model_path) yields in the
@@ -163,8 +164,13 @@ class _ShowoTrainFn(torch.autograd.Function):
         return (None, None, g_emb) + (None,) * 6 + tuple(grads)
 
 
-class Showo(nn.Module):
+class Showo(PretrainedMixin, nn.Module):
     _supports_gradient_checkpointing = True
+    # the reference's @register_to_config arguments (models/modeling_showo.py:26-37) = the keys of its config.json
+    _config_keys = ("w_clip_vit", "vocab_size", "llm_vocab_size", "llm_model_path", "codebook_size", "num_vq_tokens", "load_from_showo")
+
+    def _extra_config(self):
+        return {k: v for k, v in self.arch.items() if PHI_1_5.get(k) != v}
 
     def __init__(self, w_clip_vit, vocab_size, llm_vocab_size, llm_model_path='', codebook_size=8192,
                  num_vq_tokens=256, load_from_showo=True, **kwargs):

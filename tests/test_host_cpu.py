@@ -148,3 +148,76 @@ def test_universal_prompting_edge_cases():
     assert ids[0][0] == bos and seq[0, 12] == eos and seq[0, 0] == int(up.sptids_dict['<|t2i|>'])
     assert seq.shape[1] == 13 + 1 + img.shape[1] + 1
     assert seq[0, 13] == int(up.sptids_dict['<|soi|>']) and seq[0, -1] == int(up.sptids_dict['<|eoi|>'])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# checkpoint format I/O (reference models/modeling_utils.py:47-49, 270-414, 416-865)
+# ---------------------------------------------------------------------------------------------------------------
+def _tiny_showo_cpu():
+    d, sd_np = util.tiny_state()
+    S = util.pkg().Showo
+    m = S(d.w_clip_vit, d.vocab, d.llm_vocab, codebook_size=d.codebook, num_vq_tokens=d.num_vq_tokens, hidden_size=d.hidden,
+          intermediate_size=d.ffn, num_hidden_layers=d.layers, num_attention_heads=d.heads)
+    m.load_state_dict(O.to_torch(sd_np), strict=True)
+    return d, m
+
+
+@pytest.mark.parametrize("safe,shard", [(True, "10GB"), (False, "10GB"), (True, "200KB")])
+def test_save_pretrained_from_pretrained_roundtrip(tmp_path, safe, shard):
+    import json
+    d, m = _tiny_showo_cpu()
+    out = str(tmp_path / "checkpoint-10" / "unwrapped_model")  # the layout training/train.py:851-889 writes
+    m.save_pretrained(out, safe_serialization=safe, max_shard_size=shard)
+    cfg = json.load(open(os.path.join(out, "config.json")))
+    assert cfg["_class_name"] == "Showo" and cfg["vocab_size"] == d.vocab and cfg["llm_vocab_size"] == d.llm_vocab
+    assert cfg["codebook_size"] == d.codebook and cfg["num_vq_tokens"] == d.num_vq_tokens and cfg["w_clip_vit"] is False
+    files = sorted(os.listdir(out))
+    if shard == "10GB":
+        assert files == ["config.json", "pytorch_model.safetensors" if safe else "pytorch_model.bin"]
+    else:
+        assert "pytorch_model.safetensors.index.json" in files and sum(f.endswith(".safetensors") for f in files) > 2
+    m2 = util.pkg().Showo.from_pretrained(out, device="cpu", max_batch=2, max_seq=64)
+    assert m2.max_batch == 2 and not m2.training and m2.mask_token_id == d.vocab - 1
+    a, b = m.state_dict(), m2.state_dict()
+    assert list(a) == list(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # a second save in the other format replaces nothing it should not, and loading prefers safetensors
+    m2.save_pretrained(out, safe_serialization=not safe)
+    assert "config.json" in os.listdir(out)
+
+
+def test_from_pretrained_reads_reference_written_files_and_reports_bad_ones(tmp_path):
+    """a directory written the way the reference's ModelMixin does (torch.save of the state dict + its config.json keys)"""
+    import json
+    d, m = _tiny_showo_cpu()
+    out = str(tmp_path / "ref_style")
+    os.makedirs(out)
+    torch.save({k: v.clone() for k, v in m.state_dict().items()}, os.path.join(out, "pytorch_model.bin"))
+    json.dump({"_class_name": "Showo", "_diffusers_version": "0.30.1", "codebook_size": d.codebook, "llm_model_path": "",
+               "llm_vocab_size": d.llm_vocab, "load_from_showo": True, "num_vq_tokens": d.num_vq_tokens, "vocab_size": d.vocab,
+               "w_clip_vit": False}, open(os.path.join(out, "config.json"), "w"))
+    geo = dict(hidden_size=d.hidden, intermediate_size=d.ffn, num_hidden_layers=d.layers, num_attention_heads=d.heads)
+    m2 = util.pkg().Showo.from_pretrained(out, device="cpu", **geo)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    sd = m.state_dict()
+    first = next(iter(sd))
+    torch.save({k: v for k, v in sd.items() if k != first}, os.path.join(out, "pytorch_model.bin"))
+    with pytest.raises(KeyError):
+        util.pkg().Showo.from_pretrained(out, device="cpu", **geo)
+    torch.save({k: (v[:1] if k == first else v) for k, v in sd.items()}, os.path.join(out, "pytorch_model.bin"))
+    with pytest.raises(ValueError):
+        util.pkg().Showo.from_pretrained(out, device="cpu", **geo)
+    with pytest.raises(EnvironmentError):
+        util.pkg().Showo.from_pretrained(str(tmp_path / "nope"))
+
+
+def test_magvitv2_config_roundtrip(tmp_path):
+    V = util.pkg().MAGVITv2
+    with torch.device("meta"):
+        v = V()
+    v.save_config(str(tmp_path))
+    import json
+    assert json.load(open(tmp_path / "config.json"))["_class_name"] == "MAGVITv2"
+    assert V.load_config(str(tmp_path))["_class_name"] == "MAGVITv2"
