@@ -405,6 +405,33 @@ int showo_train_adamw_step(showo_trainer* t, float lr, float beta1, float beta2,
                            void* stream);
 int showo_gelu_bf16(const uint16_t* f, uint16_t* a, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CLIP ViT vision tower + mm_projector of the w_clip_vit understanding path.
+ * Replaces transformers.CLIPVisionModel(images, output_hidden_states=True).hidden_states[-2][:, 1:] as called by
+ * models/clip_encoder.py:29-49, and model.mm_projector (models/modeling_showo.py:48-53, inference_mmu.py:133-134).
+ * run_layers = layers + 1 + select_layer (23 of 24 for select_layer = -2).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct showo_clip showo_clip;
+typedef struct {
+    int image_size, patch_size, hidden, heads, ffn, layers, run_layers, max_batch;
+    float ln_eps;
+} showo_clip_config;
+int showo_clip_create(const showo_clip_config* cfg, showo_clip** out);
+void showo_clip_destroy(showo_clip* c);
+/* one tensor by its transformers state-dict key ("vision_model.embeddings.patch_embedding.weight", ..., optionally prefixed
+ * "vision_tower." as in the reference wrapper's state dict, with or without the "vision_model." level); src = device fp32 */
+int showo_clip_load(showo_clip* c, const char* key, const float* src, int64_t n, void* stream);
+int showo_clip_missing(const showo_clip* c);
+/* images fp32 [B,3,S,S] (normalised) -> features fp32 [B, (S/patch)^2, hidden] */
+int showo_clip_features(showo_clip* c, const float* images, int B, float* features, void* stream);
+/* mm_projector: Linear(in,out) -> exact GELU -> Linear(out,out).  Keys "0.weight", "0.bias", "2.weight", "2.bias" (optionally
+ * prefixed "mm_projector."); x fp32 [T,in] -> out fp32 [T,out], T <= max_rows. */
+typedef struct showo_projector showo_projector;
+int showo_projector_create(int in_dim, int out_dim, int max_rows, showo_projector** out);
+void showo_projector_destroy(showo_projector* p);
+int showo_projector_load(showo_projector* p, const char* key, const float* src, int64_t n, void* stream);
+int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

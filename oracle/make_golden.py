@@ -417,6 +417,43 @@ def make_prompting():
     print("prompting.npz:", len(out), "arrays; oracle restatement == reference on the 4 random-permutation cases")
 
 
+def make_clip():
+    """CLIP vision tower: the installed transformers CLIPVisionModel (what models/clip_encoder.py calls) on the deterministic
+    weights of oracle/weights.py -> hidden_states[-2][:, 1:]; the restatement is asserted against it."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    out = {}
+    for tag, cfg, B, seed in (("tiny", Wt.CLIP_TINY, 3, 21), ("l336", Wt.CLIP_L336, 1, 22)):
+        sd_np = Wt.make_clip_state(cfg, seed=seed)
+        hf = CLIPVisionModel(CLIPVisionConfig(**cfg)).eval()
+        own = hf.state_dict()
+        strip = not any(k.startswith("vision_model.") for k in own)  # transformers >= 5 dropped that level
+        hf.load_state_dict({(k[len("vision_model."):] if strip else k): torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        rs = np.random.RandomState(seed + 100)
+        x = torch.from_numpy(rs.standard_normal((B, 3, cfg["image_size"], cfg["image_size"])).astype(np.float32))
+        with torch.no_grad():
+            ref = hf(x, output_hidden_states=True).hidden_states[-2][:, 1:]
+            mine = O.clip_vision_features(O.to_torch(sd_np), cfg, x)
+        report(f"clip {tag} features", mine, ref)
+        assert (mine - ref).abs().max() <= 2e-4 * float(ref.abs().max())
+        out[f"{tag}_seed"] = seed  # weights = Wt.make_clip_state(cfg, seed); x = RandomState(seed + 100).standard_normal(...)
+        if tag == "tiny":
+            out["tiny_x"], out["tiny_features"] = x.numpy(), ref.numpy()
+        else:  # full size: a strided subset of the [1,576,1024] features
+            out["l336_rows"], out["l336_cols"] = np.arange(0, 576, 37), np.arange(0, 1024, 13)
+            out["l336_features"] = ref[0][out["l336_rows"]][:, out["l336_cols"]].numpy()
+            out["l336_absmax"], out["l336_std"] = float(ref.abs().max()), float(ref.std())
+    psd = Wt.make_projector_state(128, 192, seed=23)
+    px = torch.from_numpy(np.random.RandomState(24).standard_normal((37, 128)).astype(np.float32))
+    ref = torch.nn.Sequential(torch.nn.Linear(128, 192), torch.nn.GELU(), torch.nn.Linear(192, 192))  # modeling_showo.py:48-53
+    ref.load_state_dict(O.to_torch(psd))
+    with torch.no_grad():
+        want = ref(px)
+    assert torch.allclose(O.mm_projector(O.to_torch(psd), px), want, atol=1e-6)
+    out["proj_x"], out["proj_out"] = px.numpy(), want.numpy()
+    np.savez_compressed(os.path.join(GOLD, "clip_vision.npz"), **out)
+    print("clip_vision.npz written")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
@@ -428,6 +465,8 @@ if __name__ == "__main__":
         make_tiny_showo()
     if a.only in ("", "magvit"):
         make_magvit()
+    if a.only in ("", "clip"):
+        make_clip()
     if a.only in ("", "prompting"):
         make_prompting()
     if a.full or a.only == "full":

@@ -467,3 +467,41 @@ def magvit_decode_code(sd, ids, shape=None):
 
 def to_torch(sd_np):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIP ViT vision tower + mm_projector (models/clip_encoder.py:29-49 -> transformers CLIPVisionModel; modeling_showo.py:48-53)
+# The arithmetic is third-party (transformers, pinned 4.41.1 by requirements.txt:203; 5.15 installed here): this restates
+# CLIPVisionEmbeddings / CLIPEncoderLayer / CLIPAttention / CLIPMLP and is asserted against the installed class in
+# oracle/make_golden.py.
+# ----------------------------------------------------------------------------------------------
+def clip_vision_features(sd, cfg, images, select_layer=-2):
+    """sd: {vision_model.* key: tensor}; images fp32 [B,3,S,S] -> hidden_states[select_layer][:, 1:]  [B, P, H]"""
+    H, nH, ps, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"], cfg["layer_norm_eps"]
+    g = lambda k: sd["vision_model." + k]
+    B = images.shape[0]
+    patches = F.conv2d(images, g("embeddings.patch_embedding.weight"), stride=ps).flatten(2).transpose(1, 2)  # [B,P,H]
+    x = torch.cat([g("embeddings.class_embedding").expand(B, 1, H), patches], dim=1) + g("embeddings.position_embedding.weight")[None]
+    x = F.layer_norm(x, (H,), g("pre_layrnorm.weight"), g("pre_layrnorm.bias"), eps)
+    n_run = cfg["num_hidden_layers"] + 1 + select_layer
+    L = x.shape[1]
+    for i in range(n_run):
+        p = f"encoder.layers.{i}."
+        h = F.layer_norm(x, (H,), g(p + "layer_norm1.weight"), g(p + "layer_norm1.bias"), eps)
+        q = F.linear(h, g(p + "self_attn.q_proj.weight"), g(p + "self_attn.q_proj.bias")) * (H // nH) ** -0.5
+        k = F.linear(h, g(p + "self_attn.k_proj.weight"), g(p + "self_attn.k_proj.bias"))
+        v = F.linear(h, g(p + "self_attn.v_proj.weight"), g(p + "self_attn.v_proj.bias"))
+        sp = lambda t: t.view(B, L, nH, H // nH).transpose(1, 2)
+        a = torch.softmax(sp(q) @ sp(k).transpose(2, 3), dim=-1) @ sp(v)
+        a = a.transpose(1, 2).reshape(B, L, H)
+        x = x + F.linear(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"))
+        h = F.layer_norm(x, (H,), g(p + "layer_norm2.weight"), g(p + "layer_norm2.bias"), eps)
+        f = F.linear(h, g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"))
+        f = f * torch.sigmoid(1.702 * f)  # quick_gelu
+        x = x + F.linear(f, g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias"))
+    return x[:, 1:]
+
+
+def mm_projector(sd, x):
+    """nn.Sequential(Linear, GELU(), Linear) (modeling_showo.py:48-53); sd keys 0.weight, 0.bias, 2.weight, 2.bias"""
+    return F.linear(F.gelu(F.linear(x, sd["0.weight"], sd["0.bias"])), sd["2.weight"], sd["2.bias"])

@@ -186,3 +186,52 @@ def make_magvit_state(d: MagvitDims = None, seed: int = 0, dtype=np.float32):
     sd["quantize.embedding"] = (binary.astype(dtype) * 2 - 1)
     sd["quantize.power_vals"] = (2 ** np.arange(nb - 1, -1, -1, dtype=np.int64))
     return sd
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CLIP ViT vision tower (transformers CLIPVisionModel; openai/clip-vit-large-patch14-336 in the reference's configs)
+# ----------------------------------------------------------------------------------------------------------------
+CLIP_L336 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
+                 patch_size=14, layer_norm_eps=1e-5, hidden_act="quick_gelu")
+CLIP_TINY = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=56,
+                 patch_size=14, layer_norm_eps=1e-5, hidden_act="quick_gelu")
+
+
+def make_clip_state(cfg, seed=0, dtype=np.float32):
+    """deterministic weights under transformers-4.41 / checkpoint key names (vision_model.*); scales chosen so that
+    activations stay O(1) through the stack (LayerNorm weights ~ N(1, 0.1), projections ~ N(0, 1/sqrt(fan_in)))"""
+    rs = np.random.RandomState(seed)
+    H, F, S, ps = cfg["hidden_size"], cfg["intermediate_size"], cfg["image_size"], cfg["patch_size"]
+    sd = OrderedDict()
+
+    def put(k, shape, std, mean=0.0):
+        sd[k] = (rs.standard_normal(size=shape) * std + mean).astype(dtype)
+    put("vision_model.embeddings.class_embedding", (H,), 0.5)
+    put("vision_model.embeddings.patch_embedding.weight", (H, 3, ps, ps), 1.0 / np.sqrt(3 * ps * ps))
+    put("vision_model.embeddings.position_embedding.weight", ((S // ps) ** 2 + 1, H), 0.3)
+    put("vision_model.pre_layrnorm.weight", (H,), 0.1, 1.0)
+    put("vision_model.pre_layrnorm.bias", (H,), 0.05)
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"vision_model.encoder.layers.{i}."
+        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            put(p + f"self_attn.{nm}.weight", (H, H), (2.0 if nm in ("q_proj", "k_proj") else 1.0) / np.sqrt(H))
+            put(p + f"self_attn.{nm}.bias", (H,), 0.05)
+        put(p + "layer_norm1.weight", (H,), 0.1, 1.0)
+        put(p + "layer_norm1.bias", (H,), 0.05)
+        put(p + "mlp.fc1.weight", (F, H), 1.0 / np.sqrt(H))
+        put(p + "mlp.fc1.bias", (F,), 0.05)
+        put(p + "mlp.fc2.weight", (H, F), 1.0 / np.sqrt(F))
+        put(p + "mlp.fc2.bias", (H,), 0.05)
+        put(p + "layer_norm2.weight", (H,), 0.1, 1.0)
+        put(p + "layer_norm2.bias", (H,), 0.05)
+    put("vision_model.post_layernorm.weight", (H,), 0.1, 1.0)
+    put("vision_model.post_layernorm.bias", (H,), 0.05)
+    return sd
+
+
+def make_projector_state(din=1024, dout=2048, seed=0, dtype=np.float32):
+    rs = np.random.RandomState(seed)
+    return OrderedDict([("0.weight", (rs.standard_normal((dout, din)) / np.sqrt(din)).astype(dtype)),
+                        ("0.bias", (rs.standard_normal((dout,)) * 0.1).astype(dtype)),
+                        ("2.weight", (rs.standard_normal((dout, dout)) / np.sqrt(dout)).astype(dtype)),
+                        ("2.bias", (rs.standard_normal((dout,)) * 0.1).astype(dtype))])

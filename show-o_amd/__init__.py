@@ -14,3 +14,4 @@ from . import prompting_utils  # noqa: F401
 from . import training_utils  # noqa: F401
 from .prompting_utils import UniversalPrompting  # noqa: F401
 from .training_utils import mask_or_random_replace_tokens  # noqa: F401
+from .clip_encoder import CLIPVisionTower  # noqa: F401

@@ -103,6 +103,13 @@ _PROTOS = {
     "showo_engine_prefill": [c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "showo_engine_decode_step": [c_p, c_p, c_p, c_p, c_p],
     "showo_engine_decode_greedy": [c_p, c_p, c_i, c_p, c_p, c_i, c_p],
+    "showo_clip_create": [c_p, c_p],
+    "showo_clip_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
+    "showo_clip_missing": [c_p],
+    "showo_clip_features": [c_p, c_p, c_i, c_p, c_p],
+    "showo_projector_create": [c_i, c_i, c_i, c_p],
+    "showo_projector_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
+    "showo_projector_forward": [c_p, c_p, c_i, c_p, c_p],
     "showo_sample_topk": [c_p, c_i, c_i, c_f, c_p, c_u64, c_i, c_p, c_p],
     "showo_engine_decode_sample": [c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_p, c_u64, c_i, c_i, c_p],
     "showo_vq_create": [c_p, C.POINTER(c_p)],
@@ -116,7 +123,7 @@ _PROTOS = {
     "showo_prof_set_stride": [c_i],
     "showo_prof_totals": [c_i, c_p, c_p],
 }
-_VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p], "showo_train_destroy": [c_p]}
+_VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p], "showo_train_destroy": [c_p], "showo_clip_destroy": [c_p], "showo_projector_destroy": [c_p]}
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + ["showo_last_error"])
 
 EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3
@@ -133,6 +140,11 @@ class VQConfig(C.Structure):
                 ("enc_ch_mult", c_i * 8), ("enc_blocks", c_i * 8), ("enc_levels", c_i),
                 ("dec_ch_mult", c_i * 8), ("dec_blocks", c_i * 8), ("dec_levels", c_i),
                 ("max_batch", c_i), ("max_res", c_i), ("precision", c_i)]
+
+
+class ClipConfig(C.Structure):
+    _fields_ = [("image_size", c_i), ("patch_size", c_i), ("hidden", c_i), ("heads", c_i), ("ffn", c_i), ("layers", c_i),
+                ("run_layers", c_i), ("max_batch", c_i), ("ln_eps", c_f)]
 
 
 def build(force=False):

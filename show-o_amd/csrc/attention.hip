@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(PrepArgs a) {
     const int l0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
     if (a.pos_dev) a.pos0 = *a.pos_dev;
     const int H3 = 3 * a.nH * 64, Hq = a.nH * 64;
-    const float qw = a.qw[lane], qb = a.qb[lane], kw = a.kw[lane], kb = a.kb[lane];
+    const bool plain = a.qw == nullptr;
+    const float qw = plain ? 1.f : a.qw[lane], qb = plain ? 0.f : a.qb[lane], kw = plain ? 1.f : a.kw[lane], kb = plain ? 0.f : a.kb[lane];
     for (int i = 0; i < 16; ++i) {
         int l = l0 + wave * 16 + i;
         if (l >= a.L) break;
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(PrepArgs a) {
         int pos = a.pos0 + l;
         const float* cosr = a.cosT + (int64_t)pos * a.rot;
         const float* sinr = a.sinT + (int64_t)pos * a.rot;
-        float q = ln_rope_lane(bf2f(row[lane]), qw, qb, a.eps, cosr, sinr, a.rot, lane);
-        float k = ln_rope_lane(bf2f(row[Hq + lane]), kw, kb, a.eps, cosr, sinr, a.rot, lane);
+        // plain heads (qw == NULL: a standard multi-head attention such as the CLIP tower's): only the 1/8 scale and the relayout
+        float q = plain ? bf2f(row[lane]) : ln_rope_lane(bf2f(row[lane]), qw, qb, a.eps, cosr, sinr, a.rot, lane);
+        float k = plain ? bf2f(row[Hq + lane]) : ln_rope_lane(bf2f(row[Hq + lane]), kw, kb, a.eps, cosr, sinr, a.rot, lane);
         a.Q[(((int64_t)b * a.nH + head) * a.L + l) * 64 + lane] = f2bf(q * 0.125f);  // 1/sqrt(64), exact in bf16
         a.K[(((int64_t)b * a.nH + head) * a.Lcap + pos) * 64 + lane] = f2bf(k);
         sV[wave * 16 + i][lane] = row[2 * Hq + lane];
@@ -671,7 +673,7 @@ extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const floa
                              uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
                              void* stream) {
     if (B <= 0 || L <= 0) return 0;
-    if (rot != 32 && rot != 16 && rot != 64 && rot != 8) return set_error_msg(1, "qk_prep: rotary dim must be a power of two <= 64");
+    if (qln_w && rot != 32 && rot != 16 && rot != 64 && rot != 8) return set_error_msg(1, "qk_prep: rotary dim must be a power of two <= 64");
     if ((Lp % 64) || Lp < pos0 + L || Lcap < pos0 + L) return set_error_msg(1, "qk_prep: bad Lp/Lcap");
     PrepArgs a;
     a.qkv = qkv; a.qw = qln_w; a.qb = qln_b; a.kw = kln_w; a.kb = kln_b; a.cosT = cos_tab; a.sinT = sin_tab;

@@ -1,0 +1,346 @@
+// CLIP ViT vision tower + mm_projector for the w_clip_vit understanding path.
+//
+// Reference: models/clip_encoder.py:6-51 wraps transformers' CLIPVisionModel (openai/clip-vit-large-patch14-336) and returns
+// hidden_states[-2][:, 1:] (penultimate layer, class token dropped); inference_mmu.py:133-141 feeds that through
+// `model.mm_projector` (Linear 1024->2048, exact GELU, Linear 2048->2048; modeling_showo.py:48-53).  The arithmetic lives in
+// the third-party package (transformers; pinned 4.41.1 by requirements.txt:203): patch embedding = 14x14 stride-14 convolution
+// without bias, class token, learned position embeddings, pre-LayerNorm, then pre-LN blocks
+//     x += out_proj(MHA(LN1(x)))   (16 heads x 64, scale 1/8 applied to q, no mask)
+//     x += fc2(quick_gelu(fc1(LN2(x))))      quick_gelu(v) = v * sigmoid(1.702 v)
+// Built from the same gfx950 kernels as the Phi stack: the patch convolution is a GEMM over an im2col image written in
+// bf16 (K = 3*14*14 = 588 padded to 640), q/k/v are one packed [3H,H] projection, attention is the LDS-tiled flash kernel
+// with full-visibility intervals, LayerNorm / residual epilogues as in engine.hip.  Only the layers the selected feature
+// needs are run (23 of 24 for select_layer = -2; the post-LayerNorm is never used by the reference).
+#include "common.h"
+#include "../../include/showo_hip.h"
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace showo;
+
+namespace {
+
+#define TRY(expr)            \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+// pixel_values fp32 [B,3,S,S] -> bf16 patch rows [B*P, Kp]; column k = c*ps*ps + dy*ps + dx (the flattening of the conv weight
+// [hidden,3,ps,ps]); columns >= 3*ps*ps are zero
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int S, int ps, int G, int Kp, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % Kp);
+    const int64_t r = i / Kp;
+    const int p = (int)(r % (G * G));
+    const int64_t b = r / (G * G);
+    const int pp = ps * ps;
+    float v = 0.f;
+    if (k < 3 * pp) {
+        const int c = k / pp, dy = (k % pp) / ps, dx = k % ps;
+        const int y = (p / G) * ps + dy, x = (p % G) * ps + dx;
+        v = img[((b * 3 + c) * S + y) * S + x];
+    }
+    out[i] = f2bf(v);
+}
+
+// x[b,0,:] = cls + pos[0];  x[b,1+p,:] = patch[b*P+p,:] + pos[1+p]      (CLIPVisionEmbeddings.forward)
+__global__ void assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                float* __restrict__ x, int L, int H, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int h = (int)(i % H);
+    const int64_t r = i / H;
+    const int l = (int)(r % L);
+    const int64_t b = r / L;
+    const float v = l == 0 ? cls[h] : patch[(b * (L - 1) + (l - 1)) * H + h];
+    x[i] = v + pos[(int64_t)l * H + h];
+}
+
+// LayerNorm fp32 -> fp32 in place (pre_layrnorm: its output IS the residual stream); one wave per row, two passes
+__global__ __launch_bounds__(256) void ln_f32_kernel(float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                     int rows, int H, float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    float* xr = x + (int64_t)r * H;
+    float s = 0.f;
+    for (int i = lane; i < H; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int i = lane; i < H; i += 64) { const float a = xr[i] - mean; q += a * a; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    for (int i = lane; i < H; i += 64) xr[i] = (xr[i] - mean) * rstd * w[i] + b[i];
+}
+
+// activation between the two GEMMs of an MLP, fp32 pre-activation -> bf16 operand.  MODE 0: quick_gelu (CLIP), 1: exact GELU (erf)
+template <int MODE>
+__global__ void act_kernel(const float* __restrict__ f, bf16_t* __restrict__ a, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = f[i];
+        float y;
+        if (MODE == 0) y = v / (1.0f + __expf(-1.702f * v));
+        else y = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        a[i] = f2bf(y);
+    }
+}
+
+__global__ void fill_full_intervals_kernel(int32_t* iv, int L, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) *reinterpret_cast<int4*>(iv + (int64_t)i * 4) = make_int4(0, L, 0, 0);
+}
+
+struct ClipLayer {
+    bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+};
+
+int launch1d(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+struct showo_clip {
+    showo_clip_config cfg;
+    int H, F, nH, G, P, L, Kp, nRun;
+    std::vector<void*> allocs;
+    std::set<std::string> loaded;
+    int expected = 0;
+    bf16_t* wpatch = nullptr;
+    float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
+    std::vector<ClipLayer> layers;
+    // workspace
+    bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *attn = nullptr, *act = nullptr;
+    float *pout = nullptr, *x = nullptr, *f = nullptr;
+    int32_t* iv = nullptr;
+
+    template <class T>
+    int alloc(T** p, int64_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T));
+        if (e != hipSuccess) return set_error_hip(e, "hipMalloc", __FILE__, __LINE__);
+        allocs.push_back(q);
+        *p = (T*)q;
+        return 0;
+    }
+};
+
+extern "C" void showo_clip_destroy(showo_clip* c) {
+    if (!c) return;
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+}
+
+extern "C" int showo_clip_create(const showo_clip_config* cf, showo_clip** out) {
+    if (!cf || !out) return set_error_msg(1, "clip_create: null argument");
+    if (cf->hidden != cf->heads * 64 || (cf->hidden % 64) || (cf->ffn % 64)) return set_error_msg(1, "clip: head_dim must be 64, hidden/ffn multiples of 64");
+    if (cf->patch_size <= 0 || cf->image_size % cf->patch_size) return set_error_msg(1, "clip: image_size must be a multiple of patch_size");
+    if (cf->run_layers < 0 || cf->run_layers > cf->layers) return set_error_msg(1, "clip: run_layers out of range");
+    showo_clip* c = new showo_clip();
+    c->cfg = *cf;
+    c->H = cf->hidden; c->F = cf->ffn; c->nH = cf->heads;
+    c->G = cf->image_size / cf->patch_size; c->P = c->G * c->G; c->L = c->P + 1;
+    c->Kp = ((3 * cf->patch_size * cf->patch_size + 63) / 64) * 64;
+    c->nRun = cf->run_layers;
+    const int64_t H = c->H, F = c->F, B = cf->max_batch, T = B * c->L;
+    const int Lp = ((c->L + 63) / 64) * 64;
+    int rc = 0;
+    rc |= c->alloc(&c->wpatch, H * c->Kp); rc |= c->alloc(&c->cls, H); rc |= c->alloc(&c->pos, c->L * H);
+    rc |= c->alloc(&c->pre_w, H); rc |= c->alloc(&c->pre_b, H);
+    c->layers.resize(c->nRun);
+    for (auto& l : c->layers) {
+        rc |= c->alloc(&l.wqkv, 3 * H * H); rc |= c->alloc(&l.bqkv, 3 * H); rc |= c->alloc(&l.wo, H * H); rc |= c->alloc(&l.bo, H);
+        rc |= c->alloc(&l.w1, F * H); rc |= c->alloc(&l.b1, F); rc |= c->alloc(&l.w2, H * F); rc |= c->alloc(&l.b2, H);
+        rc |= c->alloc(&l.ln1_w, H); rc |= c->alloc(&l.ln1_b, H); rc |= c->alloc(&l.ln2_w, H); rc |= c->alloc(&l.ln2_b, H);
+    }
+    rc |= c->alloc(&c->patches, B * c->P * c->Kp); rc |= c->alloc(&c->pout, B * c->P * H);
+    rc |= c->alloc(&c->x, T * H); rc |= c->alloc(&c->h, T * H); rc |= c->alloc(&c->qkv, T * 3 * H);
+    rc |= c->alloc(&c->Q, T * H); rc |= c->alloc(&c->K, T * H); rc |= c->alloc(&c->Vt, B * H * Lp);
+    rc |= c->alloc(&c->attn, T * H); rc |= c->alloc(&c->f, T * F); rc |= c->alloc(&c->act, T * F);
+    rc |= c->alloc(&c->iv, T * 4);
+    if (rc) { showo_clip_destroy(c); return rc; }
+    hipMemset(c->Vt, 0, (size_t)B * H * Lp * sizeof(bf16_t));
+    hipMemset(c->wpatch, 0, (size_t)H * c->Kp * sizeof(bf16_t));
+    c->expected = 5 + c->nRun * 16;
+    *out = c;
+    return 0;
+}
+
+extern "C" int showo_clip_missing(const showo_clip* c) { return c ? c->expected - (int)c->loaded.size() : -1; }
+
+namespace {
+int copy_f32(float* dst, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+    if (n != expect) return set_error_msg(2, "clip_load: element count mismatch");
+    SHOWO_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int cast_w(bf16_t* dst, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+    if (n != expect) return set_error_msg(2, "clip_load: element count mismatch");
+    return showo_cast_f32_bf16(src, dst, n, s);
+}
+// conv weight fp32 [H, 3*ps*ps] -> bf16 [H, Kp] (row stride Kp, pad columns stay zero)
+__global__ void pad_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int Kp, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    dst[(i / K) * Kp + (i % K)] = f2bf(src[i]);
+}
+}  // namespace
+
+// Load one tensor by its transformers state-dict key ("vision_model.embeddings.patch_embedding.weight",
+// "vision_model.encoder.layers.7.self_attn.q_proj.weight", ...) or a projector key ("mm_projector.0.weight", ...).
+// Tensors the selected feature does not need (layers >= run_layers, post_layernorm, position_ids) are accepted and ignored.
+extern "C" int showo_clip_load(showo_clip* c, const char* key, const float* src, int64_t n, void* stream) {
+    if (!c || !key || !src) return set_error_msg(1, "clip_load: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t H = c->H, F = c->F;
+    std::string k(key);
+    if (k.rfind("vision_tower.", 0) == 0) k = k.substr(13);  // keys of the reference's CLIPVisionTower wrapper
+    // transformers >= 5 dropped the "vision_model." level of CLIPVisionModel's state dict; checkpoints (and 4.41) have it
+    if (k.rfind("embeddings.", 0) == 0 || k.rfind("encoder.", 0) == 0 || k.rfind("pre_layrnorm.", 0) == 0 ||
+        k.rfind("post_layernorm.", 0) == 0)
+        k = "vision_model." + k;
+    int rc = -1, li = -1;
+    char sub[128];
+    const int K = 3 * c->cfg.patch_size * c->cfg.patch_size;
+    if (k == "vision_model.embeddings.patch_embedding.weight") {
+        if (n != H * K) return set_error_msg(2, "clip_load: element count mismatch");
+        pad_rows_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(src, c->wpatch, K, c->Kp, n);
+        rc = 0;
+    } else if (k == "vision_model.embeddings.class_embedding") rc = copy_f32(c->cls, src, n, H, s);
+    else if (k == "vision_model.embeddings.position_embedding.weight") rc = copy_f32(c->pos, src, n, (int64_t)c->L * H, s);
+    else if (k == "vision_model.pre_layrnorm.weight") rc = copy_f32(c->pre_w, src, n, H, s);  // [sic] transformers' spelling
+    else if (k == "vision_model.pre_layrnorm.bias") rc = copy_f32(c->pre_b, src, n, H, s);
+    else if (k == "vision_model.post_layernorm.weight" || k == "vision_model.post_layernorm.bias" ||
+             k == "vision_model.embeddings.position_ids") return 0;
+    else if (sscanf(k.c_str(), "vision_model.encoder.layers.%d.%127s", &li, sub) == 2 && li >= 0 && li < c->cfg.layers) {
+        if (li >= c->nRun) return 0;
+        ClipLayer& l = c->layers[li];
+        std::string t(sub);
+        if (t == "self_attn.q_proj.weight") rc = cast_w(l.wqkv, src, n, H * H, s);
+        else if (t == "self_attn.k_proj.weight") rc = cast_w(l.wqkv + H * H, src, n, H * H, s);
+        else if (t == "self_attn.v_proj.weight") rc = cast_w(l.wqkv + 2 * H * H, src, n, H * H, s);
+        else if (t == "self_attn.q_proj.bias") rc = copy_f32(l.bqkv, src, n, H, s);
+        else if (t == "self_attn.k_proj.bias") rc = copy_f32(l.bqkv + H, src, n, H, s);
+        else if (t == "self_attn.v_proj.bias") rc = copy_f32(l.bqkv + 2 * H, src, n, H, s);
+        else if (t == "self_attn.out_proj.weight") rc = cast_w(l.wo, src, n, H * H, s);
+        else if (t == "self_attn.out_proj.bias") rc = copy_f32(l.bo, src, n, H, s);
+        else if (t == "layer_norm1.weight") rc = copy_f32(l.ln1_w, src, n, H, s);
+        else if (t == "layer_norm1.bias") rc = copy_f32(l.ln1_b, src, n, H, s);
+        else if (t == "layer_norm2.weight") rc = copy_f32(l.ln2_w, src, n, H, s);
+        else if (t == "layer_norm2.bias") rc = copy_f32(l.ln2_b, src, n, H, s);
+        else if (t == "mlp.fc1.weight") rc = cast_w(l.w1, src, n, F * H, s);
+        else if (t == "mlp.fc1.bias") rc = copy_f32(l.b1, src, n, F, s);
+        else if (t == "mlp.fc2.weight") rc = cast_w(l.w2, src, n, H * F, s);
+        else if (t == "mlp.fc2.bias") rc = copy_f32(l.b2, src, n, H, s);
+    }
+    if (rc == -1) return set_error_msg(3, "clip_load: unknown state-dict key");
+    if (rc == 0) c->loaded.insert(k);
+    return rc;
+}
+
+// images fp32 [B,3,S,S] (already normalised by the image processor) -> features fp32 [B, P, hidden] =
+// CLIPVisionModel(images, output_hidden_states=True).hidden_states[run_layers][:, 1:]   (clip_encoder.py:29-37, 40-49)
+extern "C" int showo_clip_features(showo_clip* c, const float* images, int B, float* features, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!c || !images || !features) return set_error_msg(1, "clip_features: null argument");
+    if (B <= 0 || B > c->cfg.max_batch) return set_error_msg(5, "clip_features: batch exceeds the configured workspace");
+    if (showo_clip_missing(c) != 0) return set_error_msg(4, "clip: weights missing (showo_clip_missing() != 0)");
+    const int H = c->H, F = c->F, nH = c->nH, L = c->L, P = c->P, S = c->cfg.image_size;
+    const int T = B * L, Lp = ((L + 63) / 64) * 64;
+    const float eps = c->cfg.ln_eps;
+    {   // patch embedding: im2col (bf16) + GEMM, then class token / position embeddings, then pre-LayerNorm (fp32 in place)
+        const int64_t n = (int64_t)B * P * c->Kp;
+        patchify_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(images, c->patches, S, c->cfg.patch_size, c->G, c->Kp, n);
+        TRY(showo_gemm_bf16(c->patches, c->Kp, c->wpatch, c->Kp, nullptr, 0, c->pout, H, nullptr, 0, B * P, H, c->Kp, SHOWO_EPI_F32, s));
+        const int64_t m = (int64_t)T * H;
+        assemble_kernel<<<dim3(launch1d(m)), dim3(256), 0, s>>>(c->pout, c->cls, c->pos, c->x, L, H, m);
+        ln_f32_kernel<<<dim3((T + 3) / 4), dim3(256), 0, s>>>(c->x, c->pre_w, c->pre_b, T, H, eps);
+        fill_full_intervals_kernel<<<dim3(launch1d(T)), dim3(256), 0, s>>>(c->iv, L, T);
+    }
+    for (int li = 0; li < c->nRun; ++li) {
+        ClipLayer& l = c->layers[li];
+        TRY(showo_layernorm_f32_bf16(c->x, l.ln1_w, l.ln1_b, c->h, nullptr, T, H, eps, s));
+        TRY(showo_gemm_bf16(c->h, H, l.wqkv, H, l.bqkv, 0, c->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
+        TRY(showo_qk_prep(c->qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->Q, c->K, c->Vt, B, L, nH, 0, eps, 0, L, Lp, s));
+        TRY(showo_attn_fwd(c->Q, c->K, c->Vt, c->iv, nullptr, nullptr, c->attn, B, nH, L, L, L, Lp, H, s));
+        TRY(showo_gemm_bf16(c->attn, H, l.wo, H, l.bo, 0, c->x, H, c->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+        TRY(showo_layernorm_f32_bf16(c->x, l.ln2_w, l.ln2_b, c->h, nullptr, T, H, eps, s));
+        TRY(showo_gemm_bf16(c->h, H, l.w1, H, l.b1, 0, c->f, F, nullptr, 0, T, F, H, SHOWO_EPI_F32, s));
+        act_kernel<0><<<dim3(2048), dim3(256), 0, s>>>(c->f, c->act, (int64_t)T * F);
+        TRY(showo_gemm_bf16(c->act, F, l.w2, F, l.b2, 0, c->x, H, c->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+    }
+    SHOWO_CHECK_HIP(hipGetLastError());
+    // drop the class token: rows 1..P of every image
+    SHOWO_CHECK_HIP(hipMemcpy2DAsync(features, (size_t)P * H * sizeof(float), c->x + H, (size_t)L * H * sizeof(float),
+                                     (size_t)P * H * sizeof(float), B, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mm_projector (modeling_showo.py:48-53: Linear(in, out) -> nn.GELU() (exact, erf) -> Linear(out, out)), applied by
+// inference_mmu.py:134 / training/train_w_clip_vit.py:533-536 to the tower's features.
+// ------------------------------------------------------------------------------------------------------------------
+struct showo_projector {
+    int in_dim, out_dim, max_rows;
+    bf16_t *w0 = nullptr, *w1 = nullptr, *xb = nullptr, *act = nullptr;
+    float *b0 = nullptr, *b1 = nullptr, *f = nullptr;
+    std::set<std::string> loaded;
+};
+
+extern "C" void showo_projector_destroy(showo_projector* p) {
+    if (!p) return;
+    for (void* q : {(void*)p->w0, (void*)p->w1, (void*)p->xb, (void*)p->act, (void*)p->b0, (void*)p->b1, (void*)p->f})
+        if (q) hipFree(q);
+    delete p;
+}
+
+extern "C" int showo_projector_create(int in_dim, int out_dim, int max_rows, showo_projector** out) {
+    if (!out || in_dim <= 0 || out_dim <= 0 || max_rows <= 0) return set_error_msg(1, "projector_create: bad argument");
+    if ((in_dim % 64) || (out_dim % 64)) return set_error_msg(1, "projector: dimensions must be multiples of 64");
+    showo_projector* p = new showo_projector();
+    p->in_dim = in_dim; p->out_dim = out_dim; p->max_rows = max_rows;
+    const int64_t I = in_dim, D = out_dim, T = max_rows;
+    bool ok = hipMalloc((void**)&p->w0, D * I * 2) == hipSuccess && hipMalloc((void**)&p->w1, D * D * 2) == hipSuccess &&
+              hipMalloc((void**)&p->b0, D * 4) == hipSuccess && hipMalloc((void**)&p->b1, D * 4) == hipSuccess &&
+              hipMalloc((void**)&p->xb, T * I * 2) == hipSuccess && hipMalloc((void**)&p->f, T * D * 4) == hipSuccess &&
+              hipMalloc((void**)&p->act, T * D * 2) == hipSuccess;
+    if (!ok) { showo_projector_destroy(p); return set_error_msg(7, "projector_create: hipMalloc failed"); }
+    *out = p;
+    return 0;
+}
+
+// keys "0.weight" [out,in], "0.bias", "2.weight" [out,out], "2.bias" (nn.Sequential numbering; an "mm_projector." prefix is accepted)
+extern "C" int showo_projector_load(showo_projector* p, const char* key, const float* src, int64_t n, void* stream) {
+    if (!p || !key || !src) return set_error_msg(1, "projector_load: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::string k(key);
+    if (k.rfind("mm_projector.", 0) == 0) k = k.substr(13);
+    const int64_t I = p->in_dim, D = p->out_dim;
+    int rc;
+    if (k == "0.weight") rc = cast_w(p->w0, src, n, D * I, s);
+    else if (k == "0.bias") rc = copy_f32(p->b0, src, n, D, s);
+    else if (k == "2.weight") rc = cast_w(p->w1, src, n, D * D, s);
+    else if (k == "2.bias") rc = copy_f32(p->b1, src, n, D, s);
+    else return set_error_msg(3, "projector_load: unknown key");
+    if (rc == 0) p->loaded.insert(k);
+    return rc;
+}
+
+// x fp32 [T, in] -> out fp32 [T, out] = W1 gelu(W0 x + b0) + b1
+extern "C" int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !x || !out) return set_error_msg(1, "projector_forward: null argument");
+    if (T <= 0 || T > p->max_rows) return set_error_msg(5, "projector_forward: too many rows for the workspace");
+    if (p->loaded.size() != 4) return set_error_msg(4, "projector_forward: weights missing");
+    const int I = p->in_dim, D = p->out_dim;
+    TRY(showo_cast_f32_bf16(x, p->xb, (int64_t)T * I, s));
+    TRY(showo_gemm_bf16(p->xb, I, p->w0, I, p->b0, 0, p->f, D, nullptr, 0, T, D, I, SHOWO_EPI_F32, s));
+    act_kernel<1><<<dim3(1024), dim3(256), 0, s>>>(p->f, p->act, (int64_t)T * D);
+    TRY(showo_gemm_bf16(p->act, D, p->w1, D, p->b1, 0, out, D, nullptr, 0, T, D, D, SHOWO_EPI_F32, s));
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}

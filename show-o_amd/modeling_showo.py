@@ -164,6 +164,56 @@ class _ShowoTrainFn(torch.autograd.Function):
         return (None, None, g_emb) + (None,) * 6 + tuple(grads)
 
 
+class _MMProjector(nn.Sequential):
+    """`model.mm_projector` (reference modeling_showo.py:48-53): same parameters and state-dict keys (mm_projector.0.*,
+    mm_projector.2.*).  Without autograd (inference_mmu.py:134) the forward runs on the HIP projector (two MFMA GEMMs + exact
+    GELU, csrc/clip_engine.hip); when a gradient is required (the w_clip_vit trainer fine-tunes these 6 M parameters) it stays
+    on torch autograd -- the backward of this block is not on the HIP path yet."""
+
+    def __init__(self, din, dout):
+        super().__init__(nn.Linear(din, dout), nn.GELU(), nn.Linear(dout, dout))
+        self._dims = (din, dout)
+        self._proj, self._rows, self._versions = None, 0, None
+
+    def _drop(self):
+        if getattr(self, "_proj", None) is not None:
+            _lib.load().showo_projector_destroy(self._proj)
+        self._proj, self._versions = None, None
+
+    def __del__(self):
+        try:
+            self._drop()
+        except Exception:
+            pass
+
+    def forward(self, x):
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if need_grad:
+            return super().forward(x)
+        if not x.is_cuda:
+            raise RuntimeError("show-o_amd runs the projector on the GPU (no CPU path exists)")
+        import ctypes as C
+        din, dout = self._dims
+        xin = x.detach().float().contiguous()
+        T = xin.numel() // din
+        if self._proj is None or T > self._rows:
+            self._drop()
+            h = C.c_void_p()
+            self._rows = max(T, 576)
+            _lib.check(_lib.load().showo_projector_create(din, dout, self._rows, C.byref(h)), "showo_projector_create")
+            self._proj, self._versions = h, {}
+        for k, v in self.state_dict().items():
+            ver = (v.data_ptr(), v._version)
+            if self._versions.get(k) != ver:
+                src = v.detach().float().contiguous()
+                _lib.call("showo_projector_load", self._proj, k.encode(), _lib.ptr(src), src.numel(), _lib.stream())
+                self._versions[k] = ver
+                torch.cuda.current_stream().synchronize()
+        out = torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=torch.float32, device=x.device)
+        _lib.call("showo_projector_forward", self._proj, _lib.ptr(xin), T, _lib.ptr(out), _lib.stream())
+        return out.to(x.dtype)
+
+
 class Showo(PretrainedMixin, nn.Module):
     _supports_gradient_checkpointing = True
     # the reference's @register_to_config arguments (models/modeling_showo.py:26-37) = the keys of its config.json
@@ -191,7 +241,7 @@ class Showo(PretrainedMixin, nn.Module):
                                            64, arch["layer_norm_eps"])
         self.output_size = self.vocab_size
         if w_clip_vit:
-            self.mm_projector = nn.Sequential(nn.Linear(1024, 2048), nn.GELU(), nn.Linear(2048, 2048))
+            self.mm_projector = _MMProjector(1024, hidden)  # reference: nn.Sequential(Linear(1024, 2048), GELU(), Linear(2048, 2048))
         self._engine = None
         self._engine_key = None
         self._engine_versions = None

@@ -221,3 +221,23 @@ def test_magvitv2_config_roundtrip(tmp_path):
     import json
     assert json.load(open(tmp_path / "config.json"))["_class_name"] == "MAGVITv2"
     assert V.load_config(str(tmp_path))["_class_name"] == "MAGVITv2"
+
+
+def test_clip_tower_loads_a_local_checkpoint_directory(tmp_path):
+    """config.json of a full CLIPConfig (vision part nested) + model.safetensors with text-tower tensors next to the vision ones"""
+    import json
+    from safetensors.torch import save_file
+    sd = {k: torch.from_numpy(v) for k, v in Wt.make_clip_state(Wt.CLIP_TINY, seed=3).items()}
+    sd["text_model.final_layer_norm.weight"] = torch.ones(8)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    json.dump({"model_type": "clip", "vision_config": dict(Wt.CLIP_TINY, model_type="clip_vision_model")}, open(tmp_path / "config.json", "w"))
+    t = util.pkg().CLIPVisionTower(str(tmp_path))
+    assert t.is_loaded and t.vision_tower_name == str(tmp_path) and t.hidden_size == 128 and t.num_patches == 16
+    keys = list(t.state_dict())
+    assert keys[0] == "vision_tower.vision_model.embeddings.class_embedding" and len(keys) == 5 + 3 * 16 + 2
+    assert torch.equal(t.state_dict()["vision_tower.vision_model.encoder.layers.1.mlp.fc2.weight"], sd["vision_model.encoder.layers.1.mlp.fc2.weight"])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            t(torch.zeros(1, 3, 56, 56))
+    with pytest.raises(EnvironmentError):
+        util.pkg().CLIPVisionTower(str(tmp_path / "missing"))
