@@ -432,6 +432,23 @@ void showo_projector_destroy(showo_projector* p);
 int showo_projector_load(showo_projector* p, const char* key, const float* src, int64_t n, void* stream);
 int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Image pre / post-processing on the device.
+ * showo_image_resize_crop_normalize = training/utils.py:178-185 image_transform (torchvision Resize(bicubic) on a PIL image ->
+ * CenterCrop -> ToTensor -> Normalize(0.5, 0.5)): PIL's antialiased bicubic with its 22-bit fixed-point coefficient tables
+ * (computed by the host exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do), uint8 between the two passes;
+ * byte-exact with PIL.  img u8 [H,W,C] (C = 1 or 3) -> out fp32 [C,crop_h,crop_w]; bounds int32 [n,2] = (first tap, tap count),
+ * kk int32 [n,ksize]; tmp: >= H*Wout*C bytes; out_u8 (optional) u8 [crop_h,crop_w,C] = the resized + cropped bytes.
+ * showo_images_to_uint8 = inference_t2i.py:157-159 (clamp((x+1)/2,0,1)*255, truncated, NCHW -> NHWC).
+ * showo_mask_downsample_threshold = inference_t2i.py:100-108 (F.interpolate(mode='bicubic') to s_out x s_out, >= 0.5).
+ * --------------------------------------------------------------------------------------------- */
+int showo_image_resize_crop_normalize(const uint8_t* img, int H, int W, int C, int Hout, int Wout, const int32_t* bounds_h,
+                                      const int32_t* kk_h, int ksize_h, const int32_t* bounds_v, const int32_t* kk_v, int ksize_v,
+                                      int ct, int cl, int crop_h, int crop_w, int normalize, uint8_t* tmp, float* out, uint8_t* out_u8,
+                                      void* stream);
+int showo_images_to_uint8(const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);
+int showo_mask_downsample_threshold(const float* mask, int S, int s_out, uint8_t* out, float* values, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -454,6 +454,29 @@ def make_clip():
     print("clip_vision.npz written")
 
 
+def make_image_ops():
+    """image_transform: installed Pillow (what torchvision's Resize calls) vs the oracle restatement; fixture for the GPU test"""
+    from PIL import Image
+    rs = np.random.RandomState(9)
+    img = rs.randint(0, 256, size=(167, 250, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:167, 0:250]
+    img[..., 1] = (127 + 120 * np.sin(xx / 11.0) * np.cos(yy / 19.0)).astype(np.uint8)
+    R = 128
+    ow, oh = int(R * 250 / 167), R
+    ref = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BICUBIC))
+    ct, cl = int(round((oh - R) / 2.0)), int(round((ow - R) / 2.0))
+    t, u8 = O.image_transform_np(img, R, True)
+    assert np.array_equal(u8, ref[ct:ct + R, cl:cl + R]), "oracle resize != PIL"
+    for (H, W, C, w2, h2) in [(300, 451, 3, 256, 170), (64, 64, 3, 256, 256), (123, 77, 1, 40, 64), (97, 400, 3, 256, 62)]:
+        im = rs.randint(0, 256, size=(H, W, C)).astype(np.uint8)
+        pil = Image.fromarray(im if C == 3 else im[..., 0], "RGB" if C == 3 else "L").resize((w2, h2), Image.BICUBIC)
+        assert np.array_equal(np.asarray(pil).reshape(h2, w2, C), O.pil_resize_bicubic_np(im, w2, h2)), (H, W, C)
+    import PIL
+    np.savez_compressed(os.path.join(GOLD, "image_ops.npz"), img=img, resolution=R, pil_bytes=u8, tensor=t.numpy(),
+                        pillow_version=np.array(PIL.__version__))
+    print("image_ops.npz written (oracle resize == Pillow", PIL.__version__, "byte for byte)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
@@ -465,6 +488,8 @@ if __name__ == "__main__":
         make_tiny_showo()
     if a.only in ("", "magvit"):
         make_magvit()
+    if a.only in ("", "image"):
+        make_image_ops()
     if a.only in ("", "clip"):
         make_clip()
     if a.only in ("", "prompting"):

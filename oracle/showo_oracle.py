@@ -505,3 +505,94 @@ def clip_vision_features(sd, cfg, images, select_layer=-2):
 def mm_projector(sd, x):
     """nn.Sequential(Linear, GELU(), Linear) (modeling_showo.py:48-53); sd keys 0.weight, 0.bias, 2.weight, 2.bias"""
     return F.linear(F.gelu(F.linear(x, sd["0.weight"], sd["0.bias"])), sd["2.weight"], sd["2.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# Image pre / post-processing (training/utils.py:178-185 image_transform -> torchvision Resize(BICUBIC) on a PIL image ->
+# PIL.Image.resize; third-party: Pillow src/libImaging/Resample.c, restated here and asserted against the installed Pillow)
+# ----------------------------------------------------------------------------------------------
+def _pil_bicubic(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc: bounds int32 [out,2] (first tap, tap count), kk int32 [out,ksize]"""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = sum(w)  # left-to-right double accumulation like the C loop
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        for x, v in enumerate(w):
+            kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_resize_bicubic_np(img, out_w, out_h):
+    """img uint8 [H,W,C] -> uint8 [out_h,out_w,C]: horizontal pass, uint8, vertical pass (ImagingResampleInner)"""
+    img = np.asarray(img)
+    H, W, C = img.shape
+    cur = img.astype(np.int64)
+    if out_w != W:
+        b, kk = pil_bicubic_coeffs(W, out_w)
+        nxt = np.empty((H, out_w, C), np.int64)
+        for xo in range(out_w):
+            x0, n = b[xo]
+            acc = (1 << 21) + (cur[:, x0:x0 + n, :] * kk[xo, :n].astype(np.int64)[None, :, None]).sum(1)
+            nxt[:, xo, :] = np.clip(acc >> 22, 0, 255)
+        cur = nxt
+    if out_h != H:
+        b, kk = pil_bicubic_coeffs(H, out_h)
+        nxt = np.empty((out_h, cur.shape[1], C), np.int64)
+        for yo in range(out_h):
+            y0, n = b[yo]
+            acc = (1 << 21) + (cur[y0:y0 + n] * kk[yo, :n].astype(np.int64)[:, None, None]).sum(0)
+            nxt[yo] = np.clip(acc >> 22, 0, 255)
+        cur = nxt
+    return cur.astype(np.uint8)
+
+
+def image_transform_np(img, resolution=256, normalize=True):
+    """image_transform (training/utils.py:178-185) on a uint8 [H,W,C] array: Resize(shorter side -> resolution, bicubic,
+    torchvision size rule long = int(resolution * long / short)), CenterCrop, ToTensor, Normalize(0.5, 0.5) -> fp32 [C,R,R]"""
+    img = np.asarray(img)
+    H, W = img.shape[:2]
+    if W <= H:
+        ow, oh = resolution, int(resolution * H / W)
+    else:
+        oh, ow = resolution, int(resolution * W / H)
+    r = pil_resize_bicubic_np(img, ow, oh) if (ow, oh) != (W, H) else img
+    ct, cl = int(round((oh - resolution) / 2.0)), int(round((ow - resolution) / 2.0))
+    r = r[ct:ct + resolution, cl:cl + resolution]
+    t = torch.from_numpy(np.ascontiguousarray(r)).permute(2, 0, 1).float().div(255)
+    if normalize:
+        t = t.sub(0.5).div(0.5)
+    return t, r
+
+
+def images_to_uint8_np(x):
+    """inference_t2i.py:157-159: clamp((x + 1) / 2, 0, 1) * 255 -> NHWC uint8 (truncation)"""
+    y = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0) * 255.0
+    return y.permute(0, 2, 3, 1).numpy().astype(np.uint8)
+
+
+def inpainting_token_mask(mask01, resolution):
+    """inference_t2i.py:100-108: mask fp32 [1,R,R] in [0,1] -> bool [(R/16)^2] (bicubic down-sample, >= 0.5)"""
+    m = F.interpolate(mask01[None], size=resolution // 16, mode="bicubic")
+    return (m >= 0.5).reshape(-1), m.reshape(-1)

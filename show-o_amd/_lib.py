@@ -110,6 +110,10 @@ _PROTOS = {
     "showo_projector_create": [c_i, c_i, c_i, c_p],
     "showo_projector_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_projector_forward": [c_p, c_p, c_i, c_p, c_p],
+    "showo_image_resize_crop_normalize": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p,
+                                          c_p, c_p],
+    "showo_images_to_uint8": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "showo_mask_downsample_threshold": [c_p, c_i, c_i, c_p, c_p, c_p],
     "showo_sample_topk": [c_p, c_i, c_i, c_f, c_p, c_u64, c_i, c_p, c_p],
     "showo_engine_decode_sample": [c_p, c_p, c_i, c_p, c_p, c_i, c_f, c_p, c_u64, c_i, c_i, c_p],
     "showo_vq_create": [c_p, C.POINTER(c_p)],
