@@ -75,21 +75,31 @@ del model, vq
 torch.cuda.empty_cache()
 
 # ---------------------------------------------------------------- cfg4: mmu w_clip_vit, 631 prompt embeds, 100 new tokens, top_k=1
+# the whole flow of inference_mmu.py:96-146 after image decoding: CLIP ViT-L/14-336 tower (random-init weights of the true
+# architecture) -> mm_projector -> embed the text ids -> splice -> mmu_vit mask -> prefill + KV-cached decode
 model = build_model(True, 1, 768)
+tower = showo_amd.CLIPVisionTower("synthetic", config=Wt.CLIP_L336, state_dict=O.to_torch(Wt.make_clip_state(Wt.CLIP_L336, seed=22)),
+                                  max_batch=1).cuda()
 emb_tab = model.showo.model.embed_tokens.weight
 Lp = 1 + 28 + 1 + 576 + 1 + 24
-times = []
+times, t_clip, t_first = [], [], []
 for img_i in range(4):  # 4 images = 4 independent batch-1 decodes (reference semantics, modeling_showo.py:204,229)
     g = torch.Generator(device="cuda").manual_seed(3 + img_i)
-    feats = torch.randn(1, 576, 1024, device="cuda", generator=g)
+    pixels = torch.randn(1, 3, 336, 336, device="cuda", generator=g)  # CLIPImageProcessor output (host side, not timed)
+    ids = torch.randint(0, 50256, (1, Lp - 576), device="cuda", generator=g)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     with torch.no_grad():
-        img_emb = model.mm_projector(feats)  # torch parameter container (the CLIP tower itself is out of scope)
-        txt = emb_tab[torch.randint(0, 50256, (1, Lp - 576), device="cuda", generator=g)]
+        img_emb = model.mm_projector(tower(pixels))
+        txt = emb_tab[ids]
         emb = torch.cat([txt[:, :30], img_emb, txt[:, 30:]], dim=1)
     am = P.create_attention_mask_for_mmu_vit(emb, system_prompt_len=28)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    first = model.mmu_generate(input_embeddings=emb, attention_mask=am[0], max_new_tokens=1, top_k=1)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
     toks = model.mmu_generate(input_embeddings=emb, attention_mask=am[0], max_new_tokens=100, top_k=1)
-    torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-    assert len(toks) == 100 and all(0 <= int(t) < d.vocab for t in toks)
-t = float(np.mean(times[1:]))
-print(f"cfg4 mmu w_clip_vit: prompt {Lp} embeds + 100 new tokens (KV cache): {t*1e3:.1f} ms per image -> {100 / t:.0f} tokens/s")
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    t_clip.append(t1 - t0); t_first.append(t2 - t1); times.append(t3 - t2)
+    assert len(toks) == 100 and all(0 <= int(t) < d.vocab for t in toks) and int(toks[0]) == int(first[0])
+t, tc, tf = float(np.mean(times[1:])), float(np.mean(t_clip[1:])), float(np.mean(t_first[1:]))
+print(f"cfg4 mmu w_clip_vit: CLIP ViT-L/14-336 + mm_projector + splice {tc*1e3:.1f} ms; prefill of {Lp} embeds -> first token {tf*1e3:.1f} ms "
+      f"(time to first token {1e3*(tc+tf):.1f} ms); {Lp} embeds + 100 new tokens (KV cache): {t*1e3:.1f} ms per image -> {100 / t:.0f} tokens/s")
