@@ -74,6 +74,9 @@ struct showo_engine {
     // hipGraph replay of the decode step: position and last-prompt-row intervals in device memory
     int* pos_dev = nullptr;
     int32_t* last_iv_dev = nullptr;
+    // second stream for the two independent branches of a Phi block (attention branch | fc1): see run_layers
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fc1 = nullptr;
     // hipGraph replay of the denoise step
     int* step_dev = nullptr;
     float* sched_dev = nullptr;

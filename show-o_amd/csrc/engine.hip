@@ -150,6 +150,9 @@ extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** 
 
 extern "C" void showo_engine_destroy(showo_engine* e) {
     if (!e) return;
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_fc1) hipEventDestroy(e->ev_fc1);
+    if (e->side) hipStreamDestroy(e->side);
     for (void* p : e->allocs) hipFree(p);
     delete e;
 }
@@ -228,6 +231,15 @@ static KVDest kv_decode_cache(showo_engine* e) {
     return KVDest{e->kcache, e->vtcache, (int64_t)e->nH * e->cache_cap * 64, (int64_t)e->nH * 64 * e->cache_cap, e->cache_cap, e->cache_cap};
 }
 
+static bool layer_overlap_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = getenv("SHOWO_LAYER_OVERLAP");
+        v = env ? (atoi(env) != 0) : 0;
+    }
+    return v != 0;
+}
+
 static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
                       const float* dense, hipStream_t s) {
     const int H = e->H, F = e->F, nH = e->nH;
@@ -248,11 +260,32 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         }
         return 0;
     }
+    bool overlap = T >= 1024 && layer_overlap_enabled();
+    if (overlap && !e->side) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        hipStreamIsCapturing(s, &cs);
+        if (cs != hipStreamCaptureStatusNone) overlap = false;  // never create the stream inside a capture
+        else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+                 hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&e->ev_fc1, hipEventDisableTiming) != hipSuccess)
+            return set_error_msg(7, "engine: cannot create the side stream");
+    }
     for (int li = 0; li < e->nL; ++li) {
         showo::Layer& l = e->layers[li];
         bf16_t* Kd = kv.k + li * kv.k_lstride;
         bf16_t* Vd = kv.vt + li * kv.v_lstride;
         TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
+        // Phi's block is parallel (phi.py:774-790): the attention branch (qkv -> attention -> dense) and fc1 both read the
+        // same LayerNorm output.  fc1 goes to a second stream so that its tiles fill the CUs the other branch leaves idle
+        // (partial last rounds of the GEMMs, the latency-bound attention kernel); fc2 follows on the main stream once both
+        // dense (x += ...) and fc1 are done.  Layer 0 stays sequential: GEMM shapes are auto-tuned on first use, undisturbed.
+        const bool fork = overlap && li > 0;
+        if (fork) {
+            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
+            SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, e->side));
+            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
+        }
         if (T >= 256 && e->cfg.rotary_dim == 32) {
             // prefill / t2i: one kernel (the projection's epilogue normalises, rotates and relayouts the fp32 accumulators)
             TRY(showo_gemm_qkv_bf16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
@@ -264,7 +297,8 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         }
         TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
         TRY(showo_gemm_bf16(e->attn, H, l.wd, H, l.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
-        TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, s));
+        if (fork) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
+        else TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, s));
         TRY(showo_gemm_bf16(e->ffn, F, l.w2, F, l.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
     }
     return 0;
