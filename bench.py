@@ -217,7 +217,10 @@ def main():
             "config": {"workload": "BASELINE cfg2: configs/showo_demo.yaml t2i 256x256, batch 8 prompts, CFG 5.0 (forward on [16,387]), "
                                    "18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M",
                        "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
-                       "algorithmic_tflop_per_image": 38.4, "end_to_end_algorithmic_tflops": value * 38.4},
+                       "algorithmic_tflop_per_image": 38.4, "end_to_end_algorithmic_tflops": value * 38.4,
+                       # SURVEY.md §8d counts the reference's flops (38.4 TFLOP per image, text rows recomputed every step); the
+                       # path executes fewer (prefix reuse), so the whole-job rate in the reference's units is also given
+                       "end_to_end_algorithmic_frac_of_mfma_peak": value * 38.4 / 2500.0},
             "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM, all epilogues: fused-QKV / dense / fc1+GELU / fc2 / lm_head rows)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
