@@ -166,9 +166,9 @@ class _ShowoTrainFn(torch.autograd.Function):
 
 class _MMProjector(nn.Sequential):
     """`model.mm_projector` (reference modeling_showo.py:48-53): same parameters and state-dict keys (mm_projector.0.*,
-    mm_projector.2.*).  Without autograd (inference_mmu.py:134) the forward runs on the HIP projector (two MFMA GEMMs + exact
-    GELU, csrc/clip_engine.hip); when a gradient is required (the w_clip_vit trainer fine-tunes these 6 M parameters) it stays
-    on torch autograd -- the backward of this block is not on the HIP path yet."""
+    mm_projector.2.*).  The forward runs on the HIP projector (two MFMA GEMMs + exact GELU, csrc/clip_engine.hip) whenever the
+    module is in eval() mode (inference_mmu.py:134) or no gradient is required; while it is being TRAINED (the w_clip_vit trainer
+    fine-tunes these 6 M parameters) it stays on torch autograd -- the backward of this block is not on the HIP path yet."""
 
     def __init__(self, din, dout):
         super().__init__(nn.Linear(din, dout), nn.GELU(), nn.Linear(dout, dout))
@@ -187,8 +187,9 @@ class _MMProjector(nn.Sequential):
             pass
 
     def forward(self, x):
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if need_grad:
+        # torch autograd only while TRAINING this block (module in train() mode, grad enabled, something requires grad); an
+        # eval() model always takes the HIP forward, with or without an enclosing no_grad
+        if self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return super().forward(x)
         if not x.is_cuda:
             raise RuntimeError("show-o_amd runs the projector on the GPU (no CPU path exists)")

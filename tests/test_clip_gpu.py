@@ -101,9 +101,12 @@ def test_mm_projector_hip_forward_vs_torch_module_golden():
     print(f"[parity] mm_projector: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
     assert tuple(out.shape) == (1, 37, 192) and rrms < 1e-2 and rmax < 3e-2
     assert list(proj.state_dict()) == ["0.weight", "0.bias", "2.weight", "2.bias"]
-    # with autograd on, the block stays differentiable (torch path) and agrees with the HIP forward
-    y = proj(x)
+    # in train() mode with autograd on, the block stays differentiable (torch path) and agrees with the HIP forward;
+    # in eval() mode the HIP forward is taken even without no_grad
+    y = proj.train()(x)
     assert y.requires_grad and util.relerr(y.detach(), ref)[1] < 1e-5
+    y2 = proj.eval()(x.view(1, 37, 128))
+    assert not y2.requires_grad and torch.equal(y2, out)
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             proj(x.cpu())
