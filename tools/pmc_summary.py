@@ -20,8 +20,8 @@ def load(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = re.sub(r"\(.*", "", r["Kernel_Name"])
-            name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+            name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+            name = re.sub(r"\(.*", "", name)
             a = acc[name]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
