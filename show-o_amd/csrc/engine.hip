@@ -525,14 +525,16 @@ extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const f
     if (mask) {
         TRY(showo_mask_compress(mask, e->iv, e->flag, 1, L, L, s));
         iv = e->iv; flag = e->flag;
+    } else if (e->ext_iv) {  // caller-built intervals (showo_engine_use_intervals, e.g. from showo_mask_mmu_vit)
+        iv = e->ext_iv; flag = e->ext_flag;
     }
     TRY(run_layers(e, 1, L, 0, kv_decode_cache(e), iv, flag, mask, s));
     e->prompt_len = L;
     e->cache_len = L;
-    if (mask) {
+    if (iv) {
         int32_t f = 0;
-        SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv, e->iv + (int64_t)(L - 1) * 4, 16, hipMemcpyDeviceToHost, s));
-        SHOWO_CHECK_HIP(hipMemcpyAsync(&f, e->flag, 4, hipMemcpyDeviceToHost, s));
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv, iv + (int64_t)(L - 1) * 4, 16, hipMemcpyDeviceToHost, s));
+        if (flag) SHOWO_CHECK_HIP(hipMemcpyAsync(&f, flag, 4, hipMemcpyDeviceToHost, s));
         SHOWO_CHECK_HIP(hipStreamSynchronize(s));
         if (f) return set_error_msg(6, "decode: prompt mask is not interval-representable; KV-cached decode unsupported");
     } else {

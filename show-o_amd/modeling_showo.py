@@ -481,10 +481,17 @@ class Showo(PretrainedMixin, nn.Module):
             L = idx.shape[1]
             ids = idx.to(torch.int64).contiguous()
             emb = None
-        mask = None if attention_mask is None else attention_mask.detach().float().reshape(1, 1, L, L).contiguous()
+        from .prompting_utils import IntervalMask
+        if isinstance(attention_mask, IntervalMask):  # prompting_utils.intervals_for_mmu / _mmu_vit: no [1,1,L,L] tensor at all
+            mask = self._use_mask(eng, attention_mask)
+        else:
+            mask = None if attention_mask is None else attention_mask.detach().float().reshape(1, 1, L, L).contiguous()
         logits = torch.empty((self.vocab_size,), dtype=torch.float32, device=dev)
         tok = torch.empty((1,), dtype=torch.int64, device=dev)
-        _lib.call("showo_engine_prefill", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), L, _lib.ptr(logits), _lib.stream())
+        try:
+            _lib.call("showo_engine_prefill", eng, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), L, _lib.ptr(logits), _lib.stream())
+        finally:
+            _lib.call("showo_engine_use_intervals", eng, None, None)
         # logits / temperature does not change the arg-max for temperature > 0; top_k=1 makes the reference's multinomial a
         # deterministic arg-max.  The first token comes from the prefill logits; the continuation runs in
         # chunks of `chunk` steps entirely on the device (embed -> 24 layers on the KV cache -> lm_head -> arg-max), one

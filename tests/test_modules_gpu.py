@@ -138,6 +138,9 @@ def test_tiny_mmu_generate_matches_reference_tokens():
             long_ref = [int(t) for t in toks2]
         else:
             assert [int(t) for t in toks2] == long_ref and len(long_ref) == 40
+    # the same prompt with on-device visibility intervals instead of the dense [1,1,L,L] mask
+    ivm = util.pkg().prompting_utils.intervals_for_mmu(dev(g["ids"]), eoi_id=d.eoi_id)
+    assert [int(t) for t in m.mmu_generate(dev(g["ids"]), attention_mask=ivm, max_new_tokens=40, top_k=1)] == long_ref
     first = long_ref[3]
     stopped = m.mmu_generate(dev(g["ids"]), attention_mask=dev(g["mask"]), max_new_tokens=40, top_k=1, eot_token=first)
     assert [int(t) for t in stopped] == long_ref[:long_ref.index(first) + 1]  # stops right after <eot> like the reference
