@@ -345,3 +345,28 @@ def test_on_device_mask_builders_match_reference_masks():
                                    timesteps=steps, guidance_scale=float(g2["guidance"]), config=util.gen_config(d), _exp_noise=en,
                                    _uniform=un))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_full_size_t2i_generate_is_reproducible_and_graph_equals_eager():
+    """BASELINE cfg2 shape (batch 8, CFG, [16,387], 18 steps) on random-init full-size weights: the same seed gives the same 2048
+    token ids run after run, and the hipGraph replay / the recompute-the-prefix path give the same ids as the default path
+    (size-independent property: no atomics, fixed reduction orders, tile height does not change the K-accumulation order)"""
+    P = util.pkg()
+    torch.manual_seed(0)
+    m = P.synthetic.random_init_showo(max_batch=16, max_seq=387, ln_jitter=True).eval()
+    uni = P.synthetic.prompting(128)
+    ic, iu, mask = P.synthetic.t2i_inputs(uni, 8, 256, m.mask_token_id)
+    outs = []
+    for kw in (dict(), dict(), dict(use_graph=1), dict(reuse_prefix=False)):
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        outs.append(m.t2i_generate(input_ids=ic.clone(), uncond_input_ids=iu, attention_mask=mask, temperature=1.0, timesteps=18,
+                                   guidance_scale=5.0, generator=gen, config=P.gen_config(), **kw))
+    assert tuple(outs[0].shape) == (8, 256) and int(outs[0].min()) >= 0 and int(outs[0].max()) < 8192
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    agree = float((outs[0] == outs[3]).float().mean())
+    print(f"[parity] full-size t2i: prefix reuse vs recompute token agreement {agree:.4f}")
+    assert agree == 1.0
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    other = m.t2i_generate(input_ids=ic.clone(), uncond_input_ids=iu, attention_mask=mask, temperature=1.0, timesteps=18,
+                           guidance_scale=5.0, generator=gen, config=P.gen_config())
+    assert not torch.equal(other, outs[0])
