@@ -17,3 +17,4 @@ from .training_utils import mask_or_random_replace_tokens  # noqa: F401
 from .clip_encoder import CLIPVisionTower  # noqa: F401
 from . import image_utils  # noqa: F401
 from .image_utils import image_transform  # noqa: F401
+from . import synthetic  # noqa: F401
