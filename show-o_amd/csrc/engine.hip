@@ -345,6 +345,7 @@ static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, 
 extern "C" int showo_engine_forward(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int B, int L,
                                     float* logits, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (B == 0 || L == 0) return 0;  // empty batch: nothing to compute (the reference returns an empty logits tensor)
     TRY(hidden(e, ids, embeds, mask, B, L, s));
     return head_rows(e, nullptr, B * L, 0, e->V, logits, s);
 }

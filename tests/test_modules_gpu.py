@@ -370,3 +370,25 @@ def test_full_size_t2i_generate_is_reproducible_and_graph_equals_eager():
     other = m.t2i_generate(input_ids=ic.clone(), uncond_input_ids=iu, attention_mask=mask, temperature=1.0, timesteps=18,
                            guidance_scale=5.0, generator=gen, config=P.gen_config())
     assert not torch.equal(other, outs[0])
+
+
+def test_forward_edge_sizes_empty_batch_and_maximum_positions():
+    """edge cases: an empty batch returns empty logits; a sequence of max_position_embeddings = 2048 tokens (the last RoPE row, 32
+    key tiles, L not a multiple of the 128-row attention block is covered elsewhere) matches the oracle; longer ones are refused"""
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd, max_batch=2, max_seq=2048)
+    out = m(torch.zeros((0, 27), dtype=torch.int64, device="cuda"))
+    assert tuple(out.shape) == (0, 27, d.vocab)
+    torch.manual_seed(1)
+    L = 2048
+    ids = torch.randint(0, d.llm_vocab, (1, L))
+    mask = O.mask_t2i(ids, d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False)  # plain causal
+    got = m(ids.cuda(), attention_mask=mask.cuda())
+    want = O.showo_logits(O.to_torch(sd), d, ids, attention_mask=mask)
+    rmax, rrms = util.relerr(got, want)
+    print(f"[parity] tiny forward at L = 2048 (max positions): rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rrms < 1e-2 and rmax < 3e-2
+    rows = [0, 1, 1023, 2046, 2047]
+    assert util.relerr(got[:, rows], want[:, rows])[1] < 1e-2  # first / last positions individually
+    with pytest.raises((RuntimeError, ValueError)):
+        m(torch.zeros((1, 2049), dtype=torch.int64, device="cuda"))
