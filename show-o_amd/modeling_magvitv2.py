@@ -116,6 +116,27 @@ class _LFQBuffers(nn.Module):
         self.e_dim = codebook_dim
         self.codebook_size = 2 ** codebook_dim
 
+    def get_indices(self, z_q):
+        """reference :201-206: z_q [B,C,h,w] -> ids int64 [B,1,h,w], bit of channel c (MSB first) = (z_q[c] > 0)"""
+        if not z_q.is_cuda:
+            raise RuntimeError("show-o_amd quantizes on the GPU (no CPU path exists)")
+        B, C, h, w = z_q.shape
+        z = z_q.detach().float().contiguous()
+        ids = torch.empty((B, h * w), dtype=torch.int64, device=z.device)
+        _lib.call("showo_lfq_pack_nchw", _lib.ptr(z), _lib.ptr(ids), B, C, h * w, _lib.stream())
+        return ids.view(B, 1, h, w)
+
+    def get_codebook_entry(self, indices, shape=None):
+        """reference :208-221: ids [B,n] -> z_q fp32 [B,C,h,w] of +-1"""
+        if not indices.is_cuda:
+            raise RuntimeError("show-o_amd de-quantizes on the GPU (no CPU path exists)")
+        b, n = indices.shape
+        h, w = (int(math.sqrt(n)), int(math.sqrt(n))) if shape is None else shape
+        ids = indices.to(torch.int64).contiguous()
+        zq = torch.empty((b, self.e_dim, h, w), dtype=torch.float32, device=ids.device)
+        _lib.call("showo_lfq_unpack_nchw", _lib.ptr(ids), _lib.ptr(zq), b, self.e_dim, h * w, _lib.stream())
+        return zq
+
 
 class MAGVITv2(PretrainedMixin, nn.Module):
     ENC = dict(ch_mult=(1, 2, 2, 4, 4), num_res_blocks=(4, 3, 4, 3, 4))

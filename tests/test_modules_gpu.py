@@ -392,3 +392,23 @@ def test_forward_edge_sizes_empty_batch_and_maximum_positions():
     assert util.relerr(got[:, rows], want[:, rows])[1] < 1e-2  # first / last positions individually
     with pytest.raises((RuntimeError, ValueError)):
         m(torch.zeros((1, 2049), dtype=torch.int64, device="cuda"))
+
+
+def test_quantizer_module_methods_match_reference_golden():
+    """`vq_model.quantize.get_indices / get_codebook_entry` (reference modeling_magvitv2.py:201-221) on the module, with the
+    reference's return shapes; known-answer latents incl. +-0, +-1e-9, denormals"""
+    g = util.golden("lfq_kat.npz")
+    with torch.device("meta"):
+        v = util.pkg().MAGVITv2()
+    q = util.pkg().modeling_magvitv2._LFQBuffers(13).cuda()
+    z = dev(g["z"])
+    ids = q.get_indices(z)
+    B, Cc, h, w = z.shape
+    assert tuple(ids.shape) == (B, 1, h, w) and ids.dtype == torch.int64
+    assert np.array_equal(ids.reshape(B, -1).cpu().numpy(), g["ids"])
+    back = q.get_codebook_entry(dev(g["ids"][:, :16]))
+    assert tuple(back.shape) == (B, 13, 4, 4) and np.array_equal(back.cpu().numpy(), g["back"])
+    back2 = q.get_codebook_entry(dev(g["ids"][:, :8]), shape=(2, 4))
+    assert tuple(back2.shape) == (B, 13, 2, 4)
+    assert torch.equal(q.embedding[dev(g["ids"][:, :8])].permute(0, 2, 1).reshape(B, 13, 2, 4), back2)  # = embedding lookup
+    assert isinstance(v.quantize, type(q))
