@@ -241,3 +241,28 @@ def test_clip_tower_loads_a_local_checkpoint_directory(tmp_path):
             t(torch.zeros(1, 3, 56, 56))
     with pytest.raises(EnvironmentError):
         util.pkg().CLIPVisionTower(str(tmp_path / "missing"))
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/showo_hip.h compiles as C99 (no C++-isms), and a C program linked against
+    libshowo_hip.so resolves the entry points and gets an error code + message (not a crash) for a bad call without a GPU"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(util.ROOT, "include", "showo_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "showo_hip.h"\n'
+                   'int main(void) {\n'
+                   '  if (showo_abi_version() != 1) return 2;\n'
+                   '  int rc = showo_sample_topk(0, 0, 0, 1.0f, 0, 0, 0, 0, 0);   /* null arguments: refused, no launch */\n'
+                   '  printf("%d %s\\n", rc, showo_last_error());\n'
+                   '  return rc != 0 ? 0 : 3;\n}\n')
+    lib = util.lib().LIB_PATH
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.dirname(hdr), str(src), "-o", str(exe), lib,
+                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "sample_topk" in out.stdout
