@@ -431,6 +431,10 @@ int showo_projector_create(int in_dim, int out_dim, int max_rows, showo_projecto
 void showo_projector_destroy(showo_projector* p);
 int showo_projector_load(showo_projector* p, const char* key, const float* src, int64_t n, void* stream);
 int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream);
+/* backward of the LAST showo_projector_forward (same T rows): dout fp32 [T,out] -> gw0 fp32 [out,in], gb0 [out], gw1 [out,out],
+ * gb1 [out], dx fp32 [T,in] (optional).  Autograd of nn.Sequential(Linear, GELU(), Linear) (training/train_w_clip_vit.py trains it). */
+int showo_projector_backward(showo_projector* p, const float* dout, int T, float* dx, float* gw0, float* gb0, float* gw1, float* gb1,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image pre / post-processing on the device.

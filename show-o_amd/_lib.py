@@ -110,6 +110,7 @@ _PROTOS = {
     "showo_projector_create": [c_i, c_i, c_i, c_p],
     "showo_projector_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_projector_forward": [c_p, c_p, c_i, c_p, c_p],
+    "showo_projector_backward": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "showo_image_resize_crop_normalize": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p,
                                           c_p, c_p],
     "showo_images_to_uint8": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],

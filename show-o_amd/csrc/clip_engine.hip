@@ -289,11 +289,18 @@ struct showo_projector {
     bf16_t *w0 = nullptr, *w1 = nullptr, *xb = nullptr, *act = nullptr;
     float *b0 = nullptr, *b1 = nullptr, *f = nullptr;
     std::set<std::string> loaded;
+    // backward workspace (allocated by the first showo_projector_backward): transposed weight images, bf16 gradients, transposes
+    bf16_t *w0T = nullptr, *w1T = nullptr, *dout16 = nullptr, *dact16 = nullptr, *df16 = nullptr, *tA = nullptr, *tB = nullptr, *dx16 = nullptr;
+    float* colpart = nullptr;
+    bool wT_valid = false;
+    int last_T = 0;
 };
 
 extern "C" void showo_projector_destroy(showo_projector* p) {
     if (!p) return;
-    for (void* q : {(void*)p->w0, (void*)p->w1, (void*)p->xb, (void*)p->act, (void*)p->b0, (void*)p->b1, (void*)p->f})
+    for (void* q : {(void*)p->w0, (void*)p->w1, (void*)p->xb, (void*)p->act, (void*)p->b0, (void*)p->b1, (void*)p->f, (void*)p->w0T,
+                    (void*)p->w1T, (void*)p->dout16, (void*)p->dact16, (void*)p->df16, (void*)p->tA, (void*)p->tB, (void*)p->dx16,
+                    (void*)p->colpart})
         if (q) hipFree(q);
     delete p;
 }
@@ -326,7 +333,7 @@ extern "C" int showo_projector_load(showo_projector* p, const char* key, const f
     else if (k == "2.weight") rc = cast_w(p->w1, src, n, D * D, s);
     else if (k == "2.bias") rc = copy_f32(p->b1, src, n, D, s);
     else return set_error_msg(3, "projector_load: unknown key");
-    if (rc == 0) p->loaded.insert(k);
+    if (rc == 0) { p->loaded.insert(k); p->wT_valid = false; }
     return rc;
 }
 
@@ -341,6 +348,61 @@ extern "C" int showo_projector_forward(showo_projector* p, const float* x, int T
     TRY(showo_gemm_bf16(p->xb, I, p->w0, I, p->b0, 0, p->f, D, nullptr, 0, T, D, I, SHOWO_EPI_F32, s));
     act_kernel<1><<<dim3(1024), dim3(256), 0, s>>>(p->f, p->act, (int64_t)T * D);
     TRY(showo_gemm_bf16(p->act, D, p->w1, D, p->b1, 0, out, D, nullptr, 0, T, D, D, SHOWO_EPI_F32, s));
+    SHOWO_CHECK_HIP(hipGetLastError());
+    p->last_T = T;
+    return 0;
+}
+
+namespace {
+// df = d_act * gelu'(f), exact GELU: gelu'(v) = Phi(v) + v phi(v); fp32 pre-activation saved by the forward
+__global__ void dgelu_erf_kernel(const bf16_t* __restrict__ da, const float* __restrict__ f, bf16_t* __restrict__ df, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = f[i];
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+        df[i] = f2bf(bf2f(da[i]) * (cdf + v * pdf));
+    }
+}
+}  // namespace
+
+// Backward of the LAST showo_projector_forward (same x, T): given dout fp32 [T,out] it writes the parameter gradients
+// gw0 fp32 [out,in], gb0 [out], gw1 [out,out], gb1 [out] and (optional) dx fp32 [T,in].  Same machinery as the trainer
+// (train_engine.hip): everything on the NT GEMM with transposed bf16 images, bias gradients as fixed-order column sums.
+extern "C" int showo_projector_backward(showo_projector* p, const float* dout, int T, float* dx, float* gw0, float* gb0,
+                                        float* gw1, float* gb1, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!p || !dout || !gw0 || !gb0 || !gw1 || !gb1) return set_error_msg(1, "projector_backward: null argument");
+    if (T <= 0 || T != p->last_T) return set_error_msg(1, "projector_backward: run showo_projector_forward on the same rows first");
+    const int I = p->in_dim, D = p->out_dim;
+    const int Tp = ((T + 63) / 64) * 64, Tm = ((p->max_rows + 63) / 64) * 64;
+    if (!p->w0T) {
+        const int64_t big = (int64_t)(D > I ? D : I) * Tm;
+        bool ok = hipMalloc((void**)&p->w0T, (size_t)I * D * 2) == hipSuccess && hipMalloc((void**)&p->w1T, (size_t)D * D * 2) == hipSuccess &&
+                  hipMalloc((void**)&p->dout16, (size_t)Tm * D * 2) == hipSuccess && hipMalloc((void**)&p->dact16, (size_t)Tm * D * 2) == hipSuccess &&
+                  hipMalloc((void**)&p->df16, (size_t)Tm * D * 2) == hipSuccess && hipMalloc((void**)&p->tA, (size_t)big * 2) == hipSuccess &&
+                  hipMalloc((void**)&p->tB, (size_t)big * 2) == hipSuccess && hipMalloc((void**)&p->dx16, (size_t)Tm * I * 2) == hipSuccess &&
+                  hipMalloc((void**)&p->colpart, (size_t)(Tm / 64 + 8) * (D > I ? D : I) * 4) == hipSuccess;
+        if (!ok) return set_error_msg(7, "projector_backward: hipMalloc failed");
+    }
+    if (!p->wT_valid) {  // transposed weight images for the two data-gradient GEMMs (remade when the weights change)
+        TRY(showo_transpose_bf16(p->w0, I, p->w0T, D, I, D, 0, nullptr, nullptr, 0, s));   // [out,in] -> [in,out]
+        TRY(showo_transpose_bf16(p->w1, D, p->w1T, D, D, D, 0, nullptr, nullptr, 0, s));
+        p->wT_valid = true;
+    }
+    TRY(showo_cast_f32_bf16(dout, p->dout16, (int64_t)T * D, s));
+    // second Linear: gb1 = colsum(dout), gw1 = dout^T act, d_act = dout W1
+    TRY(showo_transpose_bf16(p->dout16, D, p->tA, T, D, Tp, 0, p->colpart, gb1, 0, s));
+    TRY(showo_transpose_bf16(p->act, D, p->tB, T, D, Tp, 0, nullptr, nullptr, 0, s));
+    TRY(showo_gemm_bf16(p->tA, Tp, p->tB, Tp, nullptr, 0, gw1, D, nullptr, 0, D, D, Tp, SHOWO_EPI_F32, s));
+    TRY(showo_gemm_bf16(p->dout16, D, p->w1T, D, nullptr, 0, p->dact16, D, nullptr, 0, T, D, D, SHOWO_EPI_BF16, s));
+    dgelu_erf_kernel<<<dim3(1024), dim3(256), 0, s>>>(p->dact16, p->f, p->df16, (int64_t)T * D);
+    // first Linear: gb0 = colsum(df), gw0 = df^T x, dx = df W0
+    TRY(showo_transpose_bf16(p->df16, D, p->tA, T, D, Tp, 0, p->colpart, gb0, 0, s));
+    TRY(showo_transpose_bf16(p->xb, I, p->tB, T, I, Tp, 0, nullptr, nullptr, 0, s));
+    TRY(showo_gemm_bf16(p->tA, Tp, p->tB, Tp, nullptr, 0, gw0, I, nullptr, 0, D, I, Tp, SHOWO_EPI_F32, s));
+    if (dx) TRY(showo_gemm_bf16(p->df16, D, p->w0T, D, nullptr, 0, dx, I, nullptr, 0, T, I, D, SHOWO_EPI_F32, s));
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

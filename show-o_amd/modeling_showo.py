@@ -164,11 +164,38 @@ class _ShowoTrainFn(torch.autograd.Function):
         return (None, None, g_emb) + (None,) * 6 + tuple(grads)
 
 
+class _ProjectorFn(torch.autograd.Function):
+    """mm_projector as one autograd node: HIP forward, HIP backward (csrc/clip_engine.hip: showo_projector_backward).  The
+    backward re-runs the (two small GEMMs of the) forward on the saved input, so interleaved calls cannot mix up saved state."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w0, b0, w1, b1):
+        ctx.mod = mod
+        ctx.save_for_backward(x)
+        return mod._hip_forward(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, (x,) = ctx.mod, ctx.saved_tensors
+        din, dout_dim = mod._dims
+        mod._hip_forward(x)  # restores the engine's saved activations for exactly these rows
+        gout = g.detach().float().contiguous()
+        T = gout.numel() // dout_dim
+        dev = gout.device
+        gw0 = torch.empty((dout_dim, din), dtype=torch.float32, device=dev)
+        gb0 = torch.empty((dout_dim,), dtype=torch.float32, device=dev)
+        gw1 = torch.empty((dout_dim, dout_dim), dtype=torch.float32, device=dev)
+        gb1 = torch.empty((dout_dim,), dtype=torch.float32, device=dev)
+        dx = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        _lib.call("showo_projector_backward", mod._proj, _lib.ptr(gout), T, _lib.ptr(dx), _lib.ptr(gw0), _lib.ptr(gb0), _lib.ptr(gw1),
+                  _lib.ptr(gb1), _lib.stream())
+        return None, (None if dx is None else dx.to(x.dtype)), gw0, gb0, gw1, gb1
+
+
 class _MMProjector(nn.Sequential):
     """`model.mm_projector` (reference modeling_showo.py:48-53): same parameters and state-dict keys (mm_projector.0.*,
-    mm_projector.2.*).  The forward runs on the HIP projector (two MFMA GEMMs + exact GELU, csrc/clip_engine.hip) whenever the
-    module is in eval() mode (inference_mmu.py:134) or no gradient is required; while it is being TRAINED (the w_clip_vit trainer
-    fine-tunes these 6 M parameters) it stays on torch autograd -- the backward of this block is not on the HIP path yet."""
+    mm_projector.2.*).  Forward and backward run on the HIP projector (two MFMA GEMMs + exact GELU and their autograd,
+    csrc/clip_engine.hip): inference_mmu.py:134 as well as the w_clip_vit trainer that fine-tunes these 6 M parameters."""
 
     def __init__(self, din, dout):
         super().__init__(nn.Linear(din, dout), nn.GELU(), nn.Linear(dout, dout))
@@ -186,11 +213,7 @@ class _MMProjector(nn.Sequential):
         except Exception:
             pass
 
-    def forward(self, x):
-        # torch autograd only while TRAINING this block (module in train() mode, grad enabled, something requires grad); an
-        # eval() model always takes the HIP forward, with or without an enclosing no_grad
-        if self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return super().forward(x)
+    def _hip_forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("show-o_amd runs the projector on the GPU (no CPU path exists)")
         import ctypes as C
@@ -213,6 +236,11 @@ class _MMProjector(nn.Sequential):
         out = torch.empty(tuple(x.shape[:-1]) + (dout,), dtype=torch.float32, device=x.device)
         _lib.call("showo_projector_forward", self._proj, _lib.ptr(xin), T, _lib.ptr(out), _lib.stream())
         return out.to(x.dtype)
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _ProjectorFn.apply(self, x, self[0].weight, self[0].bias, self[2].weight, self[2].bias)
+        return self._hip_forward(x)
 
 
 class Showo(PretrainedMixin, nn.Module):

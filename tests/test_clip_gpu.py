@@ -101,12 +101,28 @@ def test_mm_projector_hip_forward_vs_torch_module_golden():
     print(f"[parity] mm_projector: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
     assert tuple(out.shape) == (1, 37, 192) and rrms < 1e-2 and rmax < 3e-2
     assert list(proj.state_dict()) == ["0.weight", "0.bias", "2.weight", "2.bias"]
-    # in train() mode with autograd on, the block stays differentiable (torch path) and agrees with the HIP forward;
-    # in eval() mode the HIP forward is taken even without no_grad
-    y = proj.train()(x)
-    assert y.requires_grad and util.relerr(y.detach(), ref)[1] < 1e-5
-    y2 = proj.eval()(x.view(1, 37, 128))
-    assert not y2.requires_grad and torch.equal(y2, out)
+    # autograd: HIP forward + HIP backward vs torch autograd of the same nn.Sequential (fp32, CPU)
+    ref_mod = torch.nn.Sequential(torch.nn.Linear(128, 192), torch.nn.GELU(), torch.nn.Linear(192, 192))
+    ref_mod.load_state_dict(O.to_torch(Wt.make_projector_state(128, 192, seed=23)))
+    xr = torch.from_numpy(g["proj_x"]).clone().requires_grad_(True)
+    torch.manual_seed(2)
+    gout = torch.randn(37, 192)
+    ref_mod(xr).backward(gout)
+    xg = x.clone().requires_grad_(True)
+    y = proj(xg)
+    assert y.requires_grad and util.relerr(y.detach(), ref)[1] < 1e-2
+    y.backward(gout.cuda())
+    for (n, p_), (_, q_) in zip(proj.named_parameters(), ref_mod.named_parameters()):
+        rmax, rrms = util.relerr(p_.grad, q_.grad)
+        print(f"[parity] mm_projector grad {n}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+        assert rrms < 1.5e-2 and rmax < 5e-2, n
+    assert util.relerr(xg.grad, xr.grad)[1] < 1.5e-2
+    # interleaved forwards before the backward do not disturb it (the backward re-runs its own forward)
+    proj.zero_grad()
+    y = proj(x.clone().requires_grad_(True))
+    proj(torch.randn(5, 128, device="cuda"))
+    y.backward(gout.cuda())
+    assert util.relerr(proj[0].weight.grad, ref_mod[0].weight.grad)[1] < 1.5e-2
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             proj(x.cpu())
