@@ -939,7 +939,7 @@ int launch3(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-int g_gemm_gn = 8, g_gemm_flags = 0;
+int g_gemm_gn = 4, g_gemm_flags = 0;  // 4 n-panels per XCD tile group: same-process sweep on the bench workload 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s
 unsigned long long* g_gemm_dbg = nullptr;
 
 template <int PH>
