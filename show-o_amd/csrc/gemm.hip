@@ -1190,7 +1190,7 @@ int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
 // (2 launches each, HIP events, ~1 ms) and the winner is cached.  Every height computes bit-identical results (same k order
 // per element), so the choice never changes numerics.  Skipped while the stream is being captured (the model is used), and
 // with SHOWO_GEMM_TUNE=0.  In-place residual launches are timed on a scratch output.
-std::map<std::tuple<int, int, int, int>, int> g_bm_cache;
+std::map<std::tuple<int, int, int, int>, int> g_bm_cache;  // (M, N, K, EPI) -> tile height | tile-group width << 16
 int g_gemm_tune = -1;
 
 template <int EPI>
@@ -1200,7 +1200,11 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     if (g_gemm_tune < 0) { const char* e = getenv("SHOWO_GEMM_TUNE"); g_gemm_tune = e ? atoi(e) : 1; }
     const auto key = std::make_tuple(g.M, g.N, g.K, EPI);
     auto it = g_bm_cache.find(key);
-    if (it != g_bm_cache.end()) return launch2p_h<EPI>(g, it->second, s);
+    if (it != g_bm_cache.end()) {
+        GemmArgs c = g;
+        if (it->second >> 16) c.gn = it->second >> 16;
+        return launch2p_h<EPI>(c, it->second & 0xffff, s);
+    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     if (!g_gemm_tune || capturing || (int64_t)g.M * g.N < ((int64_t)1 << 20)) return launch2p_h<EPI>(g, pick_bm(g.M, g.N), s);
@@ -1232,10 +1236,32 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     }
     for (int ci = 0; ci < 5; ++ci)
         if (cand_ms[ci] < best_ms) { best_ms = cand_ms[ci]; best = cand[ci]; }
+    // second dimension, at the chosen height: n-panels per XCD tile group (L2 / Infinity-Cache locality of the co-resident tiles).
+    // Measured on the bench workload the better of {4, 8} differs from box to box (+1.7 % / -0.6 %), hence per shape, per process.
+    int best_gn = g.gn;
+    {
+        const int gns[2] = {4, 8};
+        float gn_ms[2] = {1e30f, 1e30f};
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int gi = 0; gi < 2; ++gi) {
+                t.gn = gns[gi];
+                int rc = launch2p_h<EPI>(t, best, s);
+                (void)hipEventRecord(e0, s);
+                for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, best, s);
+                (void)hipEventRecord(e1, s);
+                if (rc || hipEventSynchronize(e1) != hipSuccess) continue;
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < gn_ms[gi]) gn_ms[gi] = ms;
+            }
+        }
+        if (gn_ms[0] < 1e29f || gn_ms[1] < 1e29f) best_gn = gn_ms[0] <= gn_ms[1] ? gns[0] : gns[1];
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (scratch) (void)hipFree(scratch);
-    g_bm_cache[key] = best;
-    return launch2p_h<EPI>(g, best, s);
+    g_bm_cache[key] = best | (best_gn << 16);
+    GemmArgs c = g;
+    c.gn = best_gn;
+    return launch2p_h<EPI>(c, best, s);
 }
 
 int dispatch2p(GemmArgs g, int epilogue, hipStream_t s) {

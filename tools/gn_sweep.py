@@ -25,11 +25,23 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-for gn in [8, 4, 2, 1, 3, 6, 2, 4, 8]:
-    L.call("showo_gemm_tune", gn, 0, None)
+def run(label):
     step(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    print(f"gn={gn}: {3 * B / (time.perf_counter() - t0):.2f} images/s", flush=True)
+    print(f"{label}: {3 * B / (time.perf_counter() - t0):.2f} images/s", flush=True)
+
+
+for gn in [4, 8, 4]:
+    L.call("showo_gemm_tune", gn, 0, None)
+    run(f"gn={gn}")
+L.call("showo_gemm_tune", 4, 0, None)
+for impl in [0, 3, 2, 0, 3]:
+    L.call("showo_attn_set_impl", impl)
+    run(f"attn_impl={impl}")
+L.call("showo_attn_set_impl", 0)
+for flags in [0, 1, 0]:
+    L.call("showo_gemm_tune", 4, flags, None)
+    run(f"gemm flags={flags} (1 = no stagger)")
