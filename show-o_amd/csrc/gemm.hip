@@ -1379,7 +1379,9 @@ int gemm_impl_choice(int M, int N) {
     }
     if (g_gemm_forced >= 1 && g_gemm_forced <= 6) return g_gemm_forced;
     if (M <= 8) return 6;  // decode step: weight-streaming GEMV
-    return (M >= 1024 && N >= 256) ? 5 : 1;
+    // phase-split 256-wide kernel from 256 rows up: measured on the prefill (tools/prefill_sweep.py) 631 rows 11.3 -> 9.3 ms,
+    // 387 rows 10.3 -> 9.6 ms against the 128x128 kernel
+    return (M >= 256 && N >= 256) ? 5 : 1;
 }
 
 }  // namespace
