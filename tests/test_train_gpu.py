@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import util
-from util import O, dev, from_bf16_bits, to_bf16_bits, bf16_round
+from util import O, Wt, dev, from_bf16_bits, to_bf16_bits, bf16_round
 
 pytestmark = pytest.mark.gpu
 
@@ -357,3 +357,53 @@ def test_training_from_input_embeddings_equals_training_from_ids():
     tab = torch.zeros_like(g0["showo.model.embed_tokens.weight"])
     tab.index_add_(0, ids.reshape(-1), extra.grad.reshape(-1, extra.grad.shape[-1]))
     assert (tab - g0["showo.model.embed_tokens.weight"]).abs().max() <= 1e-5 * float(tab.abs().max()) + 1e-9
+
+
+def test_w_clip_vit_training_flow_projector_to_losses_vs_oracle_autograd():
+    """the step body of training/train_w_clip_vit.py:530-613 on the tiny model: image features -> mm_projector (HIP, autograd node)
+    -> spliced between embedded text ids -> Showo.forward(input_embeddings=..., labels=...) (HIP, autograd node) -> backward.
+    Losses and the gradients of the projector, of a block and of the embedding table against torch autograd through the oracle."""
+    P = util.pkg()
+    d = Wt.ShowoDims(**dict(Wt.TINY, w_clip_vit=True))
+    sd_np = Wt.make_showo_state(d, seed=11)
+    psd = Wt.make_projector_state(1024, d.hidden, seed=5)
+    for k, v in psd.items():
+        sd_np["mm_projector." + k] = v
+    m = util.build_showo(d, sd_np).train()
+    assert isinstance(m.mm_projector, P.modeling_showo._MMProjector)
+    torch.manual_seed(4)
+    B, n_img, n_txt = 3, 16, 11
+    feats = torch.randn(B, n_img, 1024)
+    ids = torch.randint(0, d.llm_vocab, (B, n_txt))
+    L = n_img + n_txt
+    labels = torch.cat([torch.full((B, n_img + 2), -100), torch.randint(0, d.llm_vocab, (B, n_txt - 2))], dim=1)
+    mask = O.mask_mmu_vit(B, L, system_prompt_len=0)  # image block fully visible, causal text
+
+    def flow(embed_w, proj, lookup, forward):
+        img = proj(feats_in)
+        txt = lookup(ids_in, embed_w)
+        emb = torch.cat([txt[:, :2], img, txt[:, 2:]], dim=1)
+        return forward(emb)
+
+    # oracle: plain torch autograd, fp32, CPU
+    sd = {k: v.clone().requires_grad_(k.startswith("mm_projector") or "layers.0.mlp.fc1" in k or "embed_tokens" in k)
+          for k, v in O.to_torch(sd_np).items()}
+    feats_in, ids_in = feats, ids
+    out = flow(sd["showo.model.embed_tokens.weight"], lambda x: O.mm_projector({k[len("mm_projector."):]: v for k, v in sd.items() if k.startswith("mm_projector.")}, x),
+               lambda i, w: w[i], lambda e: O.showo_forward(sd, d, None, input_embeddings=e, attention_mask=mask, labels=labels,
+                                                          batch_size_t2i=0, batch_size_lm=0, batch_size_mmu=B, max_seq_length=d.max_text_len))
+    out[3].backward()
+    # HIP path
+    feats_in, ids_in = feats.cuda(), ids.cuda()
+    got = flow(m.showo.model.embed_tokens.weight, m.mm_projector, lambda i, w: m.showo.model.embed_tokens(i),
+               lambda e: m(None, input_embeddings=e, attention_mask=mask.cuda(), labels=labels.cuda(), batch_size_t2i=0, batch_size_lm=0,
+                           batch_size_mmu=B, max_seq_length=d.max_text_len))
+    assert abs(float(got[3].detach()) - float(out[3].detach())) < 5e-3 * abs(float(out[3].detach()))
+    got[3].backward()
+    named = dict(m.named_parameters())
+    for k in ("mm_projector.0.weight", "mm_projector.0.bias", "mm_projector.2.weight", "mm_projector.2.bias",
+              "showo.model.layers.0.mlp.fc1.weight", "showo.model.embed_tokens.weight"):
+        assert named[k].grad is not None, k
+        rmax, rrms = util.relerr(named[k].grad, sd[k].grad)
+        print(f"[parity] w_clip_vit flow grad {k}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+        assert rrms < 3e-2 and rmax < 1e-1, k
