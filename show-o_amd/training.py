@@ -75,6 +75,45 @@ class Trainer:
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) else None
 
+    # ---- checkpoint / resume of the optimizer (reference: accelerator.save_state / load_state, training/train.py:851-889, 429-443)
+    def state_dict(self):
+        """torch.optim.AdamW layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} with the parameters
+        numbered in `model.showo.named_parameters()` order, so the file is interchangeable with an AdamW built over that list"""
+        state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[n].detach().clone(),
+                     "exp_avg_sq": self.v[n].detach().clone()} for i, (n, _) in enumerate(self.params)}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group], "param_names": [n for n, _ in self.params]}
+
+    def load_state_dict(self, sd):
+        """moments are copied INTO the tensors bound to the native optimizer (showo_train_bind_param); lr / betas / eps / weight
+        decay / step count are taken from the file"""
+        names = [n for n, _ in self.params]
+        if "param_names" in sd and list(sd["param_names"]) != names:
+            raise ValueError("optimizer state was saved for a different parameter list")
+        if len(sd["state"]) not in (0, len(names)):
+            raise ValueError(f"optimizer state has {len(sd['state'])} entries, the model has {len(names)} parameters")
+        steps = set()
+        with torch.no_grad():
+            for i, n in enumerate(names):
+                if i not in sd["state"]:
+                    continue
+                st = sd["state"][i]
+                if tuple(st["exp_avg"].shape) != tuple(self.m[n].shape):
+                    raise ValueError(f"{n}: moment shape {tuple(st['exp_avg'].shape)} != {tuple(self.m[n].shape)}")
+                self.m[n].copy_(st["exp_avg"])
+                self.v[n].copy_(st["exp_avg_sq"])
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: not an optimizer state this trainer can resume")
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.wd = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        self.step_count = steps.pop() if steps else 0
+
+    def set_lr(self, lr):
+        """learning-rate schedulers (training/train.py:303-310 `get_scheduler`) call this between steps"""
+        self.lr = float(lr)
+
     def _exchange(self, bucket, works):
         if self.dist is None:
             return

@@ -407,3 +407,33 @@ def test_w_clip_vit_training_flow_projector_to_losses_vs_oracle_autograd():
         rmax, rrms = util.relerr(named[k].grad, sd[k].grad)
         print(f"[parity] w_clip_vit flow grad {k}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
         assert rrms < 3e-2 and rmax < 1e-1, k
+
+
+def test_trainer_checkpoint_resume_is_bit_exact_and_adamw_compatible(tmp_path):
+    """save after step 1 (weights via save_pretrained, optimizer via Trainer.state_dict), resume in a fresh model + trainer, take
+    step 2: parameters equal the uninterrupted 2-step run bit for bit; the optimizer file loads into torch.optim.AdamW"""
+    g = util.golden("showo_tiny_forward.npz")
+    d, sd = util.tiny_state()
+    ids, mask, labels = dev(g["train_ids"]), dev(g["train_mask"]), dev(g["train_labels"])
+    args = (ids, mask, labels, 2, 1, 2, d.max_text_len)
+    P = util.pkg()
+    m1 = util.build_showo(d, sd).train()
+    t1 = P.Trainer(m1, lr=3e-4)
+    t1.step(*args)
+    m1.save_pretrained(str(tmp_path / "ckpt"))
+    torch.save(t1.state_dict(), str(tmp_path / "optimizer.bin"))
+    t1.set_lr(1e-4)
+    t1.step(*args)
+    geo = dict(max_batch=8, max_seq=128)
+    m2 = P.Showo.from_pretrained(str(tmp_path / "ckpt"), **geo).train()
+    t2 = P.Trainer(m2)
+    t2.load_state_dict(torch.load(str(tmp_path / "optimizer.bin"), weights_only=False))
+    assert t2.step_count == 1 and t2.lr == 3e-4
+    t2.set_lr(1e-4)
+    t2.step(*args)
+    for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
+    opt = torch.optim.AdamW([p for _, p in m2.showo.named_parameters()], lr=1e-4)
+    st = t2.state_dict()
+    opt.load_state_dict({"state": st["state"], "param_groups": [dict(opt.param_groups[0], **{k: v for k, v in st["param_groups"][0].items()})]})
+    assert int(opt.state_dict()["state"][0]["step"]) == 2
