@@ -18,3 +18,4 @@ from .clip_encoder import CLIPVisionTower  # noqa: F401
 from . import image_utils  # noqa: F401
 from .image_utils import image_transform  # noqa: F401
 from . import synthetic  # noqa: F401
+from . import checkpointing  # noqa: F401

@@ -266,3 +266,27 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "sample_topk" in out.stdout
+
+
+def test_checkpoint_rotation_and_resume_layout(tmp_path):
+    """training/train.py:851-889 / 429-443: checkpoint-N/unwrapped_model/pytorch_model.bin + metadata.json, oldest removed before
+    saving so that at most `checkpoints_total_limit` remain, resume picks the highest N"""
+    import json
+    ck = util.pkg().checkpointing
+    d, m = _tiny_showo_cpu()
+    out = str(tmp_path / "run")
+    assert ck.resume_from_checkpoint(m, out) == 0 and ck.latest_checkpoint(out) == (None, 0)
+    for step in (10, 20, 30, 40):
+        with torch.no_grad():
+            m.showo.model.final_layernorm.bias.fill_(float(step))
+        p = ck.save_checkpoint(m, out, step, checkpoints_total_limit=2)
+        assert sorted(os.listdir(p)) == ["metadata.json", "unwrapped_model"]
+        assert sorted(os.listdir(os.path.join(p, "unwrapped_model"))) == ["config.json", "pytorch_model.bin"]
+        assert json.load(open(os.path.join(p, "metadata.json"))) == {"global_step": step}
+    assert sorted(os.listdir(out), key=lambda x: int(x.split("-")[1])) == ["checkpoint-30", "checkpoint-40"]
+    _, m2 = _tiny_showo_cpu()
+    assert ck.resume_from_checkpoint(m2, out) == 40
+    assert float(m2.showo.model.final_layernorm.bias[0]) == 40.0
+    for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
+    assert ck.save_checkpoint(m, out, 50, is_main_process=False) is None and not os.path.exists(os.path.join(out, "checkpoint-50"))
