@@ -330,3 +330,41 @@ def test_lr_schedules_equal_reference_sequences():
         LS.get_scheduler("linear", optimizer=FakeTrainer(1e-4), num_warmup_steps=2)
     with pytest.raises(ValueError):
         LS.get_polynomial_decay_schedule_with_warmup(FakeTrainer(1e-8), 2, 10)
+
+
+def test_ctypes_prototypes_match_header_argument_counts_and_kinds():
+    """every binding in show-o_amd/_lib.py has as many arguments as the C declaration, pointers where the header has pointers,
+    and the right scalar kind (int / int64 / float / uint64) elsewhere: catches ABI drift between include/*.h and the host side"""
+    import ctypes as C
+    L = util.lib()
+    hdr = open(os.path.join(util.ROOT, "include", "showo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decls = re.findall(r"\b(?:int|void|const char\*)\s+(showo_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(decls) > 100
+    protos = dict(L._PROTOS)
+    protos.update(L._VOID)
+    checked = 0
+    for name, args in decls:
+        if name not in protos:
+            continue
+        params = [a.strip() for a in args.replace("\n", " ").split(",")] if args.strip() not in ("", "void") else []
+        got = protos[name]
+        assert len(got) == len(params), (name, len(got), params)
+        for p, ct in zip(params, got):
+            is_ptr = "*" in p
+            if is_ptr:
+                assert ct in (C.c_void_p, C.c_char_p) or issubclass(ct, C._Pointer), (name, p, ct)
+            elif re.match(r"(const\s+)?(int64_t|long long)\b", p):
+                assert ct is C.c_int64, (name, p, ct)
+            elif re.match(r"(const\s+)?(uint64_t|unsigned long long)\b", p):
+                assert ct is C.c_uint64, (name, p, ct)
+            elif re.match(r"(const\s+)?uint32_t\b", p):
+                assert ct is C.c_uint32, (name, p, ct)
+            elif re.match(r"(const\s+)?float\b", p):
+                assert ct is C.c_float, (name, p, ct)
+            elif re.match(r"(const\s+)?int\b", p):
+                assert ct is C.c_int, (name, p, ct)
+            else:
+                raise AssertionError(f"{name}: unrecognised parameter type {p!r}")
+        checked += 1
+    assert checked > 95
