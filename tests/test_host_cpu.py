@@ -368,3 +368,21 @@ def test_ctypes_prototypes_match_header_argument_counts_and_kinds():
                 raise AssertionError(f"{name}: unrecognised parameter type {p!r}")
         checked += 1
     assert checked > 95
+
+
+def test_alias_package_shares_module_objects():
+    """`showo_amd.x` and `show-o_amd.x` are the same module objects (one instance of every class, so isinstance checks hold no
+    matter which spelling user code imports from)"""
+    import importlib
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import importlib, showo_amd\n"
+            "from showo_amd.prompting_utils import IntervalMask as A\n"
+            "import showo_amd.lr_schedulers as ls\n"
+            "real = importlib.import_module('show-o_amd.prompting_utils')\n"
+            "assert A is real.IntervalMask and ls is importlib.import_module('show-o_amd.lr_schedulers')\n"
+            "assert showo_amd.Showo.__module__ == 'show-o_amd.modeling_showo'\n"
+            "print('ok')\n") % util.ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout, out.stderr[-2000:])
