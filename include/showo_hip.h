@@ -85,6 +85,10 @@ int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t*
 /* fp32 -> (hi, lo) bf16 pair */
 int showo_split_f32_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
 
+/* float4 grid-stride device copy (nbytes, src, dst 16-byte aligned): the measured HBM ceiling printed next to the 8 TB/s
+ * spec by tools/ceiling.py and bench.py ("re-measure with a copy kernel"). */
+int showo_copy_b128(const void* src, void* dst, int64_t nbytes, void* stream);
+
 /* fp32 -> bf16 cast (weight packing) */
 int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 
@@ -108,6 +112,25 @@ int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ld
                         const float* qln_b, const float* kln_w, const float* kln_b, const float* cos_tab,
                         const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot,
                         float eps, int pos0, int Lcap, int Lp, void* stream);
+
+/* showo_gemm_qkv_bf16 and fc1 + gelu_new in ONE launch: PhiDecoderLayer feeds the same LayerNorm output to q/k/v_proj and to
+ * mlp.fc1 (models/phi.py:776-790, 208-212), so the weight is the row concatenation [Wqkv ; W1] bf16 [3*nH*64 + F, ldw] (bias
+ * fp32 [3*nH*64 + F]); output columns below 3*nH*64 take the QKV epilogue above, the others
+ * ffn_out bf16 [B*L, ldf] = gelu_new(A W1^T + b1).  Results are bit-identical to the two separate launches. */
+int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
+                            const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                            const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                            uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0, int Lcap,
+                            int Lp, void* stream);
+
+/* K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias) with A0 bf16 [M,K0] (lda0), A1 bf16 [M,K1] (lda1) and
+ * weight rows [W0[n,:] | W1[n,:]] bf16 [N, ldw] (ldw >= K0 + K1; K0, K1 multiples of 64).  epilogue must be SHOWO_EPI_RESID_F32
+ * (out fp32 = acc + bias + resid, in place allowed).
+ * Phi's block is parallel-residual (models/phi.py:774-790): x + dense(attn) + fc2(ffn) = x + [attn | ffn] [Wd | W2]^T + (bd + b2)
+ * is one launch with ONE read-modify-write of the fp32 residual stream instead of two. */
+int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W, int ldw,
+                         const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N, int epilogue,
+                         void* stream);
 
 /* Compress an additive attention mask [B,1,Lq,Lk] fp32 (values 0 / very negative, as built by
  * training/prompting_utils.py:466-511, 591-624) into per-row visibility intervals

@@ -75,8 +75,12 @@ _PROTOS = {
     "showo_conv3x3_bf16x3": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "showo_cast_f32_bf16": [c_p, c_p, c_i64, c_p],
+    "showo_copy_b128": [c_p, c_p, c_i64, c_p],
     "showo_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_gemm_qkv_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
+    "showo_gemm_qkv_fc1_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                                c_f, c_i, c_i, c_i, c_p],
+    "showo_gemm_kcat_bf16": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
     "showo_mask_compress": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

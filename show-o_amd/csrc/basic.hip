@@ -336,3 +336,30 @@ extern "C" int showo_argmax_f32(const float* x, int n, int64_t* out, void* strea
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ---- HBM ceiling anchor (tools/ceiling.py): float4 grid-stride copy, the measured counterpart of the 8 TB/s HBM3E spec
+namespace {
+__global__ __launch_bounds__(256) void copy_b128_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x * 4 + threadIdx.x; i < n16; i += stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i + u * 256 < n16) ? src[i + u * 256] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256 < n16) dst[i + u * 256] = v[u];
+    }
+}
+}  // namespace
+
+extern "C" int showo_copy_b128(const void* src, void* dst, int64_t nbytes, void* stream) {
+    if (nbytes <= 0) return 0;
+    if ((nbytes & 15) || (((uintptr_t)src) & 15) || (((uintptr_t)dst) & 15)) return showo::set_error_msg(1, "copy_b128: 16-byte alignment required");
+    const int64_t n16 = nbytes >> 4;
+    int64_t blocks = (n16 + 1023) / 1024;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    copy_b128_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, n16);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return showo::set_error_hip(e, "copy_b128 launch", __FILE__, __LINE__);
+    return 0;
+}

@@ -1,21 +1,34 @@
 #!/bin/bash
 # Builds libshowo_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+# A failed compile stops the build: the stale object is removed before compiling and every job's exit status is checked.
 set -e
 cd "$(dirname "$0")"
 OUT=../libshowo_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-result -Wno-unused-value"
 OBJS=""
-for f in basic gemm attention attention_bwd train_kernels decode prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops; do
-  if [ ! -f _build/$f.o ] || [ $f.hip -nt _build/$f.o ] || [ common.h -nt _build/$f.o ] || [ engine.h -nt _build/$f.o ] || [ prof.h -nt _build/$f.o ] || [ ../../include/showo_hip.h -nt _build/$f.o ]; then
-    mkdir -p _build
+PIDS=""
+mkdir -p _build
+for f in basic gemm gemm2p attention attention_bwd train_kernels decode prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops; do
+  if [ ! -f _build/$f.o ] || [ $f.hip -nt _build/$f.o ] || [ common.h -nt _build/$f.o ] || [ engine.h -nt _build/$f.o ] || [ gemm_common.h -nt _build/$f.o ] || [ prof.h -nt _build/$f.o ] || [ ../../include/showo_hip.h -nt _build/$f.o ]; then
+    rm -f _build/$f.o
     hipcc $FLAGS -c $f.hip -o _build/$f.o &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS _build/$f.o"
 done
 if [ ! -f _build/errors.o ] || [ errors.cpp -nt _build/errors.o ]; then
-  mkdir -p _build
+  rm -f _build/errors.o
   hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -c errors.cpp -o _build/errors.o &
+  PIDS="$PIDS $!"
 fi
-wait
+FAIL=0
+for p in $PIDS; do
+  wait $p || FAIL=1
+done
+if [ $FAIL -ne 0 ]; then
+  echo "build failed: a hipcc job returned non-zero" >&2
+  exit 1
+fi
+rm -f $OUT
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS _build/errors.o -o $OUT
 echo "built $(realpath $OUT)"

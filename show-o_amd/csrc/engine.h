@@ -8,8 +8,13 @@
 
 namespace showo {
 struct Layer {
+    // wqkv and w1 are ONE allocation ([3H + F, H] rows q|k|v|fc1, biases likewise): the fused [Wqkv ; W1] projection reads it as is
     bf16_t *wqkv = nullptr, *wd = nullptr, *w1 = nullptr, *w2 = nullptr;
     float *bqkv = nullptr, *bd = nullptr, *b1 = nullptr, *b2 = nullptr;
+    // K-concatenated image of the two residual projections: wd2 [H, H + F] rows [Wd[n,:] | W2[n,:]], bd2 = bd + b2
+    // (rebuilt lazily after a weight load, see fused_sync in engine.hip)
+    bf16_t* wd2 = nullptr;
+    float* bd2 = nullptr;
     float *ln_w = nullptr, *ln_b = nullptr, *qln_w = nullptr, *qln_b = nullptr, *kln_w = nullptr, *kln_b = nullptr;
 };
 }  // namespace showo
@@ -44,6 +49,7 @@ struct showo_engine {
     std::vector<void*> allocs;
     std::set<std::string> loaded;
     int expected = 0;
+    bool fused_valid = false;  // wd2 / bd2 images match wd, w2, bd, b2
     // weights
     float* embed = nullptr;
     std::vector<showo::Layer> layers;

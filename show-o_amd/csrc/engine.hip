@@ -119,10 +119,11 @@ extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** 
     rc |= e->alloc(&e->embed, (int64_t)V * H);
     e->layers.resize(e->nL);
     for (auto& l : e->layers) {
-        rc |= e->alloc(&l.wqkv, (int64_t)3 * H * H); rc |= e->alloc(&l.bqkv, 3 * H);
+        rc |= e->alloc(&l.wqkv, (int64_t)(3 * H + F) * H); rc |= e->alloc(&l.bqkv, 3 * H + F);
+        if (!rc) { l.w1 = l.wqkv + (int64_t)3 * H * H; l.b1 = l.bqkv + 3 * H; }
         rc |= e->alloc(&l.wd, (int64_t)H * H); rc |= e->alloc(&l.bd, H);
-        rc |= e->alloc(&l.w1, (int64_t)F * H); rc |= e->alloc(&l.b1, F);
         rc |= e->alloc(&l.w2, (int64_t)H * F); rc |= e->alloc(&l.b2, H);
+        rc |= e->alloc(&l.wd2, (int64_t)H * (H + F)); rc |= e->alloc(&l.bd2, H);
         rc |= e->alloc(&l.ln_w, H); rc |= e->alloc(&l.ln_b, H);
         rc |= e->alloc(&l.qln_w, 64); rc |= e->alloc(&l.qln_b, 64);
         rc |= e->alloc(&l.kln_w, 64); rc |= e->alloc(&l.kln_b, 64);
@@ -209,7 +210,39 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     }
     if (rc == -1) return set_error_msg(3, "engine_load: unknown state-dict key");
     if (rc == 0) e->loaded.insert(k);
+    e->fused_valid = false;
     return rc;
+}
+
+namespace {
+__global__ void add2_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+}  // namespace
+
+// K-concatenated images of the residual projections (dense | fc2) for showo_gemm_kcat_bf16; rebuilt after any weight load
+static int fused_sync(showo_engine* e, hipStream_t s) {
+    if (e->fused_valid) return 0;
+    const int H = e->H, F = e->F;
+    for (auto& l : e->layers) {
+        SHOWO_CHECK_HIP(hipMemcpy2DAsync(l.wd2, (size_t)(H + F) * 2, l.wd, (size_t)H * 2, (size_t)H * 2, H, hipMemcpyDeviceToDevice, s));
+        SHOWO_CHECK_HIP(hipMemcpy2DAsync(l.wd2 + H, (size_t)(H + F) * 2, l.w2, (size_t)F * 2, (size_t)F * 2, H, hipMemcpyDeviceToDevice, s));
+        add2_f32_kernel<<<dim3((H + 255) / 256), dim3(256), 0, s>>>(l.bd, l.b2, l.bd2, H);
+    }
+    SHOWO_CHECK_HIP(hipGetLastError());
+    e->fused_valid = true;
+    return 0;
+}
+
+// SHOWO_FUSED_LAYER=0 restores the four-GEMM layer (A/B runs)
+static bool fused_layer_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = getenv("SHOWO_FUSED_LAYER");
+        v = env ? (atoi(env) != 0) : 1;
+    }
+    return v != 0;
 }
 
 // ---- the 24-layer stack.  K / V^T go to the per-call workspace (layer stride 0) or to a per-layer cache:
@@ -257,6 +290,28 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
                                          e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
             TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s));
+        }
+        return 0;
+    }
+    // Prefill / t2i layers: TWO GEMM launches.  Phi's block is parallel-residual (phi.py:774-790): q/k/v_proj and fc1 read the
+    // same LayerNorm output -> one [Wqkv ; W1] projection with a column-split epilogue; dense and fc2 add into the same residual
+    // row -> one K-concatenated GEMM over [attn | ffn] with a single read-modify-write of x.
+    const bool fused = T >= 256 && e->cfg.rotary_dim == 32 && fused_layer_enabled() && !layer_overlap_enabled() && (3 * H) % 256 == 0 &&
+                       (int64_t)T * F * 2 < ((int64_t)1 << 32);
+    if (fused) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        hipStreamIsCapturing(s, &cs);
+        if (!e->fused_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine: fused weight images must be built before a stream capture");
+        TRY(fused_sync(e, s));
+        for (int li = 0; li < e->nL; ++li) {
+            showo::Layer& l = e->layers[li];
+            bf16_t* Kd = kv.k + li * kv.k_lstride;
+            bf16_t* Vd = kv.vt + li * kv.v_lstride;
+            TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
+            TRY(showo_gemm_qkv_fc1_bf16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
+                                        e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+            TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
+            TRY(showo_gemm_kcat_bf16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32, s));
         }
         return 0;
     }

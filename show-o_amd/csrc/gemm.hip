@@ -14,12 +14,9 @@
 //   prefetch of the next k-tile under the MFMAs) into a [128][64] bf16 image whose 16-B chunks are
 //   XOR-swizzled with (row & 7) so the ds_read_b128 fragment reads are at most 2-way conflicted.
 //   Block ids are remapped so that the blocks resident on one XCD (id % 8) walk the same weight panel.
-#include "common.h"
-#include "../../include/showo_hip.h"
+#include "gemm_common.h"
 #include "prof.h"
 #include <cstdlib>
-#include <map>
-#include <tuple>
 
 using namespace showo;
 
@@ -27,27 +24,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDS_TILE = 128 * 64;  // bf16 elements per operand tile
-
-struct GemmArgs {
-    const bf16_t* A; int lda;
-    const bf16_t* W; int ldw;
-    const bf16_t* Wlo;  // split-precision mode: low halves of the weights (same layout as W)
-    const float* bias; int bias_per_row;
-    void* out; int ldo;
-    const float* resid; int ldr;
-    int M, N, K;
-    int vec_out;  // 1: out/resid rows allow 4-wide vector access
-    int gn;       // v3: n-panels per tile group (L2 locality of the block -> tile map)
-    int flags;    // v3 experiments: bit0 = no group stagger
-    unsigned long long* dbg;  // v3 debug build: per-barrier timestamps of block 0
-    // fused q/k LayerNorm + RoPE + head-major relayout epilogue (EPI_QKV): out is unused
-    const float *qw, *qb, *kw, *kb, *cosT, *sinT;
-    bf16_t *Q, *Kd, *Vt;
-    int L, nH, pos0, Lcap, Lp;
-    float eps;
-};
-
-constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
 
 struct ConvArgs {
     const bf16_t* X;   // NHWC bf16 input
@@ -116,62 +92,6 @@ struct ConvLoader {
 };
 
 
-__device__ inline void load_bias4(const GemmArgs& g, int n, float (&bn)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bn[r] = 0.f;
-    if (g.bias && !g.bias_per_row) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bn[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
-    }
-}
-
-// one MFMA C fragment: this lane holds out[m][n .. n+3]
-template <int EPI>
-__device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, int m, int n, const float (&bn)[4]) {
-    if (m >= g.M || n >= g.N) return;
-    float v[4];
-    const float bm = (g.bias && g.bias_per_row) ? g.bias[m] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] + bn[r] + bm;
-    const bool full = (n + 3 < g.N) && g.vec_out;
-    if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
-        if (EPI == SHOWO_EPI_GELU_BF16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_new_fast(v[r]);
-        }
-        bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
-        if (full) {
-            uint2 pk;
-            pk.x = pack_bf2(v[0], v[1]);
-            pk.y = pack_bf2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(o) = pk;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < g.N) o[r] = f2bf(v[r]);
-        }
-    } else {
-        float* o = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n;
-        if (EPI == SHOWO_EPI_RESID_F32) {
-            const float* rs = g.resid + (int64_t)m * g.ldr + n;
-            if (full) {
-                float4 rv = *reinterpret_cast<const float4*>(rs);
-                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < g.N) v[r] += rs[r];
-            }
-        }
-        if (full) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < g.N) o[r] = v[r];
-        }
-    }
-}
 
 // SPLIT: both operands come as (hi, lo) bf16 pairs with x = hi + lo to ~2^-17; the product is accumulated as
 // hi*hi + hi*lo + lo*hi in the fp32 MFMA accumulators (3 MFMAs per tile pair, ~fp32-class accuracy at 3/16 of the
@@ -367,7 +287,6 @@ int dispatch_split(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_
 // SOURCE address and again on the ds_read (CDNA4 playbook: "swizzle both sides or neither").
 // One barrier per k-tile; the next tile's DMA is in flight under the 64 MFMAs of the current one.
 // =====================================================================================================
-constexpr int B2 = 256;
 constexpr int LDS_TILE2 = 256 * 64;
 constexpr int SMEM2_BYTES = 4 * LDS_TILE2 * 2;  // 128 KiB
 
@@ -557,115 +476,6 @@ int dispatch2(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) 
 //     RAW: every wave waits for its own DMA pieces (vmcnt) in ph3, the reads start in the next phase, i.e. after a
 //     barrier that all 8 waves passed after their wait.
 // =====================================================================================================
-constexpr int P3_BUF_ELEMS = 2 * 256 * 64;  // one k-tile: W[256][64] then A[256][64] (64 KiB)
-constexpr int SMEM3_BYTES = 2 * P3_BUF_ELEMS * 2;
-
-__device__ __forceinline__ void bar_raw_fn() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
-// the wave's m range, n0 + wn*64 = its first column.
-template <int EPI, int MF>
-__device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg) {
-    if constexpr (EPI == EPI_QKV) {
-        // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
-        // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
-        // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
-        const int nbase = n0 + wn * 64;
-        if (nbase < g.N) {
-            const int Hq = g.nH * 64;
-            const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)
-            const int head = (nbase - which * Hq) >> 6;
-            float bn[4][4], lw[4][4], lb[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                load_bias4(g, nbase + i * 16 + fg * 4, bn[i]);
-                if (which < 2) {
-                    const float4 w4 = *reinterpret_cast<const float4*>((which ? g.kw : g.qw) + i * 16 + fg * 4);
-                    const float4 b4 = *reinterpret_cast<const float4*>((which ? g.kb : g.qb) + i * 16 + fg * 4);
-                    lw[i][0] = w4.x; lw[i][1] = w4.y; lw[i][2] = w4.z; lw[i][3] = w4.w;
-                    lb[i][0] = b4.x; lb[i][1] = b4.y; lb[i][2] = b4.z; lb[i][3] = b4.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < MF; ++j) {
-                const int m = mrow0 + j * 16 + fr;
-                const bool valid = m < g.M;
-                const int mm = valid ? m : g.M - 1;
-                const int b = mm / g.L, l = mm - b * g.L, pos = g.pos0 + l;
-                const int64_t bh = (int64_t)b * g.nH + head;
-                float x[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
-                if (which == 2) {  // V^T[bh][d][pos]
-                    if (valid) {
-                        bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = f2bf(x[i][r]);
-                    }
-                    continue;
-                }
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
-                const float mean = sum * (1.0f / 64.0f);
-                float sq = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
-                const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[i][r] = x[i][r] * rstd * lw[i][r] + lb[i][r];
-                // partial rotary over dims [0, 32): rotate_half pairs d with d + 16 = fragments i = 0 and 1 of this lane
-                const float4 c0 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + fg * 4);
-                const float4 s0 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + fg * 4);
-                const float4 c1 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + 16 + fg * 4);
-                const float4 s1 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + 16 + fg * 4);
-                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, ss0[4] = {s0.x, s0.y, s0.z, s0.w};
-                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float y0 = x[0][r], y1 = x[1][r];
-                    x[0][r] = y0 * cc0[r] - y1 * ss0[r];
-                    x[1][r] = y1 * cc1[r] + y0 * ss1[r];
-                }
-                if (!valid) continue;
-                const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact in bf16)
-                bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + pos) * 64;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint2 pk;
-                    pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
-                    pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
-                    *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fg * 4;
-            float bn[4];
-            load_bias4(g, n, bn);
-#pragma unroll
-            for (int j = 0; j < MF; ++j) store_frag<EPI>(g, acc[i][j], mrow0 + j * 16 + fr, n, bn);
-        }
-    }
-}
 
 // ABL (timing ablations, results are garbage): bit0 = no ds_read in the loop, bit1 = no DMA in the loop, bit2 = no barriers
 template <int EPI, int PH, bool DBG, int ABL = 0>
@@ -939,7 +749,7 @@ int launch3(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-int g_gemm_gn = 4, g_gemm_flags = 0;  // 4 n-panels per XCD tile group: same-process sweep on the bench workload 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s
+int g_gemm_flags = 0;  // (g_gemm_gn lives in gemm2p.hip) 4 n-panels per XCD tile group: same-process sweep on the bench workload 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s
 unsigned long long* g_gemm_dbg = nullptr;
 
 template <int PH>
@@ -965,317 +775,6 @@ int dispatch3(GemmArgs g, int epilogue, hipStream_t s) {
     return set_error_msg(1, "gemm: unknown epilogue");
 }
 
-// =====================================================================================================
-// Production form of the 2-phase kernel with a selectable tile HEIGHT: the two wave groups own MF0 and MF1 16-row
-// m-fragments (tile = 16 (MF0 + MF1) rows x 256 columns; 8+8 = 256, 7+6 = 208, 5+5 = 160).  A launch is
-// rounds x tile-time long, rounds = ceil(tiles / 256 CUs): at M = 6192 the 256-row tile leaves 22 % of the chip idle
-// in the last round of every projection (200, 600, 800 tiles), the 208-row tile gives 240 / 720 / 960.
-//   tile rows: group 0 = [0, 16 MF0), group 1 = [16 MF0, 16 (MF0 + MF1)).
-//   "lo" rows of a group = its first 4 fragments (ph0), "hi" rows = the rest (ph1).
-//   DMA pieces (8 rows each): W 32 (4 per wave), A-lo 16 (2 per wave), A-hi 2 (MF0 + MF1 - 8) <= 16: every wave issues two
-//   hi pieces (index wave and wave + 8, wrapped onto an existing piece when there are fewer), so the vmcnt counts are
-//   the same for all waves.
-// Schedule, hazards and LDS image: see the phase-split kernel above (PH = 2 form).
-// =====================================================================================================
-template <int EPI, int MF0, int MF1>
-__global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
-    static_assert(MF0 >= 5 && MF0 <= 8 && MF1 >= 4 && MF1 <= 8, "each group needs 4 lo fragments; group 0 at least one hi fragment");
-    constexpr int BMT = 16 * (MF0 + MF1);
-    constexpr int NHI = 2 * (MF0 - 4) + 2 * (MF1 - 4);  // hi pieces
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
-    int nwg = tilesM * tilesN, bid = blockIdx.x;
-    {
-        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    int tn, tm;
-    {
-        const int per = g.gn * tilesM;
-        const int grp = bid / per, rem = bid - grp * per;
-        const int first = grp * g.gn;
-        const int gsz = min(tilesN - first, g.gn);
-        tm = rem / gsz;
-        tn = first + (rem - tm * gsz);
-    }
-    const int m0 = tm * BMT, n0 = tn * B2;
-    const int nk = g.K / BK;
-    const int wn = wave & 3, wm = wave >> 2;
-    const int gbase = wm * 16 * MF0;  // first tile row of this wave's group
-
-    // ---- DMA roles (byte offsets from the operand base; LDS destinations are wave-uniform)
-    const int srow = lane >> 3;
-    const int coff = ((lane & 7) ^ srow) << 3;
-    uint32_t woff[2][2], alo[2], ahi[2];
-    int hirow[2];  // tile row base of this wave's two hi pieces
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int n = n0 + h * 128 + i * 64 + wave * 8 + srow;
-            n = n < g.N ? n : g.N - 1;
-            woff[h][i] = (uint32_t)(((int64_t)n * g.ldw + coff) * 2);
-        }
-        int m = m0 + h * 16 * MF0 + wave * 8 + srow;  // lo piece `wave` of group h
-        m = m < g.M ? m : g.M - 1;
-        alo[h] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
-        int p = wave + 8 * h;
-        p = p < NHI ? p : p % NHI;
-        hirow[h] = p < 2 * (MF0 - 4) ? 64 + 8 * p : 16 * MF0 + 64 + 8 * (p - 2 * (MF0 - 4));
-        m = m0 + hirow[h] + srow;
-        m = m < g.M ? m : g.M - 1;
-        ahi[h] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
-    }
-    const char* wbase = reinterpret_cast<const char*>(g.W);
-    const char* abase = reinterpret_cast<const char*>(g.A);
-    constexpr int AOFF = 2 * 256 * 64;  // LDS (elements): W[buf][256][64] at 0, A[buf][256][64] behind it
-#define Q2_DMA_W(BUF, K0)                                                                                         \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                          \
-            glds16(reinterpret_cast<const bf16_t*>(wbase + (size_t)(K0) * 2 + (size_t)woff[h_][i_]),              \
-                   smem + (BUF) * 256 * 64 + (h_ * 128 + i_ * 64 + wave * 8) * 64)
-#define Q2_DMA_ALO(BUF, K0)                                                                                       \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                              \
-        glds16(reinterpret_cast<const bf16_t*>(abase + (size_t)(K0) * 2 + (size_t)alo[h_]),                       \
-               smem + AOFF + (BUF) * 256 * 64 + (h_ * 16 * MF0 + wave * 8) * 64)
-#define Q2_DMA_AHI(BUF, K0)                                                                                       \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                              \
-        glds16(reinterpret_cast<const bf16_t*>(abase + (size_t)(K0) * 2 + (size_t)ahi[h_]),                       \
-               smem + AOFF + (BUF) * 256 * 64 + hirow[h_] * 64)
-
-    const int fr = lane & 15, fg = lane >> 4;
-    const int lsw0 = fr * 64 + ((fg ^ (fr & 7)) << 3);
-    const int lsw1 = fr * 64 + (((fg + 4) ^ (fr & 7)) << 3);
-    const bf16_t* ldsW = smem + (wn * 64) * 64;
-    const bf16_t* ldsA = smem + AOFF + gbase * 64;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[2][4], af[2][4];
-
-#define Q2_READ_W(BUF)                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-        wf[0][i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * 256 * 64 + i * 16 * 64 + lsw0);                \
-        wf[1][i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * 256 * 64 + i * 16 * 64 + lsw1);                \
-    }
-#define Q2_READ_A(BUF, MB, CNT)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < (CNT); ++j) {                                                           \
-        af[0][j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * 256 * 64 + ((MB) + j) * 16 * 64 + lsw0);       \
-        af[1][j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * 256 * 64 + ((MB) + j) * 16 * 64 + lsw1);       \
-    }
-#define Q2_MFMA(MB, CNT)                                                                                          \
-    do {                                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-                _Pragma("unroll") for (int j = 0; j < (CNT); ++j)                                                 \
-                    acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[kk][j], acc[i][(MB) + j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                            \
-    } while (0)
-#define Q2_TILE(BUF, T)                                                                                           \
-    do {                                                                                                          \
-        const int kN = ((T) + 1) * BK;                                                                            \
-        const bool has1 = (T) + 1 < nk;                                                                           \
-        /* ph0: all W fragments + the 4 lo A fragments */                                                         \
-        Q2_READ_W(BUF)                                                                                            \
-        Q2_READ_A(BUF, 0, 4)                                                                                      \
-        if (has1) {                                                                                               \
-            Q2_DMA_W((BUF) ^ 1, kN);                                                                              \
-            Q2_DMA_ALO((BUF) ^ 1, kN);                                                                            \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); /* retires the hi pieces of this tile */             \
-        } else {                                                                                                  \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-        }                                                                                                         \
-        bar_raw_fn();                                                                                             \
-        Q2_MFMA(0, 4);                                                                                            \
-        bar_raw_fn();                                                                                             \
-        /* ph1: the hi A fragments of this group */                                                               \
-        if (MF0 == MF1 || wm == 0) { Q2_READ_A(BUF, 4, MF0 - 4) } else { Q2_READ_A(BUF, 4, MF1 - 4) }             \
-        if (has1) {                                                                                               \
-            Q2_DMA_AHI((BUF) ^ 1, kN);                                                                            \
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); /* retires W + A-lo of tile T+1 */                   \
-        } else {                                                                                                  \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-        }                                                                                                         \
-        bar_raw_fn();                                                                                             \
-        if (MF0 == MF1 || wm == 0) Q2_MFMA(4, MF0 - 4); else Q2_MFMA(4, MF1 - 4);                                 \
-        bar_raw_fn();                                                                                             \
-    } while (0)
-
-    // ---- prologue: all of tile 0
-    Q2_DMA_W(0, 0);
-    Q2_DMA_ALO(0, 0);
-    Q2_DMA_AHI(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bar_raw_fn();
-    if (wm == 1) bar_raw_fn();  // group 1 runs one barrier behind group 0
-
-    int t = 0;
-    for (; t + 1 < nk; t += 2) {
-        Q2_TILE(0, t);
-        Q2_TILE(1, t + 1);
-    }
-    if (t < nk) Q2_TILE(0, t);
-    if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-
-    if (MF0 == MF1 || wm == 0) epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg);
-    else epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg);
-#undef Q2_TILE
-#undef Q2_MFMA
-#undef Q2_READ_A
-#undef Q2_READ_W
-#undef Q2_DMA_AHI
-#undef Q2_DMA_ALO
-#undef Q2_DMA_W
-}
-
-template <int EPI, int MF0, int MF1>
-int launch2p(const GemmArgs& g, hipStream_t s) {
-    static bool attr_set = false;
-    auto kfn = gemm2p_kernel<EPI, MF0, MF1>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_BYTES);
-        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm2p)", __FILE__, __LINE__);
-        attr_set = true;
-    }
-    constexpr int BMT = 16 * (MF0 + MF1);
-    int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
-    kfn<<<dim3(tilesM * tilesN), dim3(512), SMEM3_BYTES, s>>>(g);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_error_hip(e, "gemm2p launch", __FILE__, __LINE__);
-    return 0;
-}
-
-int g_gemm_bm = 0;  // 0 = choose the tile height per launch; 256 / 208 / 160 = force
-// tile height that minimises rounds x height (rounds = ceil(tiles / CUs)); ties go to the taller tile
-int pick_bm(int M, int N) {
-    if (g_gemm_bm == 0) {  // SHOWO_GEMM_BM=256|208|160 forces a height (A/B runs of bench.py)
-        const char* e = getenv("SHOWO_GEMM_BM");
-        g_gemm_bm = e ? atoi(e) : -1;
-    }
-    if (g_gemm_bm == 256 || g_gemm_bm == 208 || g_gemm_bm == 176 || g_gemm_bm == 160 || g_gemm_bm == 144) return g_gemm_bm;
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-    }
-    // measured (tools/gemm_bench.cpp, bench.py A/B): the kernels run power-limited, so a shorter tile only pays when it
-    // removes a mostly idle last round; 160 never won at the shapes of this model and is only selectable explicitly
-    const int tilesN = (N + B2 - 1) / B2;
-    auto cost = [&](int c) { long tiles = (long)((M + c - 1) / c) * tilesN; return ((tiles + cus - 1) / cus) * c; };
-    const int best = (cost(208) * 10 <= cost(256) * 9) ? 208 : 256;
-    return best;
-}
-
-template <int EPI>
-int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
-    switch (h) {
-        case 208: return launch2p<EPI, 7, 6>(g, s);
-        case 176: return launch2p<EPI, 6, 5>(g, s);
-        case 160: return launch2p<EPI, 5, 5>(g, s);
-        case 144: return launch2p<EPI, 5, 4>(g, s);
-    }
-    return launch2p<EPI, 8, 8>(g, s);
-}
-
-// Tile height per (M, N, K, epilogue).  The rounds-x-height model mispredicts (per-tile weight streaming and fixed launch /
-// epilogue costs dominate the short tiles: tools/gemm_bench.cpp), so the first launch of a shape times the five heights
-// (2 launches each, HIP events, ~1 ms) and the winner is cached.  Every height computes bit-identical results (same k order
-// per element), so the choice never changes numerics.  Skipped while the stream is being captured (the model is used), and
-// with SHOWO_GEMM_TUNE=0.  In-place residual launches are timed on a scratch output.
-std::map<std::tuple<int, int, int, int>, int> g_bm_cache;  // (M, N, K, EPI) -> tile height | tile-group width << 16
-int g_gemm_tune = -1;
-
-template <int EPI>
-int launch2p_bm(const GemmArgs& g, hipStream_t s) {
-    if (g_gemm_bm == 0) pick_bm(g.M, g.N);  // reads SHOWO_GEMM_BM
-    if (g_gemm_bm > 0) return launch2p_h<EPI>(g, g_gemm_bm, s);
-    if (g_gemm_tune < 0) { const char* e = getenv("SHOWO_GEMM_TUNE"); g_gemm_tune = e ? atoi(e) : 1; }
-    const auto key = std::make_tuple(g.M, g.N, g.K, EPI);
-    auto it = g_bm_cache.find(key);
-    if (it != g_bm_cache.end()) {
-        GemmArgs c = g;
-        if (it->second >> 16) c.gn = it->second >> 16;
-        return launch2p_h<EPI>(c, it->second & 0xffff, s);
-    }
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    if (!g_gemm_tune || capturing || (int64_t)g.M * g.N < ((int64_t)1 << 20)) return launch2p_h<EPI>(g, pick_bm(g.M, g.N), s);
-    GemmArgs t = g;
-    void* scratch = nullptr;
-    if (EPI == SHOWO_EPI_RESID_F32) {  // accumulates in place: time it on a scratch output
-        if (hipMalloc(&scratch, (size_t)g.M * g.ldo * sizeof(float)) != hipSuccess) return launch2p_h<EPI>(g, pick_bm(g.M, g.N), s);
-        t.out = scratch; t.resid = (const float*)scratch; t.ldr = g.ldo;
-    }
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const int cand[5] = {256, 208, 176, 160, 144};
-    int best = pick_bm(g.M, g.N);
-    float best_ms = 1e30f;
-    // two interleaved passes over the candidates, 3 timed launches each, minimum per candidate: the first measurements of a
-    // process run on a GPU that is still ramping its clocks, and a single 2-launch sample mis-ranked tiles that differ by ~10 %
-    float cand_ms[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int ci = 0; ci < 5; ++ci) {
-            const int h = cand[ci];
-            int rc = launch2p_h<EPI>(t, h, s);  // warm-up (instruction cache, attribute set)
-            (void)hipEventRecord(e0, s);
-            for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, h, s);
-            (void)hipEventRecord(e1, s);
-            if (rc || hipEventSynchronize(e1) != hipSuccess) continue;
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < cand_ms[ci]) cand_ms[ci] = ms;
-        }
-    }
-    for (int ci = 0; ci < 5; ++ci)
-        if (cand_ms[ci] < best_ms) { best_ms = cand_ms[ci]; best = cand[ci]; }
-    // second dimension, at the chosen height: n-panels per XCD tile group (L2 / Infinity-Cache locality of the co-resident tiles).
-    // Measured on the bench workload the better of {4, 8} differs from box to box (+1.7 % / -0.6 %), hence per shape, per process.
-    int best_gn = g.gn;
-    {
-        const int gns[2] = {4, 8};
-        float gn_ms[2] = {1e30f, 1e30f};
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int gi = 0; gi < 2; ++gi) {
-                t.gn = gns[gi];
-                int rc = launch2p_h<EPI>(t, best, s);
-                (void)hipEventRecord(e0, s);
-                for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, best, s);
-                (void)hipEventRecord(e1, s);
-                if (rc || hipEventSynchronize(e1) != hipSuccess) continue;
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < gn_ms[gi]) gn_ms[gi] = ms;
-            }
-        }
-        if (gn_ms[0] < 1e29f || gn_ms[1] < 1e29f) best_gn = gn_ms[0] <= gn_ms[1] ? gns[0] : gns[1];
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (scratch) (void)hipFree(scratch);
-    g_bm_cache[key] = best | (best_gn << 16);
-    GemmArgs c = g;
-    c.gn = best_gn;
-    return launch2p_h<EPI>(c, best, s);
-}
-
-int dispatch2p(GemmArgs g, int epilogue, hipStream_t s) {
-    g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
-    g.flags = 0;
-    g.dbg = nullptr;
-    switch (epilogue) {
-        case SHOWO_EPI_BF16: return launch2p_bm<SHOWO_EPI_BF16>(g, s);
-        case SHOWO_EPI_GELU_BF16: return launch2p_bm<SHOWO_EPI_GELU_BF16>(g, s);
-        case SHOWO_EPI_F32: return launch2p_bm<SHOWO_EPI_F32>(g, s);
-        case SHOWO_EPI_RESID_F32: return launch2p_bm<SHOWO_EPI_RESID_F32>(g, s);
-    }
-    return set_error_msg(1, "gemm: unknown epilogue");
-}
 
 // =====================================================================================================
 // GEMV form for decode steps (M <= 8 token rows): the weight matrix is streamed ONCE straight into VGPRs (no LDS round
@@ -1426,7 +925,7 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     if (impl == 4) return dispatch3<2>(g, epilogue, (hipStream_t)stream);
     if (impl == 6 && M <= 8 && (K % 8) == 0) return dispatch_gemv(g, epilogue, (hipStream_t)stream);
     if (impl == 6) impl = 1;
-    if (impl == 5) return dispatch2p(g, epilogue, (hipStream_t)stream);
+    if (impl == 5) return gemm2p_dispatch(g, epilogue, (hipStream_t)stream);
     if (impl == 2) {
         LinearPtr lp;
         lp.A = A; lp.lda = lda; lp.M = M;
@@ -1436,11 +935,14 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
 }
 
 // fused QKV projection: Q/K/V^T = relayout(rope(layernorm(A Wqkv^T + b)))  (reference models/phi.py:657-694)
-extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias,
-                                   const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
-                                   const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B,
-                                   int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream) {
-    const int M = B * L, N = 3 * nH * 64, Kd = nH * 64;
+// With ffn_out != NULL the weight is [Wqkv ; W1] ([3 nH 64 + F, K] rows, bias likewise) and the launch also produces
+// ffn_out[m][0..F) = gelu_new(A W1^T + b1) (models/phi.py:208-212): q/k/v and fc1 read the same LayerNorm output.
+static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias, const float* qln_w,
+                         const float* qln_b, const float* kln_w, const float* kln_b, const float* cos_tab, const float* sin_tab,
+                         uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
+                         uint16_t* ffn_out, int ldf, int F, void* stream) {
+    const int M = B * L, Nq = 3 * nH * 64, Kd = nH * 64;
+    const int N = Nq + (ffn_out ? F : 0);
     if (M <= 0) return 0;
     if (rot != 32) return set_error_msg(1, "gemm_qkv: the fused epilogue implements rotary_dim 32 (use showo_gemm_bf16 + showo_qk_prep)");
     if ((Lp % 64) || Lp < pos0 + L || Lcap < pos0 + L) return set_error_msg(1, "gemm_qkv: bad Lp/Lcap");
@@ -1448,14 +950,62 @@ extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* W
         return set_error_msg(1, "gemm_qkv: A/W must be 16B aligned with lda,ldw multiples of 8");
     if ((int64_t)M * lda * 2 >= ((int64_t)1 << 32) || (int64_t)N * ldw * 2 >= ((int64_t)1 << 32))
         return set_error_msg(1, "gemm_qkv: operand larger than 4 GiB");
+    if (ffn_out && (F <= 0 || (F % 4) || (ldf % 4) || (((uintptr_t)ffn_out) & 7) || (Nq % B2)))
+        return set_error_msg(1, "gemm_qkv_fc1: F, ldf must be multiples of 4, ffn_out 8B aligned, 3*nH*64 a multiple of 256");
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = Wqkv; g.ldw = ldw; g.Wlo = nullptr; g.bias = bias; g.bias_per_row = 0;
     g.out = nullptr; g.ldo = 0; g.resid = nullptr; g.ldr = 0; g.M = M; g.N = N; g.K = Kd; g.vec_out = 1;
-    g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1; g.flags = 0; g.dbg = nullptr;
+    g.gn = 1; g.flags = 0; g.dbg = nullptr;
     g.qw = qln_w; g.qb = qln_b; g.kw = kln_w; g.kb = kln_b; g.cosT = cos_tab; g.sinT = sin_tab;
     g.Q = Q; g.Kd = K; g.Vt = Vt; g.L = L; g.nH = nH; g.pos0 = pos0; g.Lcap = Lcap; g.Lp = Lp; g.eps = eps;
+    if (ffn_out) { g.Nq = Nq; g.out2 = ffn_out; g.ldo2 = ldf; }
     ProfScope prof(PROF_GEMM, 2.0 * M * N * Kd, (hipStream_t)stream);
-    return launch2p_bm<EPI_QKV>(g, (hipStream_t)stream);
+    return gemm2p_dispatch(g, EPI_QKV, (hipStream_t)stream);
+}
+
+extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias,
+                                   const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                   const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B,
+                                   int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream) {
+    return gemm_qkv_impl(A, lda, Wqkv, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps, pos0,
+                         Lcap, Lp, nullptr, 0, 0, stream);
+}
+
+extern "C" int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
+                                       const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                       const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                                       uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0,
+                                       int Lcap, int Lp, void* stream) {
+    if (!ffn_out) return set_error_msg(1, "gemm_qkv_fc1: ffn_out required");
+    return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
+                         pos0, Lcap, Lp, ffn_out, ldf, F, stream);
+}
+
+// K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias), A0 [M,K0] (lda0), A1 [M,K1] (lda1), weight rows
+// [W0[n,:] | W1[n,:]] (ldw >= K0 + K1).  Phi's parallel block adds dense(attn) and fc2(ffn) into the same residual row
+// (models/phi.py:774-790): x += [attn | ffn] [Wd | W2]^T + (bd + b2) is ONE launch with one residual read-modify-write.
+extern "C" int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W,
+                                    int ldw, const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N,
+                                    int epilogue, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K0 <= 0 || K1 <= 0 || (K0 % BK) || (K1 % BK)) return set_error_msg(1, "gemm_kcat: K0, K1 must be positive multiples of 64");
+    if (!A0 || !A1 || !W) return set_error_msg(1, "gemm_kcat: null operand");
+    if ((lda0 % 8) || (lda1 % 8) || (ldw % 8) || (((uintptr_t)A0) & 15) || (((uintptr_t)A1) & 15) || (((uintptr_t)W) & 15))
+        return set_error_msg(1, "gemm_kcat: operands must be 16B aligned with leading dimensions multiples of 8");
+    if (epilogue != SHOWO_EPI_RESID_F32) return set_error_msg(1, "gemm_kcat: only SHOWO_EPI_RESID_F32 is implemented (the residual projections)");
+    if (!resid) return set_error_msg(1, "gemm_kcat: resid required");
+    if ((int64_t)M * lda0 * 2 >= ((int64_t)1 << 32) || (int64_t)M * lda1 * 2 >= ((int64_t)1 << 32) || (int64_t)N * ldw * 2 >= ((int64_t)1 << 32))
+        return set_error_msg(1, "gemm_kcat: operand larger than 4 GiB");
+    GemmArgs g;
+    g.A = A0; g.lda = lda0; g.W = W; g.ldw = ldw; g.Wlo = nullptr; g.bias = bias; g.bias_per_row = 0;
+    g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.M = M; g.N = N; g.K = K0 + K1;
+    g.gn = 1; g.flags = 0; g.dbg = nullptr;
+    g.A2 = A1; g.lda2 = lda1; g.Ksplit = K0;
+    const bool f32 = (epilogue == SHOWO_EPI_F32 || epilogue == SHOWO_EPI_RESID_F32);
+    g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & (f32 ? 15 : 7)) == 0);
+    if (epilogue == SHOWO_EPI_RESID_F32) g.vec_out = g.vec_out && ((ldr % 4) == 0) && ((((uintptr_t)resid) & 15) == 0);
+    ProfScope prof(PROF_GEMM, 2.0 * M * N * (K0 + K1), (hipStream_t)stream);
+    return gemm2p_dispatch(g, epilogue, (hipStream_t)stream);
 }
 
 extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, const float* resid, float* out,

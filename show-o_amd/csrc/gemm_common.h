@@ -1,0 +1,224 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip, gemm2p.hip): launch arguments, epilogues, raw barrier.
+#pragma once
+#include "common.h"
+#include "../../include/showo_hip.h"
+
+namespace showo {
+
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    const bf16_t* Wlo;  // split-precision mode: low halves of the weights (same layout as W)
+    const float* bias; int bias_per_row;
+    void* out; int ldo;
+    const float* resid; int ldr;
+    int M, N, K;
+    int vec_out;  // 1: out/resid rows allow 4-wide vector access
+    int gn;       // v3: n-panels per tile group (L2 locality of the block -> tile map)
+    int flags;    // v3 experiments: bit0 = no group stagger
+    unsigned long long* dbg;  // v3 debug build: per-barrier timestamps of block 0
+    // fused q/k LayerNorm + RoPE + head-major relayout epilogue (EPI_QKV): out is unused
+    const float *qw, *qb, *kw, *kb, *cosT, *sinT;
+    bf16_t *Q, *Kd, *Vt;
+    int L, nH, pos0, Lcap, Lp;
+    float eps;
+    // gemm2p only.  K-concatenated activation operand: columns k < Ksplit come from A (lda), k >= Ksplit from A2 (lda2) at
+    // k - Ksplit; the weight rows are [W_a | W_b] (K-contiguous, ldw).  Phi's block adds dense(attn) and fc2(ffn) into the same
+    // residual row (models/phi.py:774-790), so both projections are ONE GEMM over K = H + F with one residual read-modify-write.
+    const bf16_t* A2 = nullptr; int lda2 = 0; int Ksplit = 1 << 30;
+    // EPI_QKV only: output columns n >= Nq are the fc1 rows of the [Wqkv ; W1] weight: bias + gelu_new -> out2[m][n - Nq] (bf16).
+    // q/k/v and fc1 read the same LayerNorm output (models/phi.py:776-790).
+    int Nq = 1 << 30; bf16_t* out2 = nullptr; int ldo2 = 0;
+};
+
+constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
+constexpr int B2 = 256;   // tile width (n) of the 256-wide kernels
+constexpr int GEMM_BK = 64;
+constexpr int P3_BUF_ELEMS = 2 * 256 * 64;  // one k-tile: W[256][64] then A[256][64] (64 KiB)
+constexpr int SMEM3_BYTES = 2 * P3_BUF_ELEMS * 2;
+
+static __device__ inline void load_bias4(const GemmArgs& g, int n, float (&bn)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bn[r] = 0.f;
+    if (g.bias && !g.bias_per_row) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bn[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
+    }
+}
+
+// one MFMA C fragment: this lane holds out[m][n .. n+3]
+template <int EPI>
+static __device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, int m, int n, const float (&bn)[4]) {
+    if (m >= g.M || n >= g.N) return;
+    float v[4];
+    const float bm = (g.bias && g.bias_per_row) ? g.bias[m] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] + bn[r] + bm;
+    const bool full = (n + 3 < g.N) && g.vec_out;
+    if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
+        if (EPI == SHOWO_EPI_GELU_BF16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_new_fast(v[r]);
+        }
+        bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
+        if (full) {
+            uint2 pk;
+            pk.x = pack_bf2(v[0], v[1]);
+            pk.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(o) = pk;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < g.N) o[r] = f2bf(v[r]);
+        }
+    } else {
+        float* o = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n;
+        if (EPI == SHOWO_EPI_RESID_F32) {
+            const float* rs = g.resid + (int64_t)m * g.ldr + n;
+            if (full) {
+                float4 rv = *reinterpret_cast<const float4*>(rs);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) v[r] += rs[r];
+            }
+        }
+        if (full) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < g.N) o[r] = v[r];
+        }
+    }
+}
+
+static __device__ __forceinline__ void bar_raw_fn() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
+// the wave's m range, n0 + wn*64 = its first column.
+template <int EPI, int MF>
+static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg) {
+    if constexpr (EPI == EPI_QKV) {
+        // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
+        // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
+        // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
+        const int nbase = n0 + wn * 64;
+        if (n0 >= g.Nq) {  // fc1 tail of the fused [Wqkv ; W1] projection (block-uniform: Nq is a multiple of the tile width)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nbase + i * 16 + fg * 4;
+                float bn[4];
+                load_bias4(g, n, bn);
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = mrow0 + j * 16 + fr;
+                    if (m >= g.M || n >= g.N) continue;
+                    uint2 pk;
+                    pk.x = pack_bf2(gelu_new_fast(acc[i][j][0] + bn[0]), gelu_new_fast(acc[i][j][1] + bn[1]));
+                    pk.y = pack_bf2(gelu_new_fast(acc[i][j][2] + bn[2]), gelu_new_fast(acc[i][j][3] + bn[3]));
+                    *reinterpret_cast<uint2*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
+                }
+            }
+        } else if (nbase < g.N) {
+            const int Hq = g.nH * 64;
+            const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)
+            const int head = (nbase - which * Hq) >> 6;
+            float bn[4][4], lw[4][4], lb[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                load_bias4(g, nbase + i * 16 + fg * 4, bn[i]);
+                if (which < 2) {
+                    const float4 w4 = *reinterpret_cast<const float4*>((which ? g.kw : g.qw) + i * 16 + fg * 4);
+                    const float4 b4 = *reinterpret_cast<const float4*>((which ? g.kb : g.qb) + i * 16 + fg * 4);
+                    lw[i][0] = w4.x; lw[i][1] = w4.y; lw[i][2] = w4.z; lw[i][3] = w4.w;
+                    lb[i][0] = b4.x; lb[i][1] = b4.y; lb[i][2] = b4.z; lb[i][3] = b4.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int m = mrow0 + j * 16 + fr;
+                const bool valid = m < g.M;
+                const int mm = valid ? m : g.M - 1;
+                const int b = mm / g.L, l = mm - b * g.L, pos = g.pos0 + l;
+                const int64_t bh = (int64_t)b * g.nH + head;
+                float x[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
+                if (which == 2) {  // V^T[bh][d][pos]
+                    if (valid) {
+                        bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = f2bf(x[i][r]);
+                    }
+                    continue;
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.0f / 64.0f);
+                float sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[i][r] = x[i][r] * rstd * lw[i][r] + lb[i][r];
+                // partial rotary over dims [0, 32): rotate_half pairs d with d + 16 = fragments i = 0 and 1 of this lane
+                const float4 c0 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + fg * 4);
+                const float4 s0 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + fg * 4);
+                const float4 c1 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + 16 + fg * 4);
+                const float4 s1 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + 16 + fg * 4);
+                const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, ss0[4] = {s0.x, s0.y, s0.z, s0.w};
+                const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = x[0][r], y1 = x[1][r];
+                    x[0][r] = y0 * cc0[r] - y1 * ss0[r];
+                    x[1][r] = y1 * cc1[r] + y0 * ss1[r];
+                }
+                if (!valid) continue;
+                const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact in bf16)
+                bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + pos) * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint2 pk;
+                    pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
+                    pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
+                    *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
+#pragma unroll
+            for (int j = 0; j < MF; ++j) store_frag<EPI>(g, acc[i][j], mrow0 + j * 16 + fr, n, bn);
+        }
+    }
+}
+
+// production kernel (gemm2p.hip)
+int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
+extern int g_gemm_gn, g_gemm_bm;
+
+}  // namespace showo

@@ -535,12 +535,12 @@ def test_softmax_rows_and_small_conv():
     assert (out.cpu() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5, 5 + (256 << 16), 5 + (208 << 16), 5 + (160 << 16)])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5] + [5 + (v << 16) for v in (256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128)])
 def test_gemm_both_tile_kernels(impl):
     """the 128^2 register-staged kernel and the 256^2 global_load_lds kernel give the same result on shapes
     with ragged M/N edges (rows/cols beyond the edge are clamped on load and predicated on store)"""
     L().call("showo_gemm_set_impl", impl & 0xffff)
-    L().call("showo_gemm_tune", 8, (impl >> 16) << 8, None)  # impl 5: forced tile height 256 / 208 / 160 (0 = automatic)
+    L().call("showo_gemm_tune", 8, (impl >> 16) << 8, None)  # impl 5: forced tile variant = rows (+ 1000: n-split phase program); 0 = automatic
     try:
         torch.manual_seed(impl & 0xffff)
         for (M, N, K) in [(1100, 520, 192), (6192 // 4, 2048, 256), (300, 256, 64)]:
@@ -557,6 +557,68 @@ def test_gemm_both_tile_kernels(impl):
     finally:
         L().call("showo_gemm_set_impl", 0)
         L().call("showo_gemm_tune", 8, 0, None)
+
+
+@pytest.mark.parametrize("variant", [0, 256, 208, 1176, 1144])
+@pytest.mark.parametrize("M,K0,K1,N", [(700, 128, 512, 384), (1548, 256, 1024, 2048), (300, 64, 64, 256)])
+def test_gemm_kcat_residual(variant, M, K0, K1, N):
+    """showo_gemm_kcat_bf16: x += [A0 | A1] [W0 | W1]^T + bias in one launch (Phi's dense + fc2 into the same residual row,
+    models/phi.py:774-790), operands with DIFFERENT leading dimensions; fp64 reference on the same bf16-rounded operands."""
+    torch.manual_seed(M + variant)
+    A0, A1 = torch.randn(M, K0), torch.randn(M, K1)
+    W = torch.randn(N, K0 + K1) * 0.05
+    bias, x = torch.randn(N), torch.randn(M, N)
+    ref = bf16_round(torch.cat([A0, A1], 1)).double() @ bf16_round(W).double().T + bias.double() + x.double()
+    xd = dev(x.clone())
+    L().call("showo_gemm_tune", 8, variant << 8, None)
+    try:
+        L().call("showo_gemm_kcat_bf16", L().ptr(dev(to_bf16_bits(A0))), K0, K0, L().ptr(dev(to_bf16_bits(A1))), K1, K1,
+                 L().ptr(dev(to_bf16_bits(W))), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, L().ptr(xd), N, M, N, 3, S())
+        sync()
+    finally:
+        L().call("showo_gemm_tune", 8, 0, None)
+    assert (xd.cpu().double() - ref).abs().max() < 1e-3 * float(ref.abs().max())
+    with pytest.raises(RuntimeError):  # only the residual epilogue is implemented
+        L().call("showo_gemm_kcat_bf16", L().ptr(dev(to_bf16_bits(A0))), K0, K0, L().ptr(dev(to_bf16_bits(A1))), K1, K1,
+                 L().ptr(dev(to_bf16_bits(W))), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, None, 0, M, N, 2, S())
+
+
+@pytest.mark.parametrize("variant", [256, 224, 1192, 1160, 1128])
+@pytest.mark.parametrize("B,Lq,nH,F", [(2, 387, 4, 512), (3, 130, 4, 1024)])
+def test_fused_qkv_fc1_equals_separate_launches_bits(variant, B, Lq, nH, F):
+    """showo_gemm_qkv_fc1_bf16 ([Wqkv ; W1], column-split epilogue) is bit-identical to showo_gemm_qkv_bf16 + the fc1 GELU GEMM
+    at the same tile variant (same k order per output element)."""
+    torch.manual_seed(B * 100 + Lq + variant)
+    H, M = nH * 64, B * Lq
+    h = dev(to_bf16_bits(torch.randn(M, H)))
+    W = dev(to_bf16_bits(torch.randn(3 * H + F, H) * 0.05))
+    bias = dev(torch.randn(3 * H + F) * 0.1)
+    ln = [dev(t) for t in (torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05)]
+    cos, sin = (dev(t) for t in _rope_tables())
+    Lp = ((Lq + 63) // 64) * 64
+    outs = []
+    L().call("showo_gemm_tune", 8, variant << 8, None)
+    try:
+        for fused in (0, 1):
+            Q = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
+            K = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
+            Vt = torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda")
+            f = torch.zeros((M, F), dtype=torch.int16, device="cuda")
+            if fused:
+                L().call("showo_gemm_qkv_fc1_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos),
+                         L().ptr(sin), L().ptr(Q), L().ptr(K), L().ptr(Vt), L().ptr(f), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp, S())
+            else:
+                L().call("showo_gemm_qkv_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos),
+                         L().ptr(sin), L().ptr(Q), L().ptr(K), L().ptr(Vt), B, Lq, nH, 32, 1e-5, 0, Lq, Lp, S())
+                L().call("showo_gemm_bf16", L().ptr(h), H, W.data_ptr() + 3 * H * H * 2, H, bias.data_ptr() + 3 * H * 4, 0, L().ptr(f), F,
+                         None, 0, M, F, H, 1, S())
+            sync()
+            outs.append((Q, K, Vt, f))
+    finally:
+        L().call("showo_gemm_tune", 8, 0, None)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[1][3].ne(0).sum()) > 0.9 * M * F  # the fc1 tail was written
 
 
 # ------------------------------------------------------------------------------------ split-precision (bf16 x3) kernels

@@ -58,10 +58,19 @@ int main(int argc, char** argv) {
         {6192, 2048, 8192, 3, "fc2"}, {4096, 8192, 2048, 2, "lm_head rows"}, {6192, 14336, 2048, 0, "qkv|fc1 fused"},
         {6192, 2048, 10240, 3, "dense|fc2 fused"}, {4128, 6144, 2048, 0, "qkv act258"}, {4128, 2048, 2048, 3, "dense act258"}, {4128, 8192, 2048, 1, "fc1 act258"}, {4128, 2048, 8192, 3, "fc2 act258"}, {4128, 2048, 10240, 3, "dense|fc2 act258"}, {4128, 14336, 2048, 0, "qkv|fc1 act258"}, {9240, 6144, 2048, 0, "qkv L1155"}, {9240, 2048, 8192, 3, "fc2 L1155"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
     };
+    if (quick == 2) {  // the shapes of the t2i pipeline (steps 1..17: 4128 rows; step 0: 6192 rows), separate and fused
+        shapes = {
+            {300, 256, 64, 2, "edge-small"}, {1100, 520, 192, 2, "edge-ragged"}, {1548, 2048, 256, 3, "ragged-resid"},
+            {4128, 6144, 2048, 0, "qkv act258"}, {4128, 8192, 2048, 1, "fc1 act258"}, {4128, 14336, 2048, 0, "qkv|fc1 act258"},
+            {4128, 2048, 2048, 3, "dense act258"}, {4128, 2048, 8192, 3, "fc2 act258"}, {4128, 2048, 10240, 3, "dense|fc2 act258"},
+            {6192, 14336, 2048, 0, "qkv|fc1 full"}, {6192, 2048, 10240, 3, "dense|fc2 full"},
+            {4096, 8192, 2048, 2, "lm_head rows"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
+        };
+    }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& s : shapes) {
-        if (quick && (size_t)s.M * s.N * s.K > (size_t)6192 * 14336 * 2048) continue;
+        if (quick == 1 && (size_t)s.M * s.N * s.K > (size_t)6192 * 14336 * 2048) continue;
         const size_t nA = (size_t)s.M * s.K, nW = (size_t)s.N * s.K, nO = (size_t)s.M * s.N;
         int R = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)1 << 30) / (nW * 2)));
         uint16_t *A, *W; float *bias, *resid; void *out_ref, *out;
@@ -139,6 +148,97 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(resid)); CK(hipFree(out_ref)); CK(hipFree(out));
     }
+
+    // ---- fused entry points: K-concatenated residual GEMM and the [Wqkv ; W1] projection, checked against the separate launches
+    for (int M : {4128, 6192, 700}) {
+        const int H = 2048, F = 8192, nH = 32, B = M == 700 ? 2 : 16, L = M / B, Lp = ((L + 63) / 64) * 64;
+        const int Mx = B * L;
+        uint16_t *attn, *ffn, *Wd, *W2, *Wcat, *h, *Wq1, *Q0, *K0, *V0, *Q1, *K1, *V1, *f0, *f1;
+        float *x0, *x1, *bd, *b2, *bsum, *bq1, *lnp, *cosT, *sinT;
+        CK(hipMalloc(&attn, (size_t)Mx * H * 2)); CK(hipMalloc(&ffn, (size_t)Mx * F * 2)); CK(hipMalloc(&Wd, (size_t)H * H * 2)); CK(hipMalloc(&W2, (size_t)H * F * 2));
+        CK(hipMalloc(&Wcat, (size_t)H * (H + F) * 2)); CK(hipMalloc(&x0, (size_t)Mx * H * 4)); CK(hipMalloc(&x1, (size_t)Mx * H * 4));
+        CK(hipMalloc(&bd, H * 4)); CK(hipMalloc(&b2, H * 4)); CK(hipMalloc(&bsum, H * 4));
+        fill_kernel<<<1024, 256, 0, st>>>(attn, (size_t)Mx * H, 11u, 1.0f);
+        fill_kernel<<<1024, 256, 0, st>>>(ffn, (size_t)Mx * F, 12u, 1.0f);
+        fill_kernel<<<1024, 256, 0, st>>>(Wd, (size_t)H * H, 13u, 0.02f);
+        fill_kernel<<<1024, 256, 0, st>>>(W2, (size_t)H * F, 14u, 0.02f);
+        CK(hipMemcpy2DAsync(Wcat, (size_t)(H + F) * 2, Wd, (size_t)H * 2, (size_t)H * 2, H, hipMemcpyDeviceToDevice, st));
+        CK(hipMemcpy2DAsync(Wcat + H, (size_t)(H + F) * 2, W2, (size_t)F * 2, (size_t)F * 2, H, hipMemcpyDeviceToDevice, st));
+        std::vector<float> hb(H), hb2(H), hs(H);
+        for (int i = 0; i < H; ++i) { hb[i] = 0.01f * ((i * 37) % 101 - 50); hb2[i] = 0.02f * ((i * 53) % 89 - 44); hs[i] = hb[i] + hb2[i]; }
+        CK(hipMemcpy(bd, hb.data(), H * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b2, hb2.data(), H * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(bsum, hs.data(), H * 4, hipMemcpyHostToDevice));
+        std::vector<float> hx((size_t)Mx * H);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = 0.001f * (float)((i * 2654435761u) % 2001) - 1.0f;
+        RC(showo_gemm_set_impl(0)); RC(showo_gemm_tune(8, 0, nullptr));
+        // reference: x += attn Wd^T + bd ; x += ffn W2^T + b2 with the 128^2 kernel
+        CK(hipMemcpy(x0, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        RC(showo_gemm_set_impl(1));
+        RC(showo_gemm_bf16(attn, H, Wd, H, bd, 0, x0, H, x0, H, Mx, H, H, 3, st));
+        RC(showo_gemm_bf16(ffn, F, W2, F, b2, 0, x0, H, x0, H, Mx, H, F, 3, st));
+        RC(showo_gemm_set_impl(0));
+        CK(hipStreamSynchronize(st));
+        std::vector<float> r0((size_t)Mx * H), r1((size_t)Mx * H);
+        CK(hipMemcpy(r0.data(), x0, r0.size() * 4, hipMemcpyDeviceToHost));
+        const int vars[] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128};
+        printf("kcat M=%d:", Mx);
+        for (int v : vars) {
+            RC(showo_gemm_tune(8, v << 8, nullptr));
+            size_t bad = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipMemcpy(x1, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+                RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wcat, H + F, bsum, x1, H, x1, H, Mx, H, 3, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(r1.data(), x1, r1.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < r0.size(); ++i) if (!(fabs((double)r0[i] - r1[i]) <= 2e-3 * (1 + fabs(r0[i])))) bad++;
+            }
+            const int iters = 10;
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wcat, H + F, bsum, x1, H, x1, H, Mx, H, 3, st));
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf(" %d:%.0fTF%s", v, 2.0 * Mx * H * (H + F) * iters / (ms * 1e-3) / 1e12, bad ? "**MISMATCH**" : "");
+            fflush(stdout);
+        }
+        printf("\n");
+        // [Wqkv ; W1]: bitwise against showo_gemm_qkv_bf16 + the GELU GEMM at the same tile variant
+        const int Nq = 3 * H;
+        CK(hipMalloc(&h, (size_t)Mx * H * 2)); CK(hipMalloc(&Wq1, (size_t)(Nq + F) * H * 2)); CK(hipMalloc(&bq1, (Nq + F) * 4));
+        CK(hipMalloc(&lnp, 4 * 64 * 4)); CK(hipMalloc(&cosT, 2048 * 32 * 4)); CK(hipMalloc(&sinT, 2048 * 32 * 4));
+        const size_t nqk = (size_t)B * nH * L * 64, nvt = (size_t)B * nH * 64 * Lp;
+        CK(hipMalloc(&Q0, nqk * 2)); CK(hipMalloc(&K0, nqk * 2)); CK(hipMalloc(&V0, nvt * 2)); CK(hipMalloc(&Q1, nqk * 2)); CK(hipMalloc(&K1, nqk * 2)); CK(hipMalloc(&V1, nvt * 2));
+        CK(hipMalloc(&f0, (size_t)Mx * F * 2)); CK(hipMalloc(&f1, (size_t)Mx * F * 2));
+        fill_kernel<<<1024, 256, 0, st>>>(h, (size_t)Mx * H, 21u, 1.0f);
+        fill_kernel<<<1024, 256, 0, st>>>(Wq1, (size_t)(Nq + F) * H, 22u, 0.02f);
+        std::vector<float> hq(Nq + F), hl(256), hc(2048 * 32), hsn(2048 * 32);
+        for (int i = 0; i < Nq + F; ++i) hq[i] = 0.01f * ((i * 37) % 101 - 50);
+        for (int i = 0; i < 256; ++i) hl[i] = (i & 64) ? 0.01f * (i % 7) : 1.0f + 0.01f * (i % 5);  // qw | qb | kw | kb
+        for (int p = 0; p < 2048; ++p) for (int j = 0; j < 32; ++j) { double a = p * pow(10000.0, -2.0 * (j % 16) / 32.0); hc[p * 32 + j] = (float)cos(a); hsn[p * 32 + j] = (float)sin(a); }
+        CK(hipMemcpy(bq1, hq.data(), hq.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(lnp, hl.data(), 1024, hipMemcpyHostToDevice));
+        CK(hipMemcpy(cosT, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(sinT, hsn.data(), hsn.size() * 4, hipMemcpyHostToDevice));
+        printf("qkv|fc1 M=%d:", Mx);
+        for (int v : vars) {
+            RC(showo_gemm_tune(8, v << 8, nullptr));
+            CK(hipMemsetAsync(V0, 0, nvt * 2, st)); CK(hipMemsetAsync(V1, 0, nvt * 2, st));
+            RC(showo_gemm_qkv_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q0, K0, V0, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
+            RC(showo_gemm_bf16(h, H, Wq1 + (size_t)Nq * H, H, bq1 + Nq, 0, f0, F, nullptr, 0, Mx, F, H, 1, st));
+            RC(showo_gemm_qkv_fc1_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
+            CK(hipStreamSynchronize(st));
+            auto same = [&](const uint16_t* a, const uint16_t* b, size_t n) { std::vector<uint16_t> x(n), y(n); CK(hipMemcpy(x.data(), a, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), b, n * 2, hipMemcpyDeviceToHost)); return memcmp(x.data(), y.data(), n * 2) == 0; };
+            const bool ok = same(Q0, Q1, nqk) && same(K0, K1, nqk) && same(V0, V1, nvt) && same(f0, f1, (size_t)Mx * F);
+            const int iters = 10;
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) RC(showo_gemm_qkv_fc1_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf(" %d:%.0fTF%s", v, 2.0 * Mx * (Nq + F) * H * iters / (ms * 1e-3) / 1e12, ok ? "" : "**MISMATCH**");
+            fflush(stdout);
+        }
+        printf("\n");
+        for (void* p : {(void*)attn, (void*)ffn, (void*)Wd, (void*)W2, (void*)Wcat, (void*)x0, (void*)x1, (void*)bd, (void*)b2, (void*)bsum, (void*)h, (void*)Wq1, (void*)bq1,
+                        (void*)lnp, (void*)cosT, (void*)sinT, (void*)Q0, (void*)K0, (void*)V0, (void*)Q1, (void*)K1, (void*)V1, (void*)f0, (void*)f1}) CK(hipFree(p));
+    }
+    RC(showo_gemm_tune(8, 0, nullptr));
     RC(showo_gemm_set_impl(0));
     return 0;
 }
