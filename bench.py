@@ -93,6 +93,33 @@ def cpu_baseline(budget_s=30.0):
                       f"scaled x18/{n}; decode_code omitted (<1% of FLOPs)"}
 
 
+def self_launch(gpus, script):
+    """`python bench.py --gpus N` without a launcher: re-exec as N ranks (one process per GPU) under torch.distributed.run, as
+    the reference is started by `accelerate launch` (training/train.py:91-110; accelerate_configs/8_gpus_deepspeed_zero2.yaml).
+    Under a launcher (WORLD_SIZE set, the driver's form) this returns and the process is one of the ranks."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != gpus:
+            raise SystemExit(f"bench: --gpus {gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+        return
+    if gpus <= 1:
+        return
+    have = torch.cuda.device_count()
+    if have < gpus:
+        raise SystemExit(f"bench: --gpus {gpus} requested but {have} GPU(s) are visible")
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(script)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def aggregate(dt, units_local, dist=None, device="cpu"):
     """whole-job numbers of a replica-parallel run: (max elapsed time over ranks, units processed by all ranks).
     Independent units, no data-path collective: this MAX / SUM pair is the only communication of the benchmark."""
@@ -121,6 +148,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the denoise step as a hipGraph (no per-launch events: roofline leg reports null)")
     ap.add_argument("--workload", default="t2i", help="t2i (default, the headline metric) | train (bench_train.py: stage-1 step time)")
     a = ap.parse_args()
+    self_launch(a.gpus, __file__)
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # shows where a stuck run is
 

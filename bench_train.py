@@ -27,6 +27,55 @@ def synthetic_texts(rs, b_t2i, b_lm, b_mmu):
     return t2i, lm, mmu
 
 
+def cpu_baseline(n_seq, budget_s=40.0):
+    """oracle (CPU restatement of the reference, fp32, torch autograd) forward + backward of a 3-sequence micro-batch (1 t2i +
+    1 lm + 1 mmu x 387 tokens, the three losses of models/modeling_showo.py:80-98 weighted 1.0 / 0.1 / 1.0) + one torch AdamW
+    step over the 1.45 B parameters; the forward + backward time is scaled linearly to the n_seq sequences of the stage-1
+    per-GPU batch (the full batch does not fit host memory with fp32 activations: BASELINE.md section 3).  The frozen VQ encode
+    is left out of the CPU estimate (favouring the CPU).  The ONLY place in this file that touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bench
+    import showo_oracle as O
+    import weights as Wt
+    d = Wt.ShowoDims()
+    threads = bench._pick_threads()
+    g = torch.Generator().manual_seed(0)
+    sd = {k: (torch.randn(shape, generator=g) * std + mean).requires_grad_(True) for k, (shape, std, mean) in Wt.showo_state_spec(d).items()}
+    L = 387
+    rs = np.random.RandomState(0)
+    t2i = [d.pad_id] * 100 + [d.t2i_id, 50256] + rs.randint(0, 50256, size=26).tolist() + [50256, d.soi_id] + [d.mask_token_id] * 256 + [d.eoi_id]
+    lm = rs.randint(0, 50256, size=L).tolist()
+    mmu = [d.mmu_id, d.soi_id] + (rs.randint(0, 8192, size=256) + d.llm_vocab + d.num_new_special_tokens).tolist() + [d.eoi_id] + rs.randint(0, 50256, size=128).tolist()
+    ids = torch.tensor([t2i, lm, mmu])
+    causal = torch.zeros(1, 1, L, L)
+    causal[0, 0][torch.triu(torch.ones(L, L, dtype=torch.bool), 1)] = O.NEG_MASK
+    mask = torch.cat([O.mask_t2i(ids[:1], d.pad_id, d.soi_id, d.eoi_id), causal, O.mask_mmu(ids[2:], d.eoi_id)])
+    labels = ids.clone()
+    labels[0, :131] = -100
+
+    def fwd_bwd():
+        _, l1, l2, l3 = O.showo_forward(sd, d, ids, attention_mask=mask, labels=labels, batch_size_t2i=1, batch_size_lm=1, batch_size_mmu=1,
+                                        max_seq_length=128)
+        (l1 + 0.1 * l2 + l3).backward()
+
+    t0 = time.time()
+    fwd_bwd()  # warm-up (page-in, thread pool)
+    t_warm = time.time() - t0
+    n = int(max(1, min(3, budget_s // max(t_warm, 1e-3))))
+    t0 = time.time()
+    for _ in range(n):
+        fwd_bwd()
+    t_fb = (time.time() - t0) / n
+    opt = torch.optim.AdamW(list(sd.values()), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    t0 = time.time()
+    opt.step()
+    t_opt = time.time() - t0
+    est = t_fb * n_seq / 3.0 + t_opt
+    return {"value": est * 1e3, "unit": "ms/step", "cores": threads, "kind": "port",
+            "sample": f"{n} x forward+backward of a 3-sequence micro-batch (1 t2i + 1 lm + 1 mmu x 387 tokens, fp32 oracle autograd) = "
+                      f"{t_fb:.1f}s each, scaled x{n_seq}/3, + one torch AdamW step over 1.45 B parameters = {t_opt:.1f}s; VQ encode omitted"}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,7 +83,13 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-vq", action="store_true", help="leave the frozen VQ encode of the 25 images out of the step")
     ap.add_argument("--workload", default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (A/B of their overhead)")
+    ap.add_argument("--event-stride", type=int, default=5)
+    ap.add_argument("--wire", default="bf16", help="gradient wire of the data-parallel exchange: bf16 (default) | fp32")
     a = ap.parse_args(argv)
+    import bench
+    bench.self_launch(a.gpus, sys.argv[0])  # `--gpus N` without a launcher: re-exec as N ranks under torch.distributed.run
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local)
     dist = None
@@ -47,7 +102,7 @@ def main(argv=None):
     bt, bl, bm = 15, 4, 10
     torch.manual_seed(0)  # same initial weights on every rank (data parallel replicas)
     model = synthetic.random_init_showo(max_batch=bt + bl + bm, max_seq=387).train()
-    trainer = showo_amd.Trainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0))
+    trainer = showo_amd.Trainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0), wire=a.wire)
     vq = None if a.no_vq else showo_amd.MAGVITv2(max_batch=bt + bm, max_res=256).cuda().eval()
     uni = synthetic.prompting(max_text_len=128, cond_dropout_prob=0.1)
     off = len(uni.text_tokenizer)  # image-token offset (training/train.py:476)
@@ -76,15 +131,29 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
+    import ctypes as C
+    L = showo_amd._lib
     losses = None
     for _ in range(a.warmup):
         losses = step()
+    L.call("showo_prof_reset")
+    L.call("showo_prof_set_stride", a.event_stride)  # per-launch events on a systematic sample of the launches
+    L.call("showo_prof_enable", 0 if a.no_events else 1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = step()
     barrier()
     dt = time.perf_counter() - t0
+    L.call("showo_prof_enable", 0)
+    prof = {}
+    for kind, name in ((0, "gemm"), (1, "attention_fwd"), (2, "vq_conv")):
+        ms_k, n_k, fl_k = C.c_double(), C.c_int64(), C.c_double()
+        L.call("showo_prof_read", kind, C.byref(ms_k), C.byref(n_k), C.byref(fl_k))
+        n_all, fl_all = C.c_int64(), C.c_double()
+        L.call("showo_prof_totals", kind, C.byref(n_all), C.byref(fl_all))
+        prof[name] = {"ms": ms_k.value, "timed": int(n_k.value), "flop_timed": fl_k.value, "launches": int(n_all.value), "flop": fl_all.value}
+    L.call("showo_prof_reset")
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -93,6 +162,20 @@ def main(argv=None):
         T = (bt + bl + bm) * 387
         ms = dt / a.steps * 1e3
         flop = 3 * T * 2.732e9 + (0 if vq is None else (bt + bm) * 0.355e12)  # 3 x 11 223 x F(387) + encoder
+        gm = prof["gemm"]
+        ach = gm["flop_timed"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM: forward, dgrad and wgrad projections + lm_head, every epilogue)",
+                    "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                    "launches": gm["launches"], "timed_launches": gm["timed"], "avg_launch_ms": gm["ms"] / max(1, gm["timed"]),
+                    "executed_tflop_per_step": gm["flop"] / a.steps / 1e12,
+                    "time_share_of_step": (gm["flop"] / max(1e-9, ach * 1e12)) / dt if ach > 0 else None,
+                    "attention_fwd": {"achieved": prof["attention_fwd"]["flop_timed"] / max(1e-9, prof["attention_fwd"]["ms"] * 1e-3) / 1e12},
+                    "vq_conv": {"achieved": prof["vq_conv"]["flop_timed"] / max(1e-9, prof["vq_conv"]["ms"] * 1e-3) / 1e12}}
+        cpu = None
+        if not a.no_cpu_baseline and world == 1:
+            del trainer, model, vq
+            torch.cuda.empty_cache()
+            cpu = cpu_baseline(bt + bl + bm)
         print(json.dumps({
             "metric": "train step-time (stage-1 mixed batch, fwd+bwd+AdamW" + ("" if vq is None else "+VQ encode") + ")",
             "value": ms, "unit": "ms/step", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
@@ -101,7 +184,9 @@ def main(argv=None):
                                    "random-init Show-o 1.45B, AdamW lr 1e-4", "global_batch": (bt + bl + bm) * world, "seq_len": 387,
                        "parallelism": f"dp{world}", "tokens_per_s": T * world / (ms * 1e-3),
                        "algorithmic_tflops_per_gpu": flop / (ms * 1e-3) / 1e12,
+                       "gradient_wire": a.wire if world > 1 else None,
                        "losses_last_step": [float(x) for x in losses.cpu()]},
+            "roofline": roofline, "cpu_baseline": cpu,
         }))
     if dist is not None:
         dist.destroy_process_group()

@@ -116,12 +116,13 @@ int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ld
 /* showo_gemm_qkv_bf16 and fc1 + gelu_new in ONE launch: PhiDecoderLayer feeds the same LayerNorm output to q/k/v_proj and to
  * mlp.fc1 (models/phi.py:776-790, 208-212), so the weight is the row concatenation [Wqkv ; W1] bf16 [3*nH*64 + F, ldw] (bias
  * fp32 [3*nH*64 + F]); output columns below 3*nH*64 take the QKV epilogue above, the others
- * ffn_out bf16 [B*L, ldf] = gelu_new(A W1^T + b1).  Results are bit-identical to the two separate launches. */
+ * ffn_out bf16 [B*L, ldf] = gelu_new(A W1^T + b1).  Results are bit-identical to the two separate launches.
+ * w_tiled = 1: Wqkv_fc1 is the tiled copy made by showo_gemm_tile_weight (ldw must equal K = nH*64). */
 int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
                             const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
                             const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                             uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0, int Lcap,
-                            int Lp, void* stream);
+                            int Lp, int w_tiled, void* stream);
 
 /* K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias) with A0 bf16 [M,K0] (lda0), A1 bf16 [M,K1] (lda1) and
  * weight rows [W0[n,:] | W1[n,:]] bf16 [N, ldw] (ldw >= K0 + K1; K0, K1 multiples of 64).  epilogue must be SHOWO_EPI_RESID_F32
@@ -130,7 +131,15 @@ int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1
  * is one launch with ONE read-modify-write of the fp32 residual stream instead of two. */
 int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W, int ldw,
                          const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N, int epilogue,
-                         void* stream);
+                         int w_tiled, void* stream);
+
+/* Tiled weight layout accepted by the two entry points above (w_tiled = 1): [ceil(N/256)][K/64][256][64] bf16, rows beyond N zero,
+ * the eight 16-byte chunks of a row stored at position chunk ^ (row & 7).  One (panel, k-tile) block = 32 KiB = the LDS image the
+ * kernel's DMA fills, so a k-loop streams ONE contiguous region per weight panel (DRAM-page friendly; 1 KiB contiguous per
+ * wave-instruction).  showo_gemm_tiled_elems = number of bf16 elements of the tiled copy.  W bf16 [N, ldw] row-major (for the
+ * K-concatenated GEMM: the [W0 | W1] rows, K = K0 + K1). */
+int64_t showo_gemm_tiled_elems(int N, int K);
+int showo_gemm_tile_weight(const uint16_t* W, int ldw, int N, int K, uint16_t* out, void* stream);
 
 /* Compress an additive attention mask [B,1,Lq,Lk] fp32 (values 0 / very negative, as built by
  * training/prompting_utils.py:466-511, 591-624) into per-row visibility intervals
@@ -233,6 +242,13 @@ int showo_embed_bwd(const int64_t* ids, const float* dx, float* dE, int* order_w
 int showo_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int step, void* stream);
 int showo_scale_f32(float* x, int64_t n, float s, void* stream);
+
+/* bf16 gradient wire of the data-parallel exchange (reference: mixed_precision bf16 + DeepSpeed ZeRO-2 reduce,
+ * configs/showo_pretraining_stage1.yaml:87, accelerate_configs/8_gpus_deepspeed_zero2.yaml:2-16; SURVEY.md 8e: 2.90 GB per rank
+ * per step).  pack: wire[i] = bf16(grad[i] * scale), scale = 1 / world_size applied before rounding, so that the all-reduce SUM
+ * of the wire is the mean; unpack: grad[i] = float(wire[i]).  grad 16-byte, wire 8-byte aligned. */
+int showo_grad_wire_pack(const float* grad, uint16_t* wire, int64_t n, float scale, void* stream);
+int showo_grad_wire_unpack(const uint16_t* wire, float* grad, int64_t n, void* stream);
 /* df = da * gelu_new'(f) (bf16, elementwise) */
 int showo_dgelu_bf16(const uint16_t* da, const uint16_t* f, uint16_t* df, int64_t n, void* stream);
 

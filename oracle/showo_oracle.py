@@ -57,11 +57,42 @@ def apply_partial_rope(x, cos, sin, rotary_dim):
 # ----------------------------------------------------------------------------------------------
 # Phi transformer forward (models/phi.py:655-729, 774-790, 953-1081, 1169-1183)
 # ----------------------------------------------------------------------------------------------
-def phi_attention(sd, p, d, h, mask, cos, sin):
+def bf16r(t):
+    """round-to-nearest-even to bfloat16 and back to fp32: the value a bf16 GEMM / attention operand carries"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class Bf16Points:
+    """Rounding points of the HIP path: WHERE the MI355X kernels round to bf16, applied to this fp32
+    restatement so that the remaining difference to the GPU is accumulation order + fast-math only (the fp32 reference
+    comparison measures operand-rounding noise, this mode separates kernel error from it):
+      * GEMM weights (q/k/v/dense/fc1/fc2/lm_head) are bf16; biases, LayerNorm parameters and the embedding table fp32;
+      * h = bf16(LayerNorm(x)); the residual stream x stays fp32;
+      * q, k: bias + LayerNorm(64) + RoPE on the fp32 accumulators, q scaled by 1/8 (exact), then bf16; v = bf16(acc + bias).
+        `qkv_round=True` (rows < 256: the projection writes a bf16 [T,3H] buffer first) rounds q|k|v once more before that;
+      * softmax: P = bf16(exp(s - rowmax)) multiplies bf16 V with fp32 accumulation, the denominator sums the UNROUNDED exp;
+        o = bf16(acc / l);
+      * ffn = bf16(gelu_new(acc + b1)); x += [o | ffn] [Wd | W2]^T + (bd + b2) in fp32;
+      * hf = bf16(final LayerNorm(x)); logits fp32."""
+
+    def __init__(self, qkv_round=False):
+        self.qkv_round = qkv_round
+        self._w = {}
+
+    def w(self, sd, key):
+        if key not in self._w:
+            self._w[key] = bf16r(sd[key])
+        return self._w[key]
+
+
+def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
     B, L, Hd = h.shape
-    q = h @ sd[p + "q_proj.weight"].T + sd[p + "q_proj.bias"]
-    k = h @ sd[p + "k_proj.weight"].T + sd[p + "k_proj.bias"]
-    v = h @ sd[p + "v_proj.weight"].T + sd[p + "v_proj.bias"]
+    W = (lambda k: pts.w(sd, k)) if pts is not None else (lambda k: sd[k])
+    q = h @ W(p + "q_proj.weight").T + sd[p + "q_proj.bias"]
+    k = h @ W(p + "k_proj.weight").T + sd[p + "k_proj.bias"]
+    v = h @ W(p + "v_proj.weight").T + sd[p + "v_proj.bias"]
+    if pts is not None and pts.qkv_round:
+        q, k, v = bf16r(q), bf16r(k), bf16r(v)
     q = q.view(B, L, d.heads, d.head_dim).transpose(1, 2)
     k = k.view(B, L, d.heads, d.head_dim).transpose(1, 2)
     v = v.view(B, L, d.heads, d.head_dim).transpose(1, 2)
@@ -70,20 +101,28 @@ def phi_attention(sd, p, d, h, mask, cos, sin):
     k = layer_norm(k, sd[p + "k_layernorm.weight"], sd[p + "k_layernorm.bias"], d.ln_eps)
     q = apply_partial_rope(q, cos, sin, d.rotary_dim)
     k = apply_partial_rope(k, cos, sin, d.rotary_dim)
-    s = (q @ k.transpose(2, 3)) / math.sqrt(d.head_dim)
+    if pts is not None:
+        q, k, v = bf16r(q / math.sqrt(d.head_dim)), bf16r(k), bf16r(v)
+        s = q @ k.transpose(2, 3)
+    else:
+        s = (q @ k.transpose(2, 3)) / math.sqrt(d.head_dim)
     if mask is not None:
         s = s + mask
     else:
         # SDPA is_causal path when no mask is given (models/phi.py:713)
         causal = torch.tril(torch.ones(L, L, dtype=torch.bool))
         s = s.masked_fill(~causal, float("-inf"))
+    if pts is not None:
+        e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+        o = bf16r((bf16r(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, L, Hd)
+        return o  # the dense projection joins fc2 in ONE K-concatenated GEMM (phi_hidden)
     a = torch.softmax(s, dim=-1)
     o = (a @ v).transpose(1, 2).reshape(B, L, Hd)
     return o @ sd[p + "dense.weight"].T + sd[p + "dense.bias"]
 
 
-def phi_hidden(sd, d, input_ids=None, inputs_embeds=None, attention_mask=None, collect=None):
-    """Returns final-LayerNorm'ed hidden states [B,L,H]."""
+def phi_hidden(sd, d, input_ids=None, inputs_embeds=None, attention_mask=None, collect=None, pts=None):
+    """Returns final-LayerNorm'ed hidden states [B,L,H].  pts: a Bf16Points object = round where the HIP path rounds."""
     if inputs_embeds is None:
         x = sd["showo.model.embed_tokens.weight"][input_ids]
     else:
@@ -93,18 +132,29 @@ def phi_hidden(sd, d, input_ids=None, inputs_embeds=None, attention_mask=None, c
     for i in range(d.layers):
         p = f"showo.model.layers.{i}."
         h = layer_norm(x, sd[p + "input_layernorm.weight"], sd[p + "input_layernorm.bias"], d.ln_eps)
-        a = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin)
-        m = gelu_new(h @ sd[p + "mlp.fc1.weight"].T + sd[p + "mlp.fc1.bias"])
-        m = m @ sd[p + "mlp.fc2.weight"].T + sd[p + "mlp.fc2.bias"]
-        x = a + m + x  # parallel residual (models/phi.py:790)
+        if pts is not None:
+            h = bf16r(h)
+            o = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin, pts)
+            m = bf16r(gelu_new(h @ pts.w(sd, p + "mlp.fc1.weight").T + sd[p + "mlp.fc1.bias"]))
+            x = x + (o @ pts.w(sd, p + "self_attn.dense.weight").T + m @ pts.w(sd, p + "mlp.fc2.weight").T
+                     + (sd[p + "self_attn.dense.bias"] + sd[p + "mlp.fc2.bias"]))
+        else:
+            a = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin)
+            m = gelu_new(h @ sd[p + "mlp.fc1.weight"].T + sd[p + "mlp.fc1.bias"])
+            m = m @ sd[p + "mlp.fc2.weight"].T + sd[p + "mlp.fc2.bias"]
+            x = a + m + x  # parallel residual (models/phi.py:790)
         if collect is not None:
             collect.append(x)
-    return layer_norm(x, sd["showo.model.final_layernorm.weight"], sd["showo.model.final_layernorm.bias"], d.ln_eps)
+    hid = layer_norm(x, sd["showo.model.final_layernorm.weight"], sd["showo.model.final_layernorm.bias"], d.ln_eps)
+    return bf16r(hid) if pts is not None else hid
 
 
-def showo_logits(sd, d, input_ids=None, input_embeddings=None, attention_mask=None):
-    hid = phi_hidden(sd, d, input_ids, input_embeddings, attention_mask)
-    return (hid @ sd["showo.lm_head.weight"].T + sd["showo.lm_head.bias"]).float()
+def showo_logits(sd, d, input_ids=None, input_embeddings=None, attention_mask=None, pts=None):
+    """pts = Bf16Points(...): the same forward with the HIP path's bf16 rounding points (test_modules_gpu.py gates the GPU logits
+    against it at north_star's 1e-3; the plain fp32 call stays the reference-parity number)"""
+    hid = phi_hidden(sd, d, input_ids, input_embeddings, attention_mask, pts=pts)
+    wlm = pts.w(sd, "showo.lm_head.weight") if pts is not None else sd["showo.lm_head.weight"]
+    return (hid @ wlm.T + sd["showo.lm_head.bias"]).float()
 
 
 def cross_entropy(logits, labels, ignore_index=-100):

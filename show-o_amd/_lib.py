@@ -48,6 +48,8 @@ _PROTOS = {
     "showo_embed_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_adamw": [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_p],
     "showo_scale_f32": [c_p, c_i64, c_f, c_p],
+    "showo_grad_wire_pack": [c_p, c_p, c_i64, c_f, c_p],
+    "showo_grad_wire_unpack": [c_p, c_p, c_i64, c_p],
     "showo_dgelu_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "showo_gelu_bf16": [c_p, c_p, c_i64, c_p],
     "showo_train_create": [c_p, c_i, c_i, c_p],
@@ -79,8 +81,9 @@ _PROTOS = {
     "showo_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_gemm_qkv_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
     "showo_gemm_qkv_fc1_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
-                                c_f, c_i, c_i, c_i, c_p],
-    "showo_gemm_kcat_bf16": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+                                c_f, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_kcat_bf16": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_tile_weight": [c_p, c_i, c_i, c_i, c_p, c_p],
     "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
     "showo_mask_compress": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_attn_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -132,8 +135,9 @@ _PROTOS = {
     "showo_prof_set_stride": [c_i],
     "showo_prof_totals": [c_i, c_p, c_p],
 }
+_I64 = {"showo_gemm_tiled_elems": [c_i, c_i]}
 _VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p], "showo_train_destroy": [c_p], "showo_clip_destroy": [c_p], "showo_projector_destroy": [c_p]}
-EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + ["showo_last_error"])
+EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + list(_I64) + ["showo_last_error"])
 
 EPI_BF16, EPI_GELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3
 
@@ -182,6 +186,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = None
+    for name, args in _I64.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_i64
     lib.showo_last_error.argtypes = []
     lib.showo_last_error.restype = C.c_char_p
     _lib = lib

@@ -157,6 +157,11 @@ class CLIPVisionTower(nn.Module):
         except Exception:
             pass
 
+    def mark_weights_dirty(self):
+        """re-upload every parameter at the next call (needed after updates through `.data`, which do not bump tensor versions)"""
+        if self._clip is not None:
+            self._versions = {}
+
     def engine(self, batch=1):
         _lib.require_gpu()
         lib = _lib.load()

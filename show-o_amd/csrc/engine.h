@@ -15,6 +15,7 @@ struct Layer {
     // (rebuilt lazily after a weight load, see fused_sync in engine.hip)
     bf16_t* wd2 = nullptr;
     float* bd2 = nullptr;
+    bf16_t* wq1t = nullptr;  // tiled copy of [Wqkv ; W1] (showo_gemm_tile_weight), allocated on first use
     float *ln_w = nullptr, *ln_b = nullptr, *qln_w = nullptr, *qln_b = nullptr, *kln_w = nullptr, *kln_b = nullptr;
 };
 }  // namespace showo
@@ -49,7 +50,9 @@ struct showo_engine {
     std::vector<void*> allocs;
     std::set<std::string> loaded;
     int expected = 0;
-    bool fused_valid = false;  // wd2 / bd2 images match wd, w2, bd, b2
+    bool fused_valid = false;  // wd2 / bd2 / wq1t images match the weights
+    bool fused_tiled = false;  // layout of wd2 (and use of wq1t): tiled (default) or row-major (SHOWO_W_TILED=0)
+    bf16_t* wtmp = nullptr;    // staging of one layer's [Wd | W2] rows while its tiled image is built
     // weights
     float* embed = nullptr;
     std::vector<showo::Layer> layers;

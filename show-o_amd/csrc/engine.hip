@@ -123,7 +123,7 @@ extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** 
         if (!rc) { l.w1 = l.wqkv + (int64_t)3 * H * H; l.b1 = l.bqkv + 3 * H; }
         rc |= e->alloc(&l.wd, (int64_t)H * H); rc |= e->alloc(&l.bd, H);
         rc |= e->alloc(&l.w2, (int64_t)H * F); rc |= e->alloc(&l.b2, H);
-        rc |= e->alloc(&l.wd2, (int64_t)H * (H + F)); rc |= e->alloc(&l.bd2, H);
+        rc |= e->alloc(&l.wd2, showo_gemm_tiled_elems(H, H + F)); rc |= e->alloc(&l.bd2, H);
         rc |= e->alloc(&l.ln_w, H); rc |= e->alloc(&l.ln_b, H);
         rc |= e->alloc(&l.qln_w, 64); rc |= e->alloc(&l.qln_b, 64);
         rc |= e->alloc(&l.kln_w, 64); rc |= e->alloc(&l.kln_b, 64);
@@ -221,16 +221,37 @@ __global__ void add2_f32_kernel(const float* __restrict__ a, const float* __rest
 }
 }  // namespace
 
-// K-concatenated images of the residual projections (dense | fc2) for showo_gemm_kcat_bf16; rebuilt after any weight load
+// SHOWO_W_TILED=0 keeps the fused projections on row-major weights (A/B runs)
+static bool w_tiled_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = getenv("SHOWO_W_TILED");
+        v = env ? (atoi(env) != 0) : 1;
+    }
+    return v != 0;
+}
+
+// Weight images of the two fused projections, rebuilt after any weight load:
+//   wd2  = [Wd | W2] ([H, H + F], K-concatenated) for showo_gemm_kcat_bf16, bd2 = bd + b2;
+//   wq1t = tiled copy of [Wqkv ; W1] (showo_gemm_tile_weight) -- with SHOWO_W_TILED (default) wd2 is stored tiled as well
 static int fused_sync(showo_engine* e, hipStream_t s) {
     if (e->fused_valid) return 0;
     const int H = e->H, F = e->F;
+    const bool tiled = w_tiled_enabled();
+    if (tiled && !e->wtmp) TRY(e->alloc(&e->wtmp, (int64_t)H * (H + F)));
     for (auto& l : e->layers) {
-        SHOWO_CHECK_HIP(hipMemcpy2DAsync(l.wd2, (size_t)(H + F) * 2, l.wd, (size_t)H * 2, (size_t)H * 2, H, hipMemcpyDeviceToDevice, s));
-        SHOWO_CHECK_HIP(hipMemcpy2DAsync(l.wd2 + H, (size_t)(H + F) * 2, l.w2, (size_t)F * 2, (size_t)F * 2, H, hipMemcpyDeviceToDevice, s));
+        bf16_t* cat = tiled ? e->wtmp : l.wd2;
+        SHOWO_CHECK_HIP(hipMemcpy2DAsync(cat, (size_t)(H + F) * 2, l.wd, (size_t)H * 2, (size_t)H * 2, H, hipMemcpyDeviceToDevice, s));
+        SHOWO_CHECK_HIP(hipMemcpy2DAsync(cat + H, (size_t)(H + F) * 2, l.w2, (size_t)F * 2, (size_t)F * 2, H, hipMemcpyDeviceToDevice, s));
+        if (tiled) {
+            TRY(showo_gemm_tile_weight(cat, H + F, H, H + F, l.wd2, s));
+            if (!l.wq1t) TRY(e->alloc(&l.wq1t, showo_gemm_tiled_elems(3 * H + F, H)));
+            TRY(showo_gemm_tile_weight(l.wqkv, H, 3 * H + F, H, l.wq1t, s));
+        }
         add2_f32_kernel<<<dim3((H + 255) / 256), dim3(256), 0, s>>>(l.bd, l.b2, l.bd2, H);
     }
     SHOWO_CHECK_HIP(hipGetLastError());
+    e->fused_tiled = tiled;
     e->fused_valid = true;
     return 0;
 }
@@ -308,10 +329,12 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             bf16_t* Kd = kv.k + li * kv.k_lstride;
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
             TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
-            TRY(showo_gemm_qkv_fc1_bf16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
-                                        e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+            TRY(showo_gemm_qkv_fc1_bf16(e->h, H, e->fused_tiled ? l.wq1t : l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT,
+                                        e->sinT, e->Q, Kd, Vd, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp,
+                                        e->fused_tiled ? 1 : 0, s));
             TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
-            TRY(showo_gemm_kcat_bf16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32, s));
+            TRY(showo_gemm_kcat_bf16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32,
+                                     e->fused_tiled ? 1 : 0, s));
         }
         return 0;
     }

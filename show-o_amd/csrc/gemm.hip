@@ -895,7 +895,9 @@ extern "C" int showo_gemm_set_impl(int impl) {
 // dbg = device buffer of 512 uint64 receiving block 0's per-barrier timestamps of k-tiles 8 and 9 (bf16 epilogue only)
 extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
     g_gemm_gn = gn; g_gemm_flags = flags & 0xff; g_gemm_dbg = dbg;
-    g_gemm_bm = (flags >> 8) ? (flags >> 8) : -1;  // impl 5: tile height 256 / 208 / 160 (0 = automatic)
+    g_gemm_bm = (flags >> 8) ? (flags >> 8) : -1;  // impl 5: tile variant code (0 = automatic)
+    if (flags & 2) g_gemm_pf = 1;       // impl 5: L2 prefetch of the weight panel on ...
+    else if (flags & 4) g_gemm_pf = 0;  // ... off; neither bit: unchanged (SHOWO_GEMM_PF, default on)
     return 0;
 }
 
@@ -934,13 +936,45 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     return dispatch(g, ld, epilogue, (hipStream_t)stream);
 }
 
+// ---- tiled weight layout of the production kernel: [ceil(N/256)][K/64][256][64] bf16; inside a 32 KiB block row r holds its
+// eight 16-B chunks at positions p = chunk ^ (r & 7) -- the block IS the LDS image of one k-tile of one weight panel, so the DMA
+// source is lane-linear (1 KiB contiguous per wave-instruction) and a k-loop walks one contiguous stream per panel.
+namespace {
+__global__ __launch_bounds__(256) void tile_weight_kernel(const bf16_t* __restrict__ W, int ldw, int N, int K, bf16_t* __restrict__ out) {
+    const int64_t chunks = (int64_t)((N + 255) / 256) * (K / 64) * 256 * 8;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(c & 7), r = (int)((c >> 3) & 255);
+        const int64_t blk = c >> 11;
+        const int kt = (int)(blk % (K / 64)), np = (int)(blk / (K / 64));
+        const int n = np * 256 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n < N) v = *reinterpret_cast<const uint4*>(W + (int64_t)n * ldw + kt * 64 + ((p ^ (r & 7)) << 3));
+        *reinterpret_cast<uint4*>(out + c * 8) = v;
+    }
+}
+}  // namespace
+
+extern "C" int64_t showo_gemm_tiled_elems(int N, int K) { return (int64_t)((N + 255) / 256) * 256 * K; }
+
+extern "C" int showo_gemm_tile_weight(const uint16_t* W, int ldw, int N, int K, uint16_t* out, void* stream) {
+    if (N <= 0 || K <= 0) return 0;
+    if ((K % 64) || (ldw % 8) || (((uintptr_t)W) & 15) || (((uintptr_t)out) & 15)) return set_error_msg(1, "gemm_tile_weight: K % 64, ldw % 8, 16B alignment required");
+    const int64_t chunks = showo_gemm_tiled_elems(N, K) / 8;
+    int64_t blocks = (chunks + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    tile_weight_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(W, ldw, N, K, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "tile_weight launch", __FILE__, __LINE__);
+    return 0;
+}
+
 // fused QKV projection: Q/K/V^T = relayout(rope(layernorm(A Wqkv^T + b)))  (reference models/phi.py:657-694)
 // With ffn_out != NULL the weight is [Wqkv ; W1] ([3 nH 64 + F, K] rows, bias likewise) and the launch also produces
 // ffn_out[m][0..F) = gelu_new(A W1^T + b1) (models/phi.py:208-212): q/k/v and fc1 read the same LayerNorm output.
 static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias, const float* qln_w,
                          const float* qln_b, const float* kln_w, const float* kln_b, const float* cos_tab, const float* sin_tab,
                          uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
-                         uint16_t* ffn_out, int ldf, int F, void* stream) {
+                         uint16_t* ffn_out, int ldf, int F, int w_tiled, void* stream) {
     const int M = B * L, Nq = 3 * nH * 64, Kd = nH * 64;
     const int N = Nq + (ffn_out ? F : 0);
     if (M <= 0) return 0;
@@ -959,6 +993,7 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
     g.qw = qln_w; g.qb = qln_b; g.kw = kln_w; g.kb = kln_b; g.cosT = cos_tab; g.sinT = sin_tab;
     g.Q = Q; g.Kd = K; g.Vt = Vt; g.L = L; g.nH = nH; g.pos0 = pos0; g.Lcap = Lcap; g.Lp = Lp; g.eps = eps;
     if (ffn_out) { g.Nq = Nq; g.out2 = ffn_out; g.ldo2 = ldf; }
+    g.wtiled = w_tiled ? 1 : 0;
     ProfScope prof(PROF_GEMM, 2.0 * M * N * Kd, (hipStream_t)stream);
     return gemm2p_dispatch(g, EPI_QKV, (hipStream_t)stream);
 }
@@ -968,17 +1003,17 @@ extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* W
                                    const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt, int B,
                                    int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream) {
     return gemm_qkv_impl(A, lda, Wqkv, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps, pos0,
-                         Lcap, Lp, nullptr, 0, 0, stream);
+                         Lcap, Lp, nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
                                        const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
                                        const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                                        uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0,
-                                       int Lcap, int Lp, void* stream) {
+                                       int Lcap, int Lp, int w_tiled, void* stream) {
     if (!ffn_out) return set_error_msg(1, "gemm_qkv_fc1: ffn_out required");
     return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
-                         pos0, Lcap, Lp, ffn_out, ldf, F, stream);
+                         pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream);
 }
 
 // K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias), A0 [M,K0] (lda0), A1 [M,K1] (lda1), weight rows
@@ -986,7 +1021,7 @@ extern "C" int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_
 // (models/phi.py:774-790): x += [attn | ffn] [Wd | W2]^T + (bd + b2) is ONE launch with one residual read-modify-write.
 extern "C" int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W,
                                     int ldw, const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N,
-                                    int epilogue, void* stream) {
+                                    int epilogue, int w_tiled, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K0 <= 0 || K1 <= 0 || (K0 % BK) || (K1 % BK)) return set_error_msg(1, "gemm_kcat: K0, K1 must be positive multiples of 64");
     if (!A0 || !A1 || !W) return set_error_msg(1, "gemm_kcat: null operand");
@@ -1001,6 +1036,8 @@ extern "C" int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const 
     g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.M = M; g.N = N; g.K = K0 + K1;
     g.gn = 1; g.flags = 0; g.dbg = nullptr;
     g.A2 = A1; g.lda2 = lda1; g.Ksplit = K0;
+    g.wtiled = w_tiled ? 1 : 0;
+    if (w_tiled && ldw != K0 + K1) return set_error_msg(1, "gemm_kcat: a tiled weight has ldw == K0 + K1");
     const bool f32 = (epilogue == SHOWO_EPI_F32 || epilogue == SHOWO_EPI_RESID_F32);
     g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & (f32 ? 15 : 7)) == 0);
     if (epilogue == SHOWO_EPI_RESID_F32) g.vec_out = g.vec_out && ((ldr % 4) == 0) && ((((uintptr_t)resid) & 15) == 0);

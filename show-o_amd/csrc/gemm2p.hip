@@ -71,7 +71,11 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     const int coff = ((lane & 7) ^ srow) << 3;
     constexpr bool KC = (EPI == SHOWO_EPI_RESID_F32);  // K-concatenated A operand: only the residual epilogue carries the second offset set
     const int Ks = KC ? g.Ksplit : (1 << 30);
-    const char* wbase = reinterpret_cast<const char*>(g.W);
+    // row-major weights: base + k * 2 + row offset.  Tiled weights ([N/256][K/64][256][64] bf16, showo_gemm_tile_weight): panel base +
+    // (k / 64) * 32 KiB + offset inside the block -- every k-tile of a panel is ONE contiguous 32 KiB read (DRAM-page and TLB friendly;
+    // a wave-instruction reads 1 KiB contiguous instead of 8 lines 2 ldw bytes apart)
+    const int wks = g.wtiled ? 8 : 0;  // tiled: (k * 2) << 8 = (k / 64) * 32768 for k a multiple of 64
+    const char* wbase = reinterpret_cast<const char*>(g.W) + (g.wtiled ? (size_t)tn * (size_t)(g.K / BK) * 32768 : (size_t)0);
     const char* abase0 = reinterpret_cast<const char*>(g.A);
     // segment 1 base is biased by -Ksplit so that base + k * 2 addresses column k - Ksplit
     const char* abase1 = (KC && g.A2) ? reinterpret_cast<const char*>(g.A2) - (int64_t)Ks * 2 : abase0;
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
             wrowl[h][i] = row;
             int n = n0 + row + srow;
             n = n < g.N ? n : g.N - 1;
-            woff[h][i] = (uint32_t)(((int64_t)n * g.ldw + coff) * 2);
+            // tiled weights: the (panel, k-tile) block is the LDS image itself (256 rows x 128 B, chunks pre-swizzled): lane-linear source
+            woff[h][i] = g.wtiled ? (uint32_t)(row * 128 + lane * 16) : (uint32_t)(((int64_t)n * g.ldw + coff) * 2);
         }
 #pragma unroll
     for (int j = 0; j < NAO; ++j) {
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     }
 #define Q2_DMA_W(BUF, H, K0)                                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                              \
-        glds16(reinterpret_cast<const bf16_t*>(wbase + (size_t)(K0) * 2 + (size_t)woff[H][i_]),                   \
+        glds16(reinterpret_cast<const bf16_t*>(wbase + (((size_t)(K0) * 2) << wks) + (size_t)woff[H][i_]),       \
                smem + (BUF) * 256 * 64 + wrowl[H][i_] * 64)
 #define Q2_DMA_A(BUF, J0, J1, K0)                                                                                 \
     do {                                                                                                          \
@@ -119,6 +124,27 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_)                                                    \
             glds16(reinterpret_cast<const bf16_t*>(ab_ + (size_t)(s1_ ? aoff[KC ? 1 : 0][j_] : aoff[0][j_])),     \
                    smem + AOFF + (BUF) * 256 * 64 + arowl[j_] * 64);                                              \
+    } while (0)
+
+    // ---- L2 prefetch of the weight panel (flags bit 1).  In the 24-layer stack every launch streams its weights from HBM for the
+    // first time; all the tiles that share a weight panel run in lockstep, so an HBM miss of the one-phase-ahead DMA stalls every one
+    // of them.  Every second k-tile each thread touches one dword of one 128-B weight line of the k-tiles PFD and PFD + 1 ahead
+    // (256 rows x 2 k-tiles = 512 lines = 512 threads): the DMA issued two k-tiles later then hits L2.  The load is issued LAST in
+    // its phase, so that the counted vmcnt waits that follow leave it in flight for one whole k-tile (VMEM returns in order).
+    constexpr int PFD = 3;
+    const bool pf_on = (g.flags & 2) != 0 && nk > PFD && !g.wtiled;
+    const char* pfptr;
+    {
+        int n = n0 + (tid & 255);
+        n = n < g.N ? n : g.N - 1;
+        pfptr = wbase + (size_t)n * g.ldw * 2 + (size_t)(tid >> 8) * (BK * 2);
+    }
+    uint32_t pfreg = 0;
+#define Q2_PF(T)                                                                                                  \
+    do {                                                                                                          \
+        int kt_ = (T) + PFD;                                                                                      \
+        kt_ = kt_ + 1 < nk ? kt_ : nk - 2; /* the pair (kt_, kt_ + 1) stays inside the row */                     \
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pfreg) : "v"(pfptr + (size_t)kt_ * (BK * 2)) : "memory"); \
     } while (0)
 
     // ---- fragment read addresses (elements).  row & 7 == fr & 7 for every fragment row of this lane.
@@ -169,7 +195,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
             Q2_DMA_W((BUF) ^ 1, 0, kN);                                                                           \
             Q2_DMA_W((BUF) ^ 1, 1, kN);                                                                           \
             Q2_DMA_A((BUF) ^ 1, 0, 2, kN);                                                                        \
-            Q2_WAIT(6); /* retires the hi pieces of this tile */                                                  \
+            /* retires the hi pieces of this tile; an odd tile leaves the prefetch of the previous tile in flight */ \
+            if ((BUF) == 1 && pf_on && (T) - 1 + PFD < nk) Q2_WAIT(7); else Q2_WAIT(6);                            \
         } else {                                                                                                  \
             Q2_WAIT(0);                                                                                           \
         }                                                                                                         \
@@ -180,7 +207,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         Q2_READ_A(BUF, 4, (MFG) - 4)                                                                              \
         if (has1) {                                                                                               \
             Q2_DMA_A((BUF) ^ 1, 2, 4, kN);                                                                        \
-            Q2_WAIT(2); /* retires W + A-lo of tile T+1 */                                                        \
+            /* retires W + A-lo of tile T+1 (and, in an odd tile, the prefetch issued one k-tile ago) */          \
+            if ((BUF) == 0 && pf_on && (T) + PFD < nk) { Q2_PF(T); Q2_WAIT(3); } else Q2_WAIT(2);                  \
         } else {                                                                                                  \
             Q2_WAIT(0);                                                                                           \
         }                                                                                                         \
@@ -199,7 +227,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         if (has1) {                                                                                               \
             Q2_DMA_W((BUF) ^ 1, 0, kN);                                                                           \
             Q2_DMA_A((BUF) ^ 1, 0, NPW, kN);                                                                      \
-            Q2_WAIT(2 + NPW); /* retires the W rows of fragments 2,3 of this tile */                              \
+            /* retires the W rows of fragments 2,3 of this tile */                                                \
+            if ((BUF) == 1 && pf_on && (T) - 1 + PFD < nk) Q2_WAIT(3 + NPW); else Q2_WAIT(2 + NPW);                \
         } else {                                                                                                  \
             Q2_WAIT(0);                                                                                           \
         }                                                                                                         \
@@ -210,7 +239,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         Q2_READ_W(BUF, 2, 4)                                                                                      \
         if (has1) {                                                                                               \
             Q2_DMA_W((BUF) ^ 1, 1, kN);                                                                           \
-            Q2_WAIT(2); /* retires W 0,1 + A of tile T+1 */                                                       \
+            /* retires W 0,1 + A of tile T+1 */                                                                   \
+            if ((BUF) == 0 && pf_on && (T) + PFD < nk) { Q2_PF(T); Q2_WAIT(3); } else Q2_WAIT(2);                  \
         } else {                                                                                                  \
             Q2_WAIT(0);                                                                                           \
         }                                                                                                         \
@@ -254,6 +284,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg);
     }
 #undef Q2_RUN
+    asm volatile("" ::"v"(pfreg));  // keeps the prefetch destination register reserved for the whole loop
 #undef N2_TILE
 #undef Q2_TILE
 #undef Q2_WAIT
@@ -261,6 +292,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
 #undef Q2_READ_A
 #undef Q2_READ_W
 #undef Q2_DMA_A
+#undef Q2_PF
 #undef Q2_DMA_W
 }
 
@@ -314,6 +346,7 @@ int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
 
 int g_gemm_gn = 4;  // n-panels per XCD tile group (same-process sweep on the bench workload: 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s)
 int g_gemm_bm = 0;  // 0 = read SHOWO_GEMM_BM once; -1 = choose per shape; a variant code = force it
+int g_gemm_pf = -1; // L2 prefetch of the weight panel: -1 = read SHOWO_GEMM_PF once (default on), 0 / 1 = forced (showo_gemm_tune)
 
 namespace {
 
@@ -428,7 +461,8 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
 
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
     g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
-    g.flags = 0;
+    if (g_gemm_pf < 0) { const char* e = getenv("SHOWO_GEMM_PF"); g_gemm_pf = e ? (atoi(e) != 0) : 1; }
+    g.flags = g_gemm_pf ? 2 : 0;
     g.dbg = nullptr;
     switch (epilogue) {
         case SHOWO_EPI_BF16: return launch2p_bm<SHOWO_EPI_BF16>(g, s);

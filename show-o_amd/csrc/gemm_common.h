@@ -29,6 +29,8 @@ struct GemmArgs {
     // EPI_QKV only: output columns n >= Nq are the fc1 rows of the [Wqkv ; W1] weight: bias + gelu_new -> out2[m][n - Nq] (bf16).
     // q/k/v and fc1 read the same LayerNorm output (models/phi.py:776-790).
     int Nq = 1 << 30; bf16_t* out2 = nullptr; int ldo2 = 0;
+    // gemm2p only: W is in the tiled layout of showo_gemm_tile_weight ([ceil(N/256)][K/64][256][64] bf16, 16-B chunks pre-swizzled)
+    int wtiled = 0;
 };
 
 constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
@@ -219,6 +221,6 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 
 // production kernel (gemm2p.hip)
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
-extern int g_gemm_gn, g_gemm_bm;
+extern int g_gemm_gn, g_gemm_bm, g_gemm_pf;
 
 }  // namespace showo

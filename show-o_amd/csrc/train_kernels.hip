@@ -322,8 +322,13 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     const float tot = sbc;
     const float lse = mx + logf(tot);
     if (tid == 0) {
-        rowloss[2 * r] = (cr.bits & 1) ? lse - z[cr.labA] : 0.f;
-        rowloss[2 * r + 1] = (cr.bits & 6) ? lse - z[cr.labB] : 0.f;
+        // a label outside [0, V) (other than the ignore index, which never sets a bit) is a caller bug -- e.g. image tokens that were
+        // not offset by len(tokenizer); F.cross_entropy raises a device assert in the reference.  Never read out of bounds: the
+        // row's loss becomes NaN, which poisons the mean of its group.
+        const bool okA = !(cr.bits & 1) || (cr.labA >= 0 && cr.labA < V);
+        const bool okB = !(cr.bits & 6) || (cr.labB >= 0 && cr.labB < V);
+        rowloss[2 * r] = (cr.bits & 1) ? (okA ? lse - z[cr.labA] : __builtin_nanf("")) : 0.f;
+        rowloss[2 * r + 1] = (cr.bits & 6) ? (okB ? lse - z[cr.labB] : __builtin_nanf("")) : 0.f;
     }
     if (dz) {
         const float w = wa + wb, inv = 1.0f / tot;
@@ -565,6 +570,58 @@ extern "C" int showo_scale_f32(float* x, int64_t n, float s, void* stream) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 65536) blocks = 65536;
     scale_f32_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(x, n, s);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- bf16 gradient wire (data-parallel exchange, SURVEY §8e: 2.90 GB per rank per step instead of 5.79 GB fp32).
+// pack: wire[i] = bf16(grad[i] * scale) (scale = 1 / world, applied BEFORE rounding so the summed wire is the mean);
+// unpack: grad[i] = float(wire[i]).  4 elements per thread, 16-B loads / 8-B stores (and the converse).
+namespace {
+__global__ __launch_bounds__(256) void wire_pack_kernel(const float* __restrict__ g, bf16_t* __restrict__ w, int64_t n, float scale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            uint2 o;
+            o.x = pack_bf2(v.x * scale, v.y * scale);
+            o.y = pack_bf2(v.z * scale, v.w * scale);
+            *reinterpret_cast<uint2*>(w + i) = o;
+        } else {
+            for (int64_t j = i; j < n; ++j) w[j] = f2bf(g[j] * scale);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void wire_unpack_kernel(const bf16_t* __restrict__ w, float* __restrict__ g, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const uint2 v = *reinterpret_cast<const uint2*>(w + i);
+            *reinterpret_cast<float4*>(g + i) = make_float4(bf2f((bf16_t)(v.x & 0xffff)), bf2f((bf16_t)(v.x >> 16)),
+                                                            bf2f((bf16_t)(v.y & 0xffff)), bf2f((bf16_t)(v.y >> 16)));
+        } else {
+            for (int64_t j = i; j < n; ++j) g[j] = bf2f(w[j]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int showo_grad_wire_pack(const float* grad, uint16_t* wire, int64_t n, float scale, void* stream) {
+    if (n <= 0) return 0;
+    if ((((uintptr_t)grad) & 15) || (((uintptr_t)wire) & 7)) return set_error_msg(1, "grad_wire_pack: grad must be 16B and wire 8B aligned");
+    int64_t blocks = (n / 4 + 255) / 256 + 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    wire_pack_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(grad, wire, n, scale);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int showo_grad_wire_unpack(const uint16_t* wire, float* grad, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if ((((uintptr_t)grad) & 15) || (((uintptr_t)wire) & 7)) return set_error_msg(1, "grad_wire_unpack: grad must be 16B and wire 8B aligned");
+    int64_t blocks = (n / 4 + 255) / 256 + 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    wire_unpack_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(wire, grad, n);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -173,6 +173,11 @@ class MAGVITv2(PretrainedMixin, nn.Module):
         except Exception:
             pass
 
+    def mark_weights_dirty(self):
+        """re-upload every parameter at the next call (needed after updates through `.data`, which do not bump tensor versions)"""
+        if self._vq is not None:
+            self._versions = {}
+
     def engine(self):
         _lib.require_gpu()
         lib = _lib.load()

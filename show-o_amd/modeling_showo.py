@@ -202,6 +202,11 @@ class _MMProjector(nn.Sequential):
         self._dims = (din, dout)
         self._proj, self._rows, self._versions = None, 0, None
 
+    def mark_weights_dirty(self):
+        """re-upload the projector's parameters at the next call (updates through `.data` do not bump tensor versions)"""
+        if getattr(self, "_proj", None) is not None:
+            self._versions = {}
+
     def _drop(self):
         if getattr(self, "_proj", None) is not None:
             _lib.load().showo_projector_destroy(self._proj)
@@ -268,6 +273,10 @@ class Showo(PretrainedMixin, nn.Module):
         # end state (embed + untied lm_head of `vocab_size` rows) is what we allocate directly.
         self.showo = _PhiForCausalLMParams(vocab_size, hidden, arch["intermediate_size"], arch["num_hidden_layers"],
                                            64, arch["layer_norm_eps"])
+        if not load_from_showo:
+            # reference models/modeling_showo.py:45-46: PhiForCausalLM.from_pretrained(llm_model_path) then
+            # resize_token_embeddings(vocab_size) -- stage-1 training starts from the HF Phi-1.5 weights (training/train.py:203)
+            self._init_from_phi_checkpoint(llm_model_path)
         self.output_size = self.vocab_size
         if w_clip_vit:
             self.mm_projector = _MMProjector(1024, hidden)  # reference: nn.Sequential(Linear(1024, 2048), GELU(), Linear(2048, 2048))
@@ -278,6 +287,85 @@ class Showo(PretrainedMixin, nn.Module):
         self._weights_changed = True
         self.max_batch = int(kwargs.get("max_batch", 32))
         self.max_seq = int(kwargs.get("max_seq", 1280))
+
+    def _init_from_phi_checkpoint(self, llm_model_path):
+        """`load_from_showo=False`: start from a Hugging Face Phi checkpoint in the local directory `llm_model_path`
+        (config.json + model.safetensors | pytorch_model.bin | a sharded index; keys `model.*`, `lm_head.*`).  What the reference does
+        (models/modeling_showo.py:45-46; transformers `from_pretrained` + `resize_token_embeddings`):
+          * every checkpoint tensor is loaded under the `showo.` prefix; tensors the checkpoint lacks keep their fresh
+            initialisation -- for microsoft/phi-1_5 those are the q/k LayerNorms that PhiForCausalLM forces on (models/phi.py:1088):
+            weight 1, bias 0;
+          * the embedding and the untied, biased lm_head grow from the checkpoint's vocabulary to `vocab_size`: the first
+            min(old, new) rows (and bias entries) are the checkpoint's, the new rows are N(0, 0.02) / zero bias (`_init_weights`).
+        There is no hub access here: anything but a local directory raises."""
+        import json
+        import os
+        from .persistence import _load_file
+        if self.showo.lm_head.weight.is_meta:
+            return  # from_pretrained() builds on the meta device and overwrites every tensor from the Show-o checkpoint itself
+        d = llm_model_path
+        if not d or not os.path.isdir(d):
+            raise EnvironmentError(f"load_from_showo=False needs a local Hugging Face Phi checkpoint directory as llm_model_path "
+                                   f"(got {llm_model_path!r}); hub downloads are not supported")
+        cfg_path = os.path.join(d, "config.json")
+        if os.path.isfile(cfg_path):
+            with open(cfg_path, encoding="utf-8") as f:
+                hf = json.load(f)
+            for k in ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads"):
+                if k in hf and hf[k] != self.arch[k]:
+                    raise ValueError(f"{cfg_path}: {k} = {hf[k]} but the model was built with {self.arch[k]} "
+                                     f"(pass {k}=... to Showo for a non-Phi-1.5 geometry)")
+        files = None
+        for name in ("model.safetensors", "pytorch_model.safetensors", "pytorch_model.bin"):
+            if os.path.isfile(os.path.join(d, name)):
+                files = [os.path.join(d, name)]
+                break
+            idx = os.path.join(d, name + ".index.json")
+            if os.path.isfile(idx):
+                with open(idx, encoding="utf-8") as f:
+                    files = [os.path.join(d, fn) for fn in sorted(set(json.load(f)["weight_map"].values()))]
+                break
+        if files is None:
+            raise EnvironmentError(f"no model.safetensors / pytorch_model.bin (or sharded index) in {d}")
+        want = self.showo.state_dict()
+        for k, v in want.items():  # fresh initialisation of what a Phi-1.5 checkpoint does not hold
+            if k.endswith("_layernorm.weight") and ("q_layernorm" in k or "k_layernorm" in k):
+                v.data.fill_(1.0)
+            elif k.endswith("_layernorm.bias") and ("q_layernorm" in k or "k_layernorm" in k):
+                v.data.zero_()
+        seen = set()
+        resized = ("model.embed_tokens.weight", "lm_head.weight", "lm_head.bias")
+        with torch.no_grad():
+            for path in files:
+                part = _load_file(path, "cpu")
+                for k, v in part.items():
+                    if k not in want:
+                        continue
+                    dst = want[k]
+                    if k in resized:
+                        n = min(v.shape[0], dst.shape[0])
+                        if tuple(v.shape[1:]) != tuple(dst.shape[1:]):
+                            raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} does not match {tuple(dst.shape)} beyond the vocabulary")
+                        dst[:n].copy_(v[:n])
+                    else:
+                        if tuple(v.shape) != tuple(dst.shape):
+                            raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} != model shape {tuple(dst.shape)}")
+                        dst.copy_(v)
+                    seen.add(k)
+                del part
+        allowed_missing = [k for k in want if "q_layernorm" in k or "k_layernorm" in k]
+        missing = [k for k in want if k not in seen and k not in allowed_missing]
+        if missing:
+            raise KeyError(f"Phi checkpoint {d} lacks {len(missing)} tensors, e.g. {missing[:5]}")
+
+    def mark_weights_dirty(self):
+        """Re-upload every parameter to the HIP engine at the next call.  The engine notices parameter changes by
+        (data_ptr, tensor._version); updates made through `.data` (p.data.copy_(), DeepSpeed ZeRO flat-buffer updates, EMA swaps)
+        do not bump the version counter, so an optimizer of that kind must call this after `optimizer.step()`."""
+        self._engine_versions = {} if self._engine is not None else None
+        self._weights_changed = True
+        if getattr(self, "mm_projector", None) is not None:
+            self.mm_projector.mark_weights_dirty()
 
     # ---- reference attribute passthrough (`model.mask_token_id`, reference models/modeling_utils.py:139-155)
     def __getattr__(self, name):

@@ -27,19 +27,62 @@ def device_view(ptr, n, device):
     return torch.as_tensor(_DevView(ptr, n), device=device)
 
 
-def average_buckets(buckets, group=None, async_op=True):
-    """average every tensor of `buckets` over the process group (SUM then 1/world: AVG is not available on gloo)"""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    works = []
-    for b in buckets:
-        w = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        works.append((w, b))
-    for w, b in works:
-        if w is not None:
-            w.wait()
-        b.mul_(1.0 / world)
-    return buckets
+class HipWireOps:
+    """staging of the gradient wire on the device: HIP kernels on the current stream (include/showo_hip.h)"""
+
+    @staticmethod
+    def pack(grad, wire, scale):
+        _lib.call("showo_grad_wire_pack", grad.data_ptr(), wire.data_ptr(), grad.numel(), float(scale), _lib.stream())
+
+    @staticmethod
+    def unpack(wire, grad):
+        _lib.call("showo_grad_wire_unpack", wire.data_ptr(), grad.data_ptr(), grad.numel(), _lib.stream())
+
+    @staticmethod
+    def scale(grad, s):
+        _lib.call("showo_scale_f32", grad.data_ptr(), grad.numel(), float(s), _lib.stream())
+
+
+class GradientExchange:
+    """The ONE exchange step of a data-parallel iteration (reference: accelerate / DeepSpeed around
+    `accelerator.backward`, training/train.py:449,612): every gradient bucket is averaged over the process group with one
+    all-reduce, launched as soon as the bucket's backward kernels are queued (`launch(b)`), and all of them are completed before the
+    optimizer runs (`finish()`).
+
+    wire = "bf16" (default, the reference's `mixed_precision: bf16` wire, 2 bytes per gradient): the bucket is scaled by 1/world
+    and rounded to a bf16 staging buffer, the staging buffer is summed by the collective and widened back into the fp32 bucket.
+    wire = "fp32": the fp32 bucket itself is summed and then scaled (twice the volume, no rounding).
+    `ops` supplies pack / unpack / scale for the device the buckets live on (HipWireOps for the GPU path)."""
+
+    def __init__(self, buckets, dist, group=None, wire="bf16", ops=HipWireOps):
+        if wire not in ("bf16", "fp32"):
+            raise ValueError("wire must be 'bf16' or 'fp32'")
+        self.buckets, self.dist, self.group, self.wire, self.ops = buckets, dist, group, wire, ops
+        self.world = dist.get_world_size(group)
+        self.stage = [torch.empty(b.numel(), dtype=torch.bfloat16, device=b.device) for b in buckets] if wire == "bf16" else None
+        self.works = []
+
+    def wire_bytes(self):
+        """bytes every rank hands to the collective per step"""
+        return sum(b.numel() for b in self.buckets) * (2 if self.wire == "bf16" else 4)
+
+    def launch(self, b):
+        if self.wire == "bf16":
+            self.ops.pack(self.buckets[b], self.stage[b], 1.0 / self.world)
+            t = self.stage[b]
+        else:
+            t = self.buckets[b]
+        self.works.append((self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), b))
+
+    def finish(self):
+        for w, b in self.works:
+            if w is not None:
+                w.wait()
+            if self.wire == "bf16":
+                self.ops.unpack(self.stage[b], self.buckets[b])
+            else:
+                self.ops.scale(self.buckets[b], 1.0 / self.world)
+        self.works = []
 
 
 def train_mask(tr, attention_mask):
@@ -56,8 +99,13 @@ def train_mask(tr, attention_mask):
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0), group=None):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0), group=None,
+                 wire="bf16", max_grad_norm=None, force_exchange=False):
+        """wire: "bf16" | "fp32" gradient wire of the exchange (GradientExchange).  max_grad_norm: global-norm clipping before the
+        optimizer (training/train.py:614-615; null in the shipped stage-1 YAMLs).  force_exchange: run the exchange even in a
+        process group of one rank (tests: drives the RCCL path on a single GPU)."""
         self.model, self.lr, self.betas, self.eps, self.wd, self.coeffs, self.group = model, lr, betas, eps, weight_decay, coeffs, group
+        self.max_grad_norm = max_grad_norm
         self.step_count = 0
         self.params = [("showo." + n, p) for n, p in model.showo.named_parameters()]
         dev = self.params[0][1].device
@@ -73,7 +121,8 @@ class Trainer:
         for n, p in self.params:  # master weights + moments are registered once; the step is one C call
             _lib.call("showo_train_bind_param", self.tr, n.encode(), p.data_ptr(), self.m[n].data_ptr(), self.v[n].data_ptr(), p.numel())
         import torch.distributed as dist
-        self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) else None
+        active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
+        self.exchange = GradientExchange(self.buckets, dist, group, wire=wire) if active else None
 
     # ---- checkpoint / resume of the optimizer (reference: accelerator.save_state / load_state, training/train.py:851-889, 429-443)
     def state_dict(self):
@@ -114,13 +163,11 @@ class Trainer:
         """learning-rate schedulers (training/train.py:303-310 `get_scheduler`) call this between steps"""
         self.lr = float(lr)
 
-    def _exchange(self, bucket, works):
-        if self.dist is None:
-            return
-        works.append((self.dist.all_reduce(self.buckets[bucket], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), bucket))
-
     def step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
         """one optimisation step; returns the three losses (fp32 device tensor [3])"""
+        # model.trainer() re-uploads parameters whose (data_ptr, version) changed since the last call (load_state_dict, resume,
+        # manual edits); the native AdamW below updates them through raw pointers and refreshes the engine images itself
+        self.tr = self.model.trainer()
         m, tr, s = self.model, self.tr, _lib.stream
         B, L = input_ids.shape
         ids = input_ids.to(torch.int64).contiguous()
@@ -132,21 +179,35 @@ class Trainer:
                       batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
         finally:
             _lib.call("showo_trainer_use_intervals", tr, None, None)
-        works = []
+        ex = self.exchange
         nL = m.arch["num_hidden_layers"]
         _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,
                   self.coeffs[0], self.coeffs[1], self.coeffs[2], s())
-        self._exchange(nL + 1, works)
+        if ex is not None:
+            ex.launch(nL + 1)
         for i in range(nL - 1, -1, -1):
             _lib.call("showo_train_backward_layer", tr, i, s())
-            self._exchange(i + 1, works)
+            if ex is not None:
+                ex.launch(i + 1)  # the collective of block i overlaps the backward of block i - 1
         _lib.call("showo_train_backward_embed", tr, s())
-        self._exchange(0, works)
-        if self.dist is not None:
-            inv = 1.0 / self.dist.get_world_size(self.group)
-            for w, b in works:
-                w.wait()
-                _lib.call("showo_scale_f32", self.buckets[b].data_ptr(), self.buckets[b].numel(), inv, s())
+        if ex is not None:
+            ex.launch(0)
+            ex.finish()
+        if self.max_grad_norm is not None:
+            self.clip_grad_norm_(self.max_grad_norm)
         self.step_count += 1
         _lib.call("showo_train_adamw_step", tr, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, s())
         return losses
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ over the flat gradient buffer (reference training/train.py:614-615
+        `accelerator.clip_grad_norm_(model.parameters(), max_grad_norm)`): g *= max_norm / (||g||_2 + 1e-6) when that is < 1.
+        Returns the total norm (device scalar); the clip coefficient never visits the host."""
+        sq = torch.zeros((), dtype=torch.float32, device=self.buckets[0].device)
+        for b in self.buckets:
+            sq = sq + torch.linalg.vector_norm(b, 2.0, dtype=torch.float32) ** 2
+        total = sq.sqrt()
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for b in self.buckets:
+            b.mul_(coef)
+        return total

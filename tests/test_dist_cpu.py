@@ -1,5 +1,7 @@
 """world_size-2 tests of the multi-process paths on CPU (gloo, 127.0.0.1): the replica aggregation of bench.py and the
-gradient-bucket averaging of the data-parallel Trainer.  The GPU job runs the same code over RCCL."""
+gradient exchange of the data-parallel Trainer -- the SAME `GradientExchange` object `Trainer.step` drives (launch per bucket
+in backward order, finish before the optimizer), with the wire staging done by torch ops instead of the HIP kernels because the
+buckets live on the CPU here.  The GPU job runs the same code over RCCL (tests/test_train_gpu.py covers the HIP staging)."""
 import os
 import socket
 import sys
@@ -18,6 +20,22 @@ def _free_port():
     return p
 
 
+class TorchWireOps:
+    """CPU stand-in of show-o_amd.training.HipWireOps (same three operations, same arithmetic)"""
+
+    @staticmethod
+    def pack(grad, wire, scale):
+        wire.copy_((grad * scale).to(torch.bfloat16))
+
+    @staticmethod
+    def unpack(wire, grad):
+        grad.copy_(wire.float())
+
+    @staticmethod
+    def scale(grad, s):
+        grad.mul_(s)
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -27,18 +45,35 @@ def _worker(rank, world, port, out):
     import showo_amd
     # replica aggregation: slowest rank defines the time, units add up
     dt, units = bench.aggregate(1.0 + rank, 24, dist, "cpu")
-    # gradient buckets: every rank holds different gradients, all end with the mean (fixed bucket order)
-    buckets = [torch.full((5,), float(rank + 1)), torch.arange(7, dtype=torch.float32) * (rank + 1)]
-    showo_amd.training.average_buckets(buckets, async_op=True)
     ok = dt == float(world) and units == 24 * world
-    ok = ok and torch.allclose(buckets[0], torch.full((5,), (1 + world) / 2.0))
-    ok = ok and torch.allclose(buckets[1], torch.arange(7, dtype=torch.float32) * (1 + world) / 2.0)
+    # gradient exchange: every rank holds different gradients, all end with the mean; buckets are launched in the order
+    # Trainer.step uses (head first, embedding last) and completed by finish()
+    g = torch.Generator().manual_seed(7)
+    base = [torch.randn(n, generator=g) for n in (5, 4099, 64)]
+    # bf16 wire (unit roundoff 2^-8): each rank's x_r / world is rounded once and the sum once more: |err| <= 2^-7 * mean_r |x_r|
+    for wire, tol in (("fp32", 1e-6), ("bf16", 2.0 ** -7)):
+        buckets = [b * (rank + 1) + rank for b in base]
+        ex = showo_amd.training.GradientExchange(buckets, dist, None, wire=wire, ops=TorchWireOps)
+        for b in (2, 1, 0):
+            ex.launch(b)
+        ex.finish()
+        assert ex.works == []
+        for got, b in zip(buckets, base):
+            want = sum(b * (r + 1) + r for r in range(world)) / world
+            mag = sum((b * (r + 1) + r).abs() for r in range(world)) / world
+            ok = ok and bool(((got - want).abs() <= tol * mag + 1e-7).all())
+        ok = ok and ex.wire_bytes() == sum(b.numel() for b in base) * (4 if wire == "fp32" else 2)
+        # every rank ends with bit-identical buckets (the replicas must not drift apart)
+        mine = torch.cat(buckets)
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        ok = ok and all(torch.equal(both[0], t) for t in both)
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo_aggregate_and_bucket_average():
+def test_world_size_2_gloo_aggregate_and_gradient_exchange():
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()

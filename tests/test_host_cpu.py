@@ -386,3 +386,74 @@ def test_alias_package_shares_module_objects():
             "print('ok')\n") % util.ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout, out.stderr[-2000:])
+
+
+def test_load_from_showo_false_initialises_from_a_local_phi_checkpoint(tmp_path):
+    """reference models/modeling_showo.py:45-46: PhiForCausalLM.from_pretrained(llm_model_path) + resize_token_embeddings.
+    A tiny synthetic HF-layout Phi checkpoint (keys model.* / lm_head.*, vocabulary 96, no q/k LayerNorms like phi-1_5):
+    every tensor arrives under the showo. prefix, the first 96 embedding / lm_head rows are the checkpoint's, the q/k
+    LayerNorms are freshly initialised (1, 0), and a missing directory raises instead of training from noise."""
+    import json
+    import showo_amd
+    from safetensors.torch import save_file
+    H, F, nL, V0, V1 = 128, 256, 2, 96, 140
+    g = torch.Generator().manual_seed(3)
+    sd = {"model.embed_tokens.weight": torch.randn(V0, H, generator=g), "lm_head.weight": torch.randn(V0, H, generator=g),
+          "lm_head.bias": torch.randn(V0, generator=g), "model.final_layernorm.weight": torch.randn(H, generator=g),
+          "model.final_layernorm.bias": torch.randn(H, generator=g)}
+    for i in range(nL):
+        p = f"model.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "dense"):
+            sd[p + f"self_attn.{n}.weight"] = torch.randn(H, H, generator=g)
+            sd[p + f"self_attn.{n}.bias"] = torch.randn(H, generator=g)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = torch.randn(F, H, generator=g), torch.randn(F, generator=g)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = torch.randn(H, F, generator=g), torch.randn(H, generator=g)
+        sd[p + "input_layernorm.weight"], sd[p + "input_layernorm.bias"] = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    d = tmp_path / "phi-tiny"
+    d.mkdir()
+    save_file(sd, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"model_type": "phi", "hidden_size": H, "intermediate_size": F, "num_hidden_layers": nL,
+                                               "num_attention_heads": 2, "vocab_size": V0}))
+    kw = dict(hidden_size=H, intermediate_size=F, num_hidden_layers=nL, num_attention_heads=2)
+    m = showo_amd.Showo(False, V1, V0, llm_model_path=str(d), load_from_showo=False, **kw)
+    got = m.state_dict()
+    for k, v in sd.items():
+        if k in ("model.embed_tokens.weight", "lm_head.weight", "lm_head.bias"):
+            assert torch.equal(got["showo." + k][:V0], v) and got["showo." + k].shape[0] == V1
+        else:
+            assert torch.equal(got["showo." + k], v), k
+    assert float(got["showo.lm_head.bias"][V0:].abs().max()) == 0.0          # new bias entries: zero
+    assert 0.005 < float(got["showo.model.embed_tokens.weight"][V0:].std()) < 0.05  # new rows: N(0, 0.02)
+    for i in range(nL):
+        for n in ("q_layernorm", "k_layernorm"):
+            assert bool((got[f"showo.model.layers.{i}.self_attn.{n}.weight"] == 1).all())
+            assert bool((got[f"showo.model.layers.{i}.self_attn.{n}.bias"] == 0).all())
+    with pytest.raises(EnvironmentError):
+        showo_amd.Showo(False, V1, V0, llm_model_path="microsoft/phi-1_5", load_from_showo=False, **kw)
+    with pytest.raises(ValueError):  # geometry mismatch between config.json and the constructor
+        showo_amd.Showo(False, V1, V0, llm_model_path=str(d), load_from_showo=False, hidden_size=H, intermediate_size=F,
+                        num_hidden_layers=nL + 1, num_attention_heads=2)
+    # a Show-o checkpoint saved with load_from_showo=False in its config.json reloads without the Phi directory
+    out = tmp_path / "showo-ckpt"
+    m.save_pretrained(str(out))
+    (d / "model.safetensors").unlink()
+    m2 = showo_amd.Showo.from_pretrained(str(out), device="cpu")
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
+    """`python bench.py --gpus N` self-launches N ranks; with fewer visible GPUs it must refuse instead of running one replica
+    and reporting n_gpus = 1 (reference launch: accelerate, one process per GPU, training/train.py:91-110)."""
+    import subprocess
+    import sys
+    ROOT = util.ROOT
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    for script in ("bench.py", "bench_train.py"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "--gpus 64 requested" in (r.stderr + r.stdout), (script, r.stderr[-500:])
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -559,9 +559,33 @@ def test_gemm_both_tile_kernels(impl):
         L().call("showo_gemm_tune", 8, 0, None)
 
 
+def _tiled(W):
+    """device copy of a bf16 weight [N, K] in the tiled layout of showo_gemm_tile_weight"""
+    N, K = W.shape
+    n = L().load().showo_gemm_tiled_elems(N, K)
+    out = torch.full((n,), -1, dtype=torch.int16, device="cuda")
+    L().call("showo_gemm_tile_weight", L().ptr(W), K, N, K, L().ptr(out), S())
+    return out
+
+
+def test_tile_weight_layout():
+    """[ceil(N/256)][K/64][256][64] blocks, chunk p of row r holds logical chunk p ^ (r & 7), rows beyond N are zero"""
+    N, K = 300, 192
+    W = torch.arange(N * K, dtype=torch.int32).remainder(30011).to(torch.int16).view(N, K)
+    got = _tiled(dev(W)).cpu().view(2, K // 64, 256, 8, 8)
+    want = torch.zeros(2, K // 64, 256, 8, 8, dtype=torch.int16)
+    Wp = torch.zeros(512, K, dtype=torch.int16)
+    Wp[:N] = W
+    for r in range(256):
+        for p in range(8):
+            want[:, :, r, p] = Wp.view(2, 256, K // 64, 8, 8)[:, r, :, p ^ (r & 7)]
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("variant", [0, 256, 208, 1176, 1144])
 @pytest.mark.parametrize("M,K0,K1,N", [(700, 128, 512, 384), (1548, 256, 1024, 2048), (300, 64, 64, 256)])
-def test_gemm_kcat_residual(variant, M, K0, K1, N):
+def test_gemm_kcat_residual(variant, M, K0, K1, N, tiled):
     """showo_gemm_kcat_bf16: x += [A0 | A1] [W0 | W1]^T + bias in one launch (Phi's dense + fc2 into the same residual row,
     models/phi.py:774-790), operands with DIFFERENT leading dimensions; fp64 reference on the same bf16-rounded operands."""
     torch.manual_seed(M + variant)
@@ -570,17 +594,20 @@ def test_gemm_kcat_residual(variant, M, K0, K1, N):
     bias, x = torch.randn(N), torch.randn(M, N)
     ref = bf16_round(torch.cat([A0, A1], 1)).double() @ bf16_round(W).double().T + bias.double() + x.double()
     xd = dev(x.clone())
+    Wd = dev(to_bf16_bits(W))
+    if tiled:
+        Wd = _tiled(Wd)
     L().call("showo_gemm_tune", 8, variant << 8, None)
     try:
         L().call("showo_gemm_kcat_bf16", L().ptr(dev(to_bf16_bits(A0))), K0, K0, L().ptr(dev(to_bf16_bits(A1))), K1, K1,
-                 L().ptr(dev(to_bf16_bits(W))), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, L().ptr(xd), N, M, N, 3, S())
+                 L().ptr(Wd), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, L().ptr(xd), N, M, N, 3, tiled, S())
         sync()
     finally:
         L().call("showo_gemm_tune", 8, 0, None)
     assert (xd.cpu().double() - ref).abs().max() < 1e-3 * float(ref.abs().max())
     with pytest.raises(RuntimeError):  # only the residual epilogue is implemented
         L().call("showo_gemm_kcat_bf16", L().ptr(dev(to_bf16_bits(A0))), K0, K0, L().ptr(dev(to_bf16_bits(A1))), K1, K1,
-                 L().ptr(dev(to_bf16_bits(W))), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, None, 0, M, N, 2, S())
+                 L().ptr(dev(to_bf16_bits(W))), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, None, 0, M, N, 2, 0, S())
 
 
 @pytest.mark.parametrize("variant", [256, 224, 1192, 1160, 1128])
@@ -597,16 +624,18 @@ def test_fused_qkv_fc1_equals_separate_launches_bits(variant, B, Lq, nH, F):
     cos, sin = (dev(t) for t in _rope_tables())
     Lp = ((Lq + 63) // 64) * 64
     outs = []
+    Wt = _tiled(W)
     L().call("showo_gemm_tune", 8, variant << 8, None)
     try:
-        for fused in (0, 1):
+        for fused in (0, 1, 2):  # separate launches | fused, row-major weights | fused, tiled weights
             Q = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
             K = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
             Vt = torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda")
             f = torch.zeros((M, F), dtype=torch.int16, device="cuda")
             if fused:
-                L().call("showo_gemm_qkv_fc1_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos),
-                         L().ptr(sin), L().ptr(Q), L().ptr(K), L().ptr(Vt), L().ptr(f), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp, S())
+                L().call("showo_gemm_qkv_fc1_bf16", L().ptr(h), H, L().ptr(Wt if fused == 2 else W), H, L().ptr(bias), *[L().ptr(t) for t in ln],
+                         L().ptr(cos), L().ptr(sin), L().ptr(Q), L().ptr(K), L().ptr(Vt), L().ptr(f), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp,
+                         int(fused == 2), S())
             else:
                 L().call("showo_gemm_qkv_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos),
                          L().ptr(sin), L().ptr(Q), L().ptr(K), L().ptr(Vt), B, Lq, nH, 32, 1e-5, 0, Lq, Lp, S())
@@ -616,8 +645,9 @@ def test_fused_qkv_fc1_equals_separate_launches_bits(variant, B, Lq, nH, F):
             outs.append((Q, K, Vt, f))
     finally:
         L().call("showo_gemm_tune", 8, 0, None)
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
     assert int(outs[1][3].ne(0).sum()) > 0.9 * M * F  # the fc1 tail was written
 
 

@@ -7,6 +7,12 @@ accumulation and keeps the residual stream in fp32.  Logits are compared with th
 a bf16-operand transformer reproduces fp32 logits to a few 1e-3 of the logit scale (each bf16 operand
 rounding is 2^-9 relative), so the gates are rel_rms <= 1e-2 and rel_max <= 3e-2.  Index outputs
 (sampled ids under injected noise, arg-max decode, VQ ids away from z = 0) must be identical.
+
+north_star's "logits within 1e-3 bf16 tol" is gated separately: against the oracle evaluated WITH the HIP path's bf16 rounding
+points (oracle `Bf16Points`: weights, LayerNorm output, q/k/v, P, attention output, GELU output, final hidden state), where the
+only remaining differences are fp32 accumulation order and fast-math intrinsics, the logits must agree to
+    max|d| / max|ref| <= 1e-3   (BF16_POINTS_TOL).
+That separates kernel error from operand-rounding noise; the fp32-reference numbers above stay the reported parity figure.
 """
 import numpy as np
 import pytest
@@ -18,6 +24,7 @@ from util import O, Wt, dev
 pytestmark = pytest.mark.gpu
 
 REL_RMS, REL_MAX = 1e-2, 3e-2
+BF16_POINTS_TOL = 1e-3
 
 
 def _check_logits(got, ref, what):
@@ -43,6 +50,40 @@ def test_tiny_forward_matches_reference_golden():
     assert torch.equal(lg, lg) and (lg2 - m(dev(g["mmu_ids"]), attention_mask=dev(g["mmu_mask"]))).abs().max() == 0
     with pytest.raises(ValueError):
         m(dev(g["mmu_ids"]), attention_mask=dev(g["t2i_mask"]))
+
+
+def _check_bf16_points(got, want, what):
+    rmax, rrms = util.relerr(got, want)
+    print(f"[parity] {what} vs bf16-rounding-point oracle: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rmax <= BF16_POINTS_TOL, (what, rmax, rrms)
+
+
+def test_tiny_forward_vs_bf16_points_oracle():
+    """logits within 1e-3 of the oracle that rounds where the HIP path rounds (north_star's bf16 tolerance).  Batches below 256
+    token rows take the unfused projection (q|k|v pass through a bf16 buffer: qkv_round); a [3,130] batch takes the fused
+    [Wqkv ; W1] + K-concatenated path of the benches."""
+    g = util.golden("showo_tiny_forward.npz")
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd)
+    sdt = O.to_torch(sd)
+    for name in ("t2i", "mmu", "train"):
+        ids, mask = torch.from_numpy(g[name + "_ids"]), torch.from_numpy(g[name + "_mask"])
+        assert ids.numel() < 256
+        got = m(ids.cuda(), attention_mask=mask.cuda())
+        want = O.showo_logits(sdt, d, ids, attention_mask=mask, pts=O.Bf16Points(qkv_round=True))
+        _check_bf16_points(got, want, f"tiny {name} logits")
+    torch.manual_seed(3)
+    T = d.max_text_len + 1
+    rows = [[d.pad_id] * (T - k) + [d.t2i_id] + torch.randint(0, d.llm_vocab, (k - 2,)).tolist() + [20, d.soi_id]
+            + torch.randint(d.image_offset, d.image_offset + d.codebook, (d.num_vq_tokens,)).tolist() + [d.eoi_id] for k in (3, 5, 9)]
+    ids = torch.tensor(rows * 4)  # 12 sequences: >= 256 token rows -> fused layer path
+    assert ids.numel() >= 256
+    mask = O.mask_t2i(ids, d.pad_id, d.soi_id, d.eoi_id)
+    m2 = util.build_showo(d, sd, max_batch=12, max_seq=ids.shape[1])
+    got = m2(ids.cuda(), attention_mask=mask.cuda())
+    want = O.showo_logits(sdt, d, ids, attention_mask=mask, pts=O.Bf16Points())
+    _check_bf16_points(got, want, "tiny fused-path logits")
+    _check_logits(got, O.showo_logits(sdt, d, ids, attention_mask=mask), "tiny fused-path logits vs fp32 oracle")
 
 
 def test_tiny_forward_rows_equals_full_forward_slice():
@@ -79,10 +120,9 @@ def test_tiny_t2i_generate_noise_injected():
     print(f"[parity] tiny t2i_generate (reference noise injected): id agreement {agree:.4f}")
     assert out.dtype == torch.int64 and tuple(out.shape) == (B, N)
     assert int(out.min()) >= 0 and int(out.max()) < V
-    # bf16 logits vs fp32 reference can flip a near-tie draw; the trajectory must otherwise be the reference's
-    assert agree >= 0.9
-    if agree == 1.0:
-        assert torch.equal(ids.cpu(), torch.from_numpy(g["final_input_ids"]))
+    # the whole trajectory (every sampled id and every re-masking decision of every step) is the reference's
+    assert agree == 1.0
+    assert torch.equal(ids.cpu(), torch.from_numpy(g["final_input_ids"]))
     # hipGraph replay of the denoise step (step index + schedule constants in device memory): identical trajectory
     ids_g = dev(g["ids_cond"]).clone()
     out_g = m.t2i_generate(input_ids=ids_g, uncond_input_ids=dev(g["ids_uncond"]), attention_mask=dev(g["mask"]), temperature=1.0,
@@ -217,6 +257,14 @@ def test_full_size_logits_vs_reference_subset():
     print(f"[parity] full-size logits vs reference subset: rel_max={rmax:.3e} rel_rms={rrms:.3e} "
           f"(abs max err {float((sub.cpu() - ref).abs().max()):.3e}, logit absmax {float(g['logit_absmax']):.3f}, std {float(g['logit_std']):.3f})")
     assert rrms <= REL_RMS and rmax <= REL_MAX
+    # north_star's 1e-3: the same logits against the oracle with the HIP path's bf16 rounding points (full [2,387,58498] tensor)
+    sdt = O.to_torch(Wt.make_showo_state(d, seed=int(g["seed"])))
+    want = O.showo_logits(sdt, d, torch.from_numpy(g["ids"]), attention_mask=mask.cpu(), pts=O.Bf16Points())
+    del sdt
+    _check_bf16_points(lg, want, "full-size logits [2,387,58498]")
+    sub_w = want[:, torch.from_numpy(g["rows"])][:, :, torch.from_numpy(g["cols"])]
+    print(f"[parity] bf16-rounding-point oracle vs fp32 reference (operand rounding alone): rel_max={util.relerr(sub_w, ref)[0]:.3e}")
+    del want
     # size-independent properties at the BASELINE size: cfg2 shape [16,387], 3 steps
     B, N = 8, 256
     rs = np.random.RandomState(0)

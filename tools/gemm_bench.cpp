@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
         uint16_t *attn, *ffn, *Wd, *W2, *Wcat, *h, *Wq1, *Q0, *K0, *V0, *Q1, *K1, *V1, *f0, *f1;
         float *x0, *x1, *bd, *b2, *bsum, *bq1, *lnp, *cosT, *sinT;
         CK(hipMalloc(&attn, (size_t)Mx * H * 2)); CK(hipMalloc(&ffn, (size_t)Mx * F * 2)); CK(hipMalloc(&Wd, (size_t)H * H * 2)); CK(hipMalloc(&W2, (size_t)H * F * 2));
-        CK(hipMalloc(&Wcat, (size_t)H * (H + F) * 2)); CK(hipMalloc(&x0, (size_t)Mx * H * 4)); CK(hipMalloc(&x1, (size_t)Mx * H * 4));
+        const int RW = 8; CK(hipMalloc(&Wcat, (size_t)RW * H * (H + F) * 2)); CK(hipMalloc(&x0, (size_t)Mx * H * 4)); CK(hipMalloc(&x1, (size_t)Mx * H * 4));
         CK(hipMalloc(&bd, H * 4)); CK(hipMalloc(&b2, H * 4)); CK(hipMalloc(&bsum, H * 4));
         fill_kernel<<<1024, 256, 0, st>>>(attn, (size_t)Mx * H, 11u, 1.0f);
         fill_kernel<<<1024, 256, 0, st>>>(ffn, (size_t)Mx * F, 12u, 1.0f);
@@ -164,6 +164,7 @@ int main(int argc, char** argv) {
         fill_kernel<<<1024, 256, 0, st>>>(W2, (size_t)H * F, 14u, 0.02f);
         CK(hipMemcpy2DAsync(Wcat, (size_t)(H + F) * 2, Wd, (size_t)H * 2, (size_t)H * 2, H, hipMemcpyDeviceToDevice, st));
         CK(hipMemcpy2DAsync(Wcat + H, (size_t)(H + F) * 2, W2, (size_t)F * 2, (size_t)F * 2, H, hipMemcpyDeviceToDevice, st));
+        for (int r = 1; r < RW; ++r) CK(hipMemcpyAsync(Wcat + (size_t)r * H * (H + F), Wcat, (size_t)H * (H + F) * 2, hipMemcpyDeviceToDevice, st));
         std::vector<float> hb(H), hb2(H), hs(H);
         for (int i = 0; i < H; ++i) { hb[i] = 0.01f * ((i * 37) % 101 - 50); hb2[i] = 0.02f * ((i * 53) % 89 - 44); hs[i] = hb[i] + hb2[i]; }
         CK(hipMemcpy(bd, hb.data(), H * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b2, hb2.data(), H * 4, hipMemcpyHostToDevice));
@@ -181,64 +182,75 @@ int main(int argc, char** argv) {
         std::vector<float> r0((size_t)Mx * H), r1((size_t)Mx * H);
         CK(hipMemcpy(r0.data(), x0, r0.size() * 4, hipMemcpyDeviceToHost));
         const int vars[] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128};
-        printf("kcat M=%d:", Mx);
+        uint16_t* WcatT; CK(hipMalloc(&WcatT, (size_t)RW * showo_gemm_tiled_elems(H, H + F) * 2));
+        for (int r = 0; r < RW; ++r) RC(showo_gemm_tile_weight(Wcat, H + F, H, H + F, WcatT + (size_t)r * showo_gemm_tiled_elems(H, H + F), st));
+        for (int tl : {0, 1}) {
+        const uint16_t* Wk = tl ? WcatT : Wcat; const size_t wstride = tl ? (size_t)showo_gemm_tiled_elems(H, H + F) : (size_t)H * (H + F);
+        printf("kcat M=%d tiled=%d:", Mx, tl);
         for (int v : vars) {
-            RC(showo_gemm_tune(8, v << 8, nullptr));
+            RC(showo_gemm_tune(8, (v << 8) | 4, nullptr));
             size_t bad = 0;
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipMemcpy(x1, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-                RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wcat, H + F, bsum, x1, H, x1, H, Mx, H, 3, st));
+                RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wk, H + F, bsum, x1, H, x1, H, Mx, H, 3, tl, st));
                 CK(hipStreamSynchronize(st));
                 CK(hipMemcpy(r1.data(), x1, r1.size() * 4, hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < r0.size(); ++i) if (!(fabs((double)r0[i] - r1[i]) <= 2e-3 * (1 + fabs(r0[i])))) bad++;
             }
             const int iters = 10;
             CK(hipEventRecord(e0, st));
-            for (int i = 0; i < iters; ++i) RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wcat, H + F, bsum, x1, H, x1, H, Mx, H, 3, st));
+            for (int i = 0; i < iters; ++i) RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wk + (size_t)(i % RW) * wstride, H + F, bsum, x1, H, x1, H, Mx, H, 3, tl, st));
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf(" %d:%.0fTF%s", v, 2.0 * Mx * H * (H + F) * iters / (ms * 1e-3) / 1e12, bad ? "**MISMATCH**" : "");
             fflush(stdout);
         }
         printf("\n");
+        }
         // [Wqkv ; W1]: bitwise against showo_gemm_qkv_bf16 + the GELU GEMM at the same tile variant
         const int Nq = 3 * H;
-        CK(hipMalloc(&h, (size_t)Mx * H * 2)); CK(hipMalloc(&Wq1, (size_t)(Nq + F) * H * 2)); CK(hipMalloc(&bq1, (Nq + F) * 4));
+        CK(hipMalloc(&h, (size_t)Mx * H * 2)); CK(hipMalloc(&Wq1, (size_t)RW * (Nq + F) * H * 2)); CK(hipMalloc(&bq1, (Nq + F) * 4));
         CK(hipMalloc(&lnp, 4 * 64 * 4)); CK(hipMalloc(&cosT, 2048 * 32 * 4)); CK(hipMalloc(&sinT, 2048 * 32 * 4));
         const size_t nqk = (size_t)B * nH * L * 64, nvt = (size_t)B * nH * 64 * Lp;
         CK(hipMalloc(&Q0, nqk * 2)); CK(hipMalloc(&K0, nqk * 2)); CK(hipMalloc(&V0, nvt * 2)); CK(hipMalloc(&Q1, nqk * 2)); CK(hipMalloc(&K1, nqk * 2)); CK(hipMalloc(&V1, nvt * 2));
         CK(hipMalloc(&f0, (size_t)Mx * F * 2)); CK(hipMalloc(&f1, (size_t)Mx * F * 2));
         fill_kernel<<<1024, 256, 0, st>>>(h, (size_t)Mx * H, 21u, 1.0f);
         fill_kernel<<<1024, 256, 0, st>>>(Wq1, (size_t)(Nq + F) * H, 22u, 0.02f);
+        for (int r = 1; r < RW; ++r) CK(hipMemcpyAsync(Wq1 + (size_t)r * (Nq + F) * H, Wq1, (size_t)(Nq + F) * H * 2, hipMemcpyDeviceToDevice, st));
         std::vector<float> hq(Nq + F), hl(256), hc(2048 * 32), hsn(2048 * 32);
         for (int i = 0; i < Nq + F; ++i) hq[i] = 0.01f * ((i * 37) % 101 - 50);
         for (int i = 0; i < 256; ++i) hl[i] = (i & 64) ? 0.01f * (i % 7) : 1.0f + 0.01f * (i % 5);  // qw | qb | kw | kb
         for (int p = 0; p < 2048; ++p) for (int j = 0; j < 32; ++j) { double a = p * pow(10000.0, -2.0 * (j % 16) / 32.0); hc[p * 32 + j] = (float)cos(a); hsn[p * 32 + j] = (float)sin(a); }
         CK(hipMemcpy(bq1, hq.data(), hq.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(lnp, hl.data(), 1024, hipMemcpyHostToDevice));
         CK(hipMemcpy(cosT, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(sinT, hsn.data(), hsn.size() * 4, hipMemcpyHostToDevice));
-        printf("qkv|fc1 M=%d:", Mx);
+        uint16_t* Wq1T; const size_t q1e = (size_t)showo_gemm_tiled_elems(Nq + F, H); CK(hipMalloc(&Wq1T, (size_t)RW * q1e * 2));
+        for (int r = 0; r < RW; ++r) RC(showo_gemm_tile_weight(Wq1, H, Nq + F, H, Wq1T + (size_t)r * q1e, st));
+        for (int tl : {0, 1}) {
+        const uint16_t* Wq = tl ? Wq1T : Wq1; const size_t qstride = tl ? q1e : (size_t)(Nq + F) * H;
+        printf("qkv|fc1 M=%d tiled=%d:", Mx, tl);
         for (int v : vars) {
-            RC(showo_gemm_tune(8, v << 8, nullptr));
+            RC(showo_gemm_tune(8, (v << 8) | 4, nullptr));
             CK(hipMemsetAsync(V0, 0, nvt * 2, st)); CK(hipMemsetAsync(V1, 0, nvt * 2, st));
             RC(showo_gemm_qkv_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q0, K0, V0, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
             RC(showo_gemm_bf16(h, H, Wq1 + (size_t)Nq * H, H, bq1 + Nq, 0, f0, F, nullptr, 0, Mx, F, H, 1, st));
-            RC(showo_gemm_qkv_fc1_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
+            RC(showo_gemm_qkv_fc1_bf16(h, H, Wq, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, tl, st));
             CK(hipStreamSynchronize(st));
             auto same = [&](const uint16_t* a, const uint16_t* b, size_t n) { std::vector<uint16_t> x(n), y(n); CK(hipMemcpy(x.data(), a, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), b, n * 2, hipMemcpyDeviceToHost)); return memcmp(x.data(), y.data(), n * 2) == 0; };
             const bool ok = same(Q0, Q1, nqk) && same(K0, K1, nqk) && same(V0, V1, nvt) && same(f0, f1, (size_t)Mx * F);
             const int iters = 10;
             CK(hipEventRecord(e0, st));
-            for (int i = 0; i < iters; ++i) RC(showo_gemm_qkv_fc1_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
+            for (int i = 0; i < iters; ++i) RC(showo_gemm_qkv_fc1_bf16(h, H, Wq + (size_t)(i % RW) * qstride, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, tl, st));
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf(" %d:%.0fTF%s", v, 2.0 * Mx * (Nq + F) * H * iters / (ms * 1e-3) / 1e12, ok ? "" : "**MISMATCH**");
             fflush(stdout);
         }
         printf("\n");
+        }
         for (void* p : {(void*)attn, (void*)ffn, (void*)Wd, (void*)W2, (void*)Wcat, (void*)x0, (void*)x1, (void*)bd, (void*)b2, (void*)bsum, (void*)h, (void*)Wq1, (void*)bq1,
-                        (void*)lnp, (void*)cosT, (void*)sinT, (void*)Q0, (void*)K0, (void*)V0, (void*)Q1, (void*)K1, (void*)V1, (void*)f0, (void*)f1}) CK(hipFree(p));
+                        (void*)lnp, (void*)cosT, (void*)sinT, (void*)WcatT, (void*)Wq1T, (void*)Q0, (void*)K0, (void*)V0, (void*)Q1, (void*)K1, (void*)V1, (void*)f0, (void*)f1}) CK(hipFree(p));
     }
-    RC(showo_gemm_tune(8, 0, nullptr));
+    RC(showo_gemm_tune(8, 2, nullptr));
     RC(showo_gemm_set_impl(0));
     return 0;
 }
