@@ -1,0 +1,183 @@
+"""bench_configs.py — the two BASELINE.json configs that are not the headline line, as bench workloads with their own JSON line
+(`python bench.py --workload t2i512 | mmu`; same flags, same one-line contract, N = 1 only):
+
+  t2i512 (configs[2]): configs/showo_demo_512x512.yaml, t2i 512x512, batch 4, inpainting of the centred 16x16 token block
+      (inference_t2i.py:100-113), CFG 5.0 -> forward on [8,1155], 18 mask-predict steps, including MAGVITv2.get_code of the
+      input image and decode_code of the result.  MFMA-bound like the headline; roofline kernel = gemm2p_kernel.
+  mmu (configs[3]): inference_mmu.py w_clip_vit, 512x512: per image CLIP ViT-L/14-336 tower + mm_projector + splice, prefill of
+      the 631 prompt embeddings, 100 new tokens (top_k = 1) against the KV cache; 4 images = 4 independent batch-1 decodes
+      (modeling_showo.py:204,229).  HBM-bound: every decoded token streams the 2.66 GB of bf16 weights once
+      (24 x 100.7 MB + 240 MB lm_head), so roofline.achieved = 2.66 GB x tokens / decode time.
+
+Synthetic data, random-init weights of the true architectures (no checkpoints offline).  Nothing here touches oracle/."""
+import argparse
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def _events(L, enable, stride=5):
+    L.call("showo_prof_reset")
+    L.call("showo_prof_set_stride", stride)
+    L.call("showo_prof_enable", 1 if enable else 0)
+
+
+def _read(L, kind):
+    ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+    L.call("showo_prof_read", kind, C.byref(ms), C.byref(n), C.byref(fl))
+    return ms.value, int(n.value), fl.value
+
+
+def t2i512(a):
+    import showo_amd
+    from showo_amd import synthetic
+    from showo_amd.prompting_utils import intervals_predict_next
+    L = showo_amd._lib
+    B, N = 4, 1024
+    Lseq = 129 + 1 + N + 1
+    torch.manual_seed(0)
+    model = synthetic.random_init_showo(max_batch=2 * B, max_seq=Lseq, ln_jitter=True, num_vq_tokens=N).eval()
+    vq = showo_amd.MAGVITv2(max_batch=B, max_res=512).cuda().eval()
+    uni = synthetic.prompting(max_text_len=128)
+    sp = uni.sptids_dict
+    off = len(uni.text_tokenizer)
+    x = (torch.rand(1, 3, 512, 512, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)) * 2 - 1).expand(B, -1, -1, -1).contiguous()
+    grid = torch.zeros(32, 32, dtype=torch.bool)
+    grid[8:24, 8:24] = True  # the centred 16x16 block of the 32x32 token grid is generated, the rest is kept
+    hole = grid.reshape(-1).cuda()
+    rs = np.random.RandomState(0)
+    prompts = [synthetic.random_text(rs, 3 + 7 * i) for i in range(B)]
+    cfg = showo_amd.gen_config(num_vq_tokens=N)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def step():
+        codes = vq.get_code(x)
+        img = torch.where(hole[None], torch.full_like(codes, model.mask_token_id), codes + off)
+        ic, _ = uni((prompts, img), 't2i_gen')
+        iu, _ = uni(([''] * B, img), 't2i_gen')
+        mask = intervals_predict_next(torch.cat([ic, iu]), pad_id=int(sp['<|pad|>']), soi_id=int(sp['<|soi|>']), eoi_id=int(sp['<|eoi|>']),
+                                      rm_pad_in_image=True)
+        toks = model.t2i_generate(input_ids=ic.contiguous(), uncond_input_ids=iu.contiguous(), attention_mask=mask, timesteps=18,
+                                  guidance_scale=5.0, generator=gen, config=cfg, use_graph=a.graph)
+        return codes, toks, vq.decode_code(toks)
+
+    for _ in range(a.warmup):
+        codes, toks, img = step()
+    torch.cuda.synchronize()
+    assert tuple(img.shape) == (B, 3, 512, 512) and torch.isfinite(img).all()
+    assert torch.equal(toks[:, ~hole], codes[:, ~hole])  # known tokens come back untouched
+    _events(L, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _events(L, True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    dt_evt = time.perf_counter() - t1
+    L.call("showo_prof_enable", 0)
+    ms_g, n_g, fl_g = _read(L, 0)
+    ms_a, n_a, fl_a = _read(L, 1)
+    ms_c, n_c, fl_c = _read(L, 2)
+    ach = fl_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
+    value = B * a.steps / dt
+    return {"metric": "t2i images/sec @512x512 (18 denoise steps, inpainting, incl. get_code + decode_code)", "value": value, "unit": "images/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg3: configs/showo_demo_512x512.yaml t2i 512x512 batch 4, centred 16x16-token inpainting mask, CFG 5.0 "
+                                   "(forward on [8,1155]), 18 steps, MAGVITv2.get_code + decode_code; random-init Show-o 1.45B + MAGVIT-v2",
+                       "global_batch": B, "seq_len": Lseq, "parallelism": "replicas x1", "algorithmic_tflop_per_image": 122.5,
+                       "end_to_end_algorithmic_tflops": value * 122.5},
+            "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                         "traffic": None, "timed_launches": n_g, "avg_launch_ms": ms_g / max(1, n_g),
+                         "measured_in": f"1 extra eager step with HIP events ({dt_evt * 1e3:.0f} ms)",
+                         "attention": {"achieved": fl_a / max(1e-9, ms_a * 1e-3) / 1e12}, "vq_conv": {"achieved": fl_c / max(1e-9, ms_c * 1e-3) / 1e12}},
+            "cpu_baseline": None}
+
+
+def mmu(a):
+    import showo_amd
+    from showo_amd import synthetic
+    from showo_amd.clip_encoder import CLIP_VIT_L_14_336, vision_state_spec
+    from showo_amd.prompting_utils import create_attention_mask_for_mmu_vit
+    torch.manual_seed(0)
+    model = synthetic.random_init_showo(max_batch=1, max_seq=768, w_clip_vit=True).eval()
+    g = torch.Generator().manual_seed(22)
+    sd = {}
+    for k, shape in vision_state_spec(CLIP_VIT_L_14_336).items():  # random-init weights of the true ViT-L/14-336 architecture
+        if "layer_norm" in k or "layernorm" in k or "layrnorm" in k:
+            sd[k] = torch.ones(shape) if k.endswith("weight") else torch.zeros(shape)
+        else:
+            sd[k] = torch.randn(shape, generator=g) * 0.02
+    tower = showo_amd.CLIPVisionTower("synthetic", config=CLIP_VIT_L_14_336, state_dict=sd, max_batch=1).cuda()
+    emb_tab = model.showo.model.embed_tokens.weight
+    Lp, NEW = 1 + 28 + 1 + 576 + 1 + 24, 100
+    n_img = 4 * max(1, a.steps)
+    t_clip, t_first, t_dec = [], [], []
+    for i in range(a.warmup + n_img):
+        gg = torch.Generator(device="cuda").manual_seed(3 + i)
+        pixels = torch.randn(1, 3, 336, 336, device="cuda", generator=gg)  # CLIPImageProcessor output (host side, not timed)
+        ids = torch.randint(0, 50256, (1, Lp - 576), device="cuda", generator=gg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            img_emb = model.mm_projector(tower(pixels))
+            txt = emb_tab[ids]
+            emb = torch.cat([txt[:, :30], img_emb, txt[:, 30:]], dim=1)
+        am = create_attention_mask_for_mmu_vit(emb, system_prompt_len=28)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        first = model.mmu_generate(input_embeddings=emb, attention_mask=am[0], max_new_tokens=1, top_k=1)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        toks = model.mmu_generate(input_embeddings=emb, attention_mask=am[0], max_new_tokens=NEW, top_k=1)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        assert len(toks) == NEW and int(toks[0]) == int(first[0])
+        if i >= a.warmup:
+            t_clip.append(t1 - t0), t_first.append(t2 - t1), t_dec.append(t3 - t2)
+    tc, tf, td = float(np.mean(t_clip)), float(np.mean(t_first)), float(np.mean(t_dec))
+    # decode time of the NEW - 1 cached steps = whole call minus the prefill + first token (measured on the same prompt)
+    t_tok = max(1e-9, (td - tf) / (NEW - 1))
+    bytes_per_token = 2.0 * (24 * (4 * 2048 * 2048 + 2 * 2048 * 8192) + 58498 * 2048)  # bf16 weights streamed once per token
+    ach = bytes_per_token / t_tok / 1e9
+    return {"metric": "mmu AR decode tokens/sec (w_clip_vit, 631-embedding prompt, 100 new tokens, batch 1)", "value": NEW / td, "unit": "tokens/s",
+            "n_gpus": 1, "steps": n_img, "warmup": a.warmup, "ms_per_step": td * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg4: inference_mmu.py w_clip_vit 512x512, per image CLIP ViT-L/14-336 + mm_projector + splice, prefill of "
+                                   "631 embeddings, 100 new tokens top_k=1 (KV cache, device-side loop, hipGraph per token); 4 images per step as 4 "
+                                   "independent batch-1 decodes", "global_batch": 1, "seq_len": Lp + NEW, "parallelism": "replicas x1",
+                       "clip_projector_splice_ms": tc * 1e3, "prefill_to_first_token_ms": tf * 1e3, "time_to_first_token_ms": (tc + tf) * 1e3,
+                       "ms_per_decoded_token": t_tok * 1e3},
+            "roofline": {"bound": "hbm", "kernel": "decode step = 24 x (ln_gemv2 + attn_decode + out_gemv2) + lm_head GEMV + arg-max", "achieved": ach,
+                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_token": bytes_per_token, "measured_peak_copy_GBps": None},
+            "cpu_baseline": None}
+
+
+def main(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", required=True)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a, _ = ap.parse_known_args(argv)
+    if a.gpus != 1:
+        raise SystemExit("bench: the t2i512 / mmu workloads are single-GPU lines (replicas scale like the headline)")
+    torch.cuda.set_device(0)
+    out = t2i512(a) if a.workload == "t2i512" else mmu(a)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -172,12 +172,14 @@ def main(argv=None):
                     "attention_fwd": {"achieved": prof["attention_fwd"]["flop_timed"] / max(1e-9, prof["attention_fwd"]["ms"] * 1e-3) / 1e12},
                     "vq_conv": {"achieved": prof["vq_conv"]["flop_timed"] / max(1e-9, prof["vq_conv"]["ms"] * 1e-3) / 1e12}}
         cpu = None
+        with_vq = vq is not None
+        losses_host = [float(x) for x in losses.cpu()]
         if not a.no_cpu_baseline and world == 1:
-            del trainer, model, vq
+            trainer = model = vq = None  # free the 30+ GB of GPU-side state before the host-side leg allocates its own
             torch.cuda.empty_cache()
             cpu = cpu_baseline(bt + bl + bm)
         print(json.dumps({
-            "metric": "train step-time (stage-1 mixed batch, fwd+bwd+AdamW" + ("" if vq is None else "+VQ encode") + ")",
+            "metric": "train step-time (stage-1 mixed batch, fwd+bwd+AdamW" + ("+VQ encode" if with_vq else "") + ")",
             "value": ms, "unit": "ms/step", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE cfg5: showo_pretraining_stage1 per-GPU batch 15 t2i + 4 lm + 10 mmu x 387 tokens, "
@@ -185,7 +187,7 @@ def main(argv=None):
                        "parallelism": f"dp{world}", "tokens_per_s": T * world / (ms * 1e-3),
                        "algorithmic_tflops_per_gpu": flop / (ms * 1e-3) / 1e12,
                        "gradient_wire": a.wire if world > 1 else None,
-                       "losses_last_step": [float(x) for x in losses.cpu()]},
+                       "losses_last_step": losses_host},
             "roofline": roofline, "cpu_baseline": cpu,
         }))
     if dist is not None:

@@ -323,6 +323,13 @@ void showo_engine_destroy(showo_engine* e);
 int showo_engine_load(showo_engine* e, const char* key, const float* src, int64_t n, void* stream);
 /* number of tensors still missing (0 = ready) */
 int showo_engine_missing(const showo_engine* e);
+/* number of times showo_engine_t2i_generate captured a denoise step into a hipGraph on this engine (the instantiated graph is
+ * cached: identical calls replay it without capturing again) */
+int showo_engine_t2i_captures(const showo_engine* e);
+/* parity hook: while buf != NULL every forward copies the fp32 residual stream into buf fp32 [layers + 1, B*L, hidden] (slot 0 = the
+ * embedded input, slot i = output of transformer block i - 1), so that a test can check each block against the oracle evaluated on
+ * the block's own input as the GPU computed it (no error amplification across blocks). */
+int showo_engine_set_collect(showo_engine* e, float* buf);
 /* Showo.forward without labels (modeling_showo.py:76-79 -> phi.py:953-1183):
  * ids int64 [B,L] or embeds fp32 [B,L,H] (exactly one non-NULL); mask fp32 [B,1,L,L] or NULL (causal);
  * logits fp32 [B,L,vocab]. */

@@ -121,6 +121,30 @@ def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
     return o @ sd[p + "dense.weight"].T + sd[p + "dense.bias"]
 
 
+def phi_layer(sd, d, i, x, mask, cos, sin, pts=None):
+    """one PhiDecoderLayer (models/phi.py:774-790): x + Attn(LN(x)) + MLP(LN(x)); pts = round where the HIP path rounds"""
+    p = f"showo.model.layers.{i}."
+    h = layer_norm(x, sd[p + "input_layernorm.weight"], sd[p + "input_layernorm.bias"], d.ln_eps)
+    if pts is not None:
+        h = bf16r(h)
+        o = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin, pts)
+        m = bf16r(gelu_new(h @ pts.w(sd, p + "mlp.fc1.weight").T + sd[p + "mlp.fc1.bias"]))
+        return x + (o @ pts.w(sd, p + "self_attn.dense.weight").T + m @ pts.w(sd, p + "mlp.fc2.weight").T
+                    + (sd[p + "self_attn.dense.bias"] + sd[p + "mlp.fc2.bias"]))
+    a = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin)
+    m = gelu_new(h @ sd[p + "mlp.fc1.weight"].T + sd[p + "mlp.fc1.bias"])
+    m = m @ sd[p + "mlp.fc2.weight"].T + sd[p + "mlp.fc2.bias"]
+    return a + m + x  # parallel residual (models/phi.py:790)
+
+
+def phi_head(sd, d, x, pts=None):
+    """final LayerNorm + biased lm_head + .float() (models/phi.py:1078, 1182-1183)"""
+    hid = layer_norm(x, sd["showo.model.final_layernorm.weight"], sd["showo.model.final_layernorm.bias"], d.ln_eps)
+    if pts is not None:
+        return (bf16r(hid) @ pts.w(sd, "showo.lm_head.weight").T + sd["showo.lm_head.bias"]).float()
+    return (hid @ sd["showo.lm_head.weight"].T + sd["showo.lm_head.bias"]).float()
+
+
 def phi_hidden(sd, d, input_ids=None, inputs_embeds=None, attention_mask=None, collect=None, pts=None):
     """Returns final-LayerNorm'ed hidden states [B,L,H].  pts: a Bf16Points object = round where the HIP path rounds."""
     if inputs_embeds is None:
@@ -130,19 +154,7 @@ def phi_hidden(sd, d, input_ids=None, inputs_embeds=None, attention_mask=None, c
     cos, sin = rope_tables(d.rotary_dim, d.max_pos, d.rope_theta)
     mask = None if attention_mask is None else attention_mask.to(torch.float32)
     for i in range(d.layers):
-        p = f"showo.model.layers.{i}."
-        h = layer_norm(x, sd[p + "input_layernorm.weight"], sd[p + "input_layernorm.bias"], d.ln_eps)
-        if pts is not None:
-            h = bf16r(h)
-            o = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin, pts)
-            m = bf16r(gelu_new(h @ pts.w(sd, p + "mlp.fc1.weight").T + sd[p + "mlp.fc1.bias"]))
-            x = x + (o @ pts.w(sd, p + "self_attn.dense.weight").T + m @ pts.w(sd, p + "mlp.fc2.weight").T
-                     + (sd[p + "self_attn.dense.bias"] + sd[p + "mlp.fc2.bias"]))
-        else:
-            a = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin)
-            m = gelu_new(h @ sd[p + "mlp.fc1.weight"].T + sd[p + "mlp.fc1.bias"])
-            m = m @ sd[p + "mlp.fc2.weight"].T + sd[p + "mlp.fc2.bias"]
-            x = a + m + x  # parallel residual (models/phi.py:790)
+        x = phi_layer(sd, d, i, x, mask, cos, sin, pts)
         if collect is not None:
             collect.append(x)
     hid = layer_norm(x, sd["showo.model.final_layernorm.weight"], sd["showo.model.final_layernorm.bias"], d.ln_eps)

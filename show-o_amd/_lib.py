@@ -102,6 +102,8 @@ _PROTOS = {
     "showo_engine_create": [c_p, C.POINTER(c_p)],
     "showo_engine_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_engine_missing": [c_p],
+    "showo_engine_t2i_captures": [c_p],
+    "showo_engine_set_collect": [c_p, c_p],
     "showo_engine_use_intervals": [c_p, c_p, c_p],
     "showo_engine_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "showo_engine_forward_rows": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p],

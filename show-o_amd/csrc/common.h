@@ -60,6 +60,14 @@ __device__ inline float gelu_new_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 
+// 16-byte streaming load with the non-temporal hint (global_load_dwordx4 ... nt): weights that ONE wave reads once (decode GEMVs)
+// should not displace reusable lines; measured on MI355X decode layers: issued -> landed -18 % (MI355X_MICROARCH.md, "nt-weights")
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint4 ldg_nt16(const void* p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // direct HBM -> LDS copy, 16 B per lane; the LDS destination is wave-uniform base + lane * 16 (lane-linear image)
 __device__ inline void glds16(const bf16_t* src, bf16_t* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

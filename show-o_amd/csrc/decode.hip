@@ -38,7 +38,7 @@ __device__ inline void load4(const bf16_t* row, int k0, int K, uint4 (&wv)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * 512;
-        wv[u] = k < K ? *reinterpret_cast<const uint4*>(row + k) : make_uint4(0, 0, 0, 0);
+        wv[u] = k < K ? ldg_nt16(row + k) : make_uint4(0, 0, 0, 0);
     }
 }
 // acc += sum over the 4 loaded 8-element groups, in gemv_kernel's order (u ascending, j ascending)

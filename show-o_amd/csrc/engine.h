@@ -86,7 +86,18 @@ struct showo_engine {
     // second stream for the two independent branches of a Phi block (attention branch | fc1): see run_layers
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fc1 = nullptr;
-    // hipGraph replay of the denoise step
+    // hipGraph replay of the denoise step: the instantiated graph of one active-rows step is cached, keyed by everything baked
+    // into its launches (shapes, scalars, every pointer that is not engine-owned-and-fixed)
+    struct T2IGraphKey {
+        int nseq, L, N, prefix, steps, id_offset, codebook, reuse;
+        int64_t mask_id;
+        float guidance;
+        const void* p[11];
+    };
+    T2IGraphKey t2i_key{};
+    hipGraphExec_t t2i_exec = nullptr;
+    float* collect = nullptr;  // parity hook (showo_engine_set_collect)
+    int t2i_captures = 0;  // how often a denoise step was captured (tests: a second identical call must not capture again)
     int* step_dev = nullptr;
     float* sched_dev = nullptr;
     int sched_cap = 0;

@@ -151,12 +151,23 @@ extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** 
 
 extern "C" void showo_engine_destroy(showo_engine* e) {
     if (!e) return;
+    if (e->t2i_exec) hipGraphExecDestroy(e->t2i_exec);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_fc1) hipEventDestroy(e->ev_fc1);
     if (e->side) hipStreamDestroy(e->side);
     for (void* p : e->allocs) hipFree(p);
     delete e;
 }
+
+// parity hook: the next forward calls copy the fp32 residual stream into buf [layers + 1, B*L, hidden] (slot 0 = embeddings,
+// slot i = output of block i - 1); NULL switches it off.  Lets a test hold EVERY block to the oracle on the GPU's own block input.
+extern "C" int showo_engine_set_collect(showo_engine* e, float* buf) {
+    if (!e) return set_error_msg(1, "engine: null handle");
+    e->collect = buf;
+    return 0;
+}
+
+extern "C" int showo_engine_t2i_captures(const showo_engine* e) { return e ? e->t2i_captures : -1; }
 
 extern "C" int showo_engine_missing(const showo_engine* e) { return e ? e->expected - (int)e->loaded.size() : -1; }
 
@@ -210,7 +221,7 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     }
     if (rc == -1) return set_error_msg(3, "engine_load: unknown state-dict key");
     if (rc == 0) e->loaded.insert(k);
-    e->fused_valid = false;
+    e->fused_valid = false;  // the fused weight images (and with them a cached t2i graph's preconditions) are rebuilt on the next call
     return rc;
 }
 
@@ -294,10 +305,18 @@ static bool layer_overlap_enabled() {
     return v != 0;
 }
 
+// parity hook (showo_engine_set_collect): copy the fp32 residual stream after layer `slot - 1` (slot 0 = the embeddings)
+static int collect_x(showo_engine* e, int slot, int T, hipStream_t s) {
+    if (!e->collect) return 0;
+    SHOWO_CHECK_HIP(hipMemcpyAsync(e->collect + (int64_t)slot * T * e->H, e->x, (size_t)T * e->H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
                       const float* dense, hipStream_t s) {
     const int H = e->H, F = e->F, nH = e->nH;
     const int T = B * L;
+    TRY(collect_x(e, 0, T, s));
     const int Lk = pos0 + L;
     const int Lcap = kv.Lcap, Lp = kv.Lp;
     if (T == 1 && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
@@ -335,6 +354,7 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
             TRY(showo_gemm_kcat_bf16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32,
                                      e->fused_tiled ? 1 : 0, s));
+            TRY(collect_x(e, li + 1, T, s));
         }
         return 0;
     }
@@ -378,6 +398,7 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         if (fork) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
         else TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, s));
         TRY(showo_gemm_bf16(e->ffn, F, l.w2, F, l.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+        TRY(collect_x(e, li + 1, T, s));
     }
     return 0;
 }
@@ -524,29 +545,41 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
                                B, N, s));
         return 0;
     };
-    // hipGraph path: step 0 runs eagerly (first-use kernel attributes are set outside a capture), then ONE step is captured
-    // with the step index in device memory and replayed for the remaining steps.  Not combined with per-launch event timing.
-    const int n_eager = reuse ? 2 : 1;  // eager steps before a capture: every kernel variant has been launched once
+    // hipGraph path (the default of Showo.t2i_generate): ONE denoise step -- every row from <soi> on, ~80 kernels -- is captured with
+    // everything that changes from step to step or call to call in device memory (step index, schedule constants, seed) and the
+    // instantiated graph is CACHED on the engine, keyed by every launch argument baked into it; later calls with the same key
+    // replay it without capturing again.  The eager steps before a capture (2 with prefix reuse: the full step 0 and one
+    // active-rows step) launch every kernel variant once (first-use attributes, GEMM tile tuning) outside the capture; step 0
+    // always runs eagerly.  Not combined with per-launch event timing.
+    const int n_eager = reuse ? 2 : 1;
     const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query();
     if (!graph) {
         for (int step = 0; step < steps; ++step) TRY(denoise_step(step, step == 0 || !reuse));
     } else {
-        if (!e->step_dev) TRY(e->alloc(&e->step_dev, 4));
+        if (!e->step_dev) { TRY(e->alloc(&e->step_dev, 4)); }
         if (e->sched_cap < 2 * steps) { TRY(e->alloc(&e->sched_dev, 2 * steps)); e->sched_cap = 2 * steps; }
         std::vector<float> sched(2 * steps);
         for (int i = 0; i < steps; ++i) { sched[i] = mask_len_host[i]; sched[steps + i] = temps_host[i]; }
+        const int hdr[4] = {0, 0, (int)(uint32_t)(seed & 0xffffffffu), (int)(uint32_t)(seed >> 32)};  // step index | pad | seed
         SHOWO_CHECK_HIP(hipMemcpyAsync(e->sched_dev, sched.data(), sizeof(float) * 2 * steps, hipMemcpyHostToDevice, s));
-        SHOWO_CHECK_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
-        SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // `sched` is a host temporary
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->step_dev, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
+        SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // `sched` / `hdr` are host temporaries
         showo::sampler_set_device_step(e->step_dev, e->sched_dev, steps);
+        showo_engine::T2IGraphKey key{};
+        key.nseq = nseq; key.L = L; key.N = N; key.prefix = prefix; key.steps = steps; key.id_offset = id_offset; key.codebook = codebook;
+        key.reuse = reuse ? 1 : 0; key.mask_id = mask_id; key.guidance = guidance;
+        key.p[0] = iv; key.p[1] = flag; key.p[2] = mask; key.p[3] = exp_noise; key.p[4] = uniform; key.p[5] = e->row_logits;
+        key.p[6] = e->tk; key.p[7] = e->tvt; key.p[8] = e->sched_dev; key.p[9] = e->step_dev; key.p[10] = s;
+        const bool hit = e->t2i_exec && memcmp(&key, &e->t2i_key, sizeof(key)) == 0 && e->fused_valid;
         int rc = 0;
-        for (int i = 0; i < n_eager && !rc; ++i) {
+        const int first_replay = hit ? 1 : n_eager;
+        for (int i = 0; i < first_replay && !rc; ++i) {
             rc = denoise_step(-1, i == 0 || !reuse);
             if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
         }
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        if (!rc) {
+        if (!rc && !hit) {
+            if (e->t2i_exec) { hipGraphExecDestroy(e->t2i_exec); e->t2i_exec = nullptr; }
+            hipGraph_t g = nullptr;
             hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (he == hipSuccess) {
                 rc = denoise_step(-1, !reuse);
@@ -556,18 +589,18 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
             } else {
                 rc = set_error_hip(he, "hipStreamBeginCapture", __FILE__, __LINE__);
             }
+            if (!rc) {
+                hipError_t he3 = hipGraphInstantiate(&e->t2i_exec, g, nullptr, nullptr, 0);
+                if (he3 != hipSuccess) { e->t2i_exec = nullptr; rc = set_error_hip(he3, "hipGraphInstantiate", __FILE__, __LINE__); }
+                else { e->t2i_key = key; e->t2i_captures++; }
+            }
+            if (g) hipGraphDestroy(g);
         }
-        if (!rc) {
-            hipError_t he = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-            if (he != hipSuccess) rc = set_error_hip(he, "hipGraphInstantiate", __FILE__, __LINE__);
-        }
-        for (int step = n_eager; !rc && step < steps; ++step) {
-            hipError_t he = hipGraphLaunch(ge, s);
+        for (int step = first_replay; !rc && step < steps; ++step) {
+            hipError_t he = hipGraphLaunch(e->t2i_exec, s);
             if (he != hipSuccess) rc = set_error_hip(he, "hipGraphLaunch", __FILE__, __LINE__);
         }
         showo::sampler_set_device_step(nullptr, nullptr, 0);
-        if (ge) { hipStreamSynchronize(s); hipGraphExecDestroy(ge); }
-        if (g) hipGraphDestroy(g);
         if (rc) return rc;
     }
     copy_i64_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(e->ids_all, ids_cond, B * L);  // in-place update like the reference

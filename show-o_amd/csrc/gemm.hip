@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
 #pragma unroll
             for (int c = 0; c < GV_COLS; ++c) {
                 const int k = k0 + u * 512;
-                wv[u][c] = k < g.K ? *reinterpret_cast<const uint4*>(wr[c] + k) : make_uint4(0, 0, 0, 0);
+                wv[u][c] = k < g.K ? ldg_nt16(wr[c] + k) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -897,7 +897,7 @@ extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
     g_gemm_gn = gn; g_gemm_flags = flags & 0xff; g_gemm_dbg = dbg;
     g_gemm_bm = (flags >> 8) ? (flags >> 8) : -1;  // impl 5: tile variant code (0 = automatic)
     if (flags & 2) g_gemm_pf = 1;       // impl 5: L2 prefetch of the weight panel on ...
-    else if (flags & 4) g_gemm_pf = 0;  // ... off; neither bit: unchanged (SHOWO_GEMM_PF, default on)
+    else if (flags & 4) g_gemm_pf = 0;  // ... off; neither bit: unchanged (SHOWO_GEMM_PF, default off)
     return 0;
 }
 

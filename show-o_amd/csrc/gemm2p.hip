@@ -346,7 +346,8 @@ int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
 
 int g_gemm_gn = 4;  // n-panels per XCD tile group (same-process sweep on the bench workload: 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s)
 int g_gemm_bm = 0;  // 0 = read SHOWO_GEMM_BM once; -1 = choose per shape; a variant code = force it
-int g_gemm_pf = -1; // L2 prefetch of the weight panel: -1 = read SHOWO_GEMM_PF once (default on), 0 / 1 = forced (showo_gemm_tune)
+int g_gemm_pf = -1; // L2 prefetch of the weight panel: -1 = read SHOWO_GEMM_PF once (default OFF: measured -3...-8 % in the harness
+                    // with cold weights and within noise in the pipeline, profiles/r2_gemm_harness.txt), 0 / 1 = forced (showo_gemm_tune)
 
 namespace {
 
@@ -461,7 +462,7 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
 
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
     g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
-    if (g_gemm_pf < 0) { const char* e = getenv("SHOWO_GEMM_PF"); g_gemm_pf = e ? (atoi(e) != 0) : 1; }
+    if (g_gemm_pf < 0) { const char* e = getenv("SHOWO_GEMM_PF"); g_gemm_pf = e ? (atoi(e) != 0) : 0; }
     g.flags = g_gemm_pf ? 2 : 0;
     g.dbg = nullptr;
     switch (epilogue) {

@@ -24,7 +24,8 @@ struct SampleArgs {
     int64_t* sampled;
     float* sel;
     int N, V;
-    // graph replay: the step index lives in device memory (the captured launch is identical for every step)
+    // graph replay: the step index (and the seed: int32 pair at step_dev + 2) live in device memory -- the captured launch is
+    // identical for every step and every call
     const int* step_dev;
     int64_t noise_stride;  // elements of injected noise per step
 };
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(256) void cfg_softmax_sample_kernel(SampleArgs a) {
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.step_dev) {
         a.step = (uint32_t)*a.step_dev;
+        a.seed = (uint64_t)(uint32_t)a.step_dev[2] | ((uint64_t)(uint32_t)a.step_dev[3] << 32);
         if (a.exp_noise) a.exp_noise += (int64_t)a.step * a.noise_stride;
     }
     const int64_t c = a.cur[row];
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void mask_by_topk_kernel(TopkArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (a.step_dev) {
         a.step = (uint32_t)*a.step_dev;
+        a.seed = (uint64_t)(uint32_t)a.step_dev[2] | ((uint64_t)(uint32_t)a.step_dev[3] << 32);
         a.mask_len_f = a.sched[a.step];
         a.temp = a.sched[a.steps + a.step];
         if (a.uniform) a.uniform += (int64_t)a.step * a.noise_stride;

@@ -541,7 +541,9 @@ class Showo(PretrainedMixin, nn.Module):
         else:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         out = torch.empty((B, N), dtype=torch.int64, device=input_ids.device)
-        use_graph = int(kwargs.get("use_graph", 0))
+        # the denoise steps run as replays of ONE captured hipGraph (cached on the engine across calls) unless use_graph=0 is
+        # passed or per-launch event timing is on (the engine then runs the steps eagerly)
+        use_graph = int(kwargs.get("use_graph", 1))
         # bit 0: hipGraph replay of the denoise step; bit 1: recompute the step-invariant text rows every step (A/B switch)
         flags = (1 if use_graph else 0) | (0 if kwargs.get("reuse_prefix", True) else 2)
 

@@ -44,6 +44,13 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "showo_oracle" not in src and "ref_loader" not in src and "/root/reference" not in src, f
+    # tools/ and the secondary bench workloads never touch the oracle either; bench.py / bench_train.py only inside cpu_baseline()
+    for f in [os.path.join("tools", n) for n in os.listdir(os.path.join(util.ROOT, "tools")) if n.endswith((".py", ".cpp"))] + ["bench_configs.py"]:
+        src = open(os.path.join(util.ROOT, f)).read()
+        assert "showo_oracle" not in src and "import weights" not in src and "/root/reference" not in src, f
+    for f in ("bench.py", "bench_train.py"):
+        src = open(os.path.join(util.ROOT, f)).read()
+        assert src.count("import showo_oracle") == 1 and src.index("import showo_oracle") > src.index("def cpu_baseline"), f
 
 
 def test_state_dict_keys_match_reference_layout():

@@ -757,3 +757,15 @@ def test_sample_topk_philox_distribution_and_support():
     assert cnt[~keep].sum() == 0
     chi2 = float((((cnt - n * p) ** 2)[keep] / (n * p[keep])).sum())
     assert chi2 < 40.0, chi2  # dof = 5; P(chi2 > 40) ~ 1e-7
+
+
+@pytest.mark.parametrize("n", [7, 4097, 16384, 58498, 100003])
+def test_argmax_first_maximal_index(n):
+    """showo_argmax_f32 (single-block and two-stage forms) == torch.argmax incl. ties (first maximal index), NaN-free input"""
+    torch.manual_seed(n)
+    x = torch.randn(n)
+    x[torch.randint(0, n, (5,))] = float(x.max()) + 1.0  # five-way tie for the maximum
+    out = torch.zeros(1, dtype=torch.int64, device="cuda")
+    L().call("showo_argmax_f32", L().ptr(dev(x)), n, L().ptr(out), S())
+    sync()
+    assert int(out) == int(torch.nonzero(x == x.max())[0])
