@@ -503,6 +503,105 @@ def make_lr_schedules():
     print("lr_schedules.npz written")
 
 
+def _record_t2i(ref, d, ids_c, ids_u, mask, steps, w, seed):
+    """run the REFERENCE t2i_generate with its random draws recorded (multinomial as argmax(p / Exp(1)), Gumbel uniforms) and
+    every forward's input ids / logits; returns (result, final input ids, rec)"""
+    gen = torch.Generator().manual_seed(seed)
+    rec = dict(exp=[], uni=[], multi=[], fwd_in=[], fwd_out=[])
+    real_multinomial, real_uniform, real_forward = torch.multinomial, torch.Tensor.uniform_, ref.forward
+
+    def rec_multinomial(p, n, generator=None, **kw):
+        st = generator.get_state()
+        q = torch.empty_like(p).exponential_(1, generator=generator)
+        mine = torch.argmax(p / q, dim=-1, keepdim=True)
+        generator.set_state(st)
+        res = real_multinomial(p, n, generator=generator, **kw)
+        assert torch.equal(res, mine), "torch.multinomial != argmax(p/Exp(1))"
+        rec["exp"].append(q.clone())
+        rec["multi"].append(res.clone())
+        return res
+
+    def rec_uniform(self, a=0, b=1, generator=None):
+        r = real_uniform(self, a, b, generator=generator)
+        rec["uni"].append(r.clone())
+        return r
+
+    def rec_forward(x, **kw):
+        rec["fwd_in"].append(x.clone())
+        y = real_forward(x, **kw)
+        rec["fwd_out"].append(y.clone())
+        return y
+
+    torch.multinomial, torch.Tensor.uniform_, ref.forward = rec_multinomial, rec_uniform, rec_forward
+    try:
+        with torch.no_grad():
+            ids_run = ids_c.clone()
+            res = ref.t2i_generate(input_ids=ids_run, uncond_input_ids=ids_u.clone(), attention_mask=mask, temperature=1.0,
+                                   timesteps=steps, guidance_scale=w, noise_schedule=R.load_reference().sampling.cosine_schedule,
+                                   generator=gen, config=gen_config(d))
+    finally:
+        torch.multinomial, torch.Tensor.uniform_, ref.forward = real_multinomial, real_uniform, real_forward
+    return res, ids_run, rec
+
+
+def make_tiny_inpaint():
+    """cfg3-shaped trajectory on the tiny model (inference_t2i.py:100-113): batch 4, N = 64 image tokens (8x8 grid),
+    the centred 4x4 block is generated, every other position is pre-filled with the codes of ONE image repeated over the batch,
+    CFG 5.0, 18 steps -> tests/golden/showo_tiny_inpaint.npz"""
+    print("[tiny inpainting t2i_generate, N = 64, 18 steps]")
+    P = R.load_reference().prompting
+    d = Wt.ShowoDims(**dict(Wt.TINY, num_vq_tokens=64))
+    sd_np = Wt.make_showo_state(d, seed=11)
+    ref = ref_showo_from_state(d, sd_np)
+    sd = O.to_torch(sd_np)
+    rs = np.random.RandomState(12)
+    grid = np.zeros((8, 8), dtype=bool)
+    grid[2:6, 2:6] = True
+    codes = rs.randint(0, d.codebook, size=64)
+    img = np.where(grid.reshape(-1), d.mask_token_id, codes + d.image_offset)
+    ids_c = t2i_ids(d, [4, 6, 8, 9], rs, image_tokens=[img] * 4)
+    ids_u = t2i_ids(d, [3, 3, 3, 3], rs, image_tokens=[img] * 4)
+    ids_c0 = ids_c.clone()
+    mask = P.create_attention_mask_predict_next(torch.cat([ids_c, ids_u]), pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id,
+                                                rm_pad_in_image=True)
+    steps, w = 18, 5.0
+    res, ids_run, rec = _record_t2i(ref, d, ids_c, ids_u, mask, steps, w, seed=9)
+    noise = O.RecordedNoise(rec["exp"], rec["uni"])
+    o_ids = ids_c0.clone()
+    o_res = O.t2i_generate(sd, d, o_ids, ids_u.clone(), mask, 1.0, steps, w, noise=noise)
+    assert torch.equal(o_res, res) and torch.equal(o_ids, ids_run), "oracle inpainting trajectory differs from the reference"
+    keep = ~torch.from_numpy(grid.reshape(-1))
+    assert torch.equal(res[:, keep], torch.from_numpy(codes)[keep].expand(4, -1))  # known tokens come back untouched
+    print("  oracle == reference over", steps, "steps; known tokens untouched")
+    np.savez_compressed(os.path.join(GOLD, "showo_tiny_inpaint.npz"), ids_cond=ids_c0.numpy(), ids_uncond=ids_u.numpy(),
+                        mask=mask.numpy().astype(np.float32), steps=steps, guidance=w, num_vq_tokens=64, hole=grid.reshape(-1),
+                        exp_noise=torch.stack(rec["exp"]).numpy().astype(np.float32), uniform=torch.stack(rec["uni"]).numpy(),
+                        result=res.numpy(), final_input_ids=ids_run.numpy())
+
+
+def make_magvit_256():
+    """config-size VQ fixture (the bench's decode_code runs at 256x256): the REFERENCE MAGVITv2 on one 256x256 image ->
+    all 256 ids, the full latent (13x16x16), and every 4th pixel of decode_code(ids) -> tests/golden/magvit_256.npz.  The input is
+    regenerated from its seed by the test (RandomState(31).uniform(-1, 1, (1, 3, 256, 256)))."""
+    print("[magvit 256x256]")
+    sd_np = Wt.make_magvit_state(seed=21)
+    ref = R.build_reference_magvit()
+    ref.load_state_dict(O.to_torch(sd_np), strict=True)
+    x = torch.from_numpy(np.random.RandomState(31).uniform(-1, 1, size=(1, 3, 256, 256)).astype(np.float32))
+    with torch.no_grad():
+        z = ref.encoder(x)
+        ids = ref.get_code(x)
+        img = ref.decode_code(ids)
+    sd = O.to_torch(sd_np)
+    o_ids, o_z = O.magvit_get_code(sd, x, return_z=True)
+    report("encoder z @256", o_z, z)
+    assert torch.equal(o_ids, ids)
+    assert report("decode_code @256", O.magvit_decode_code(sd, ids), img) < 1e-3
+    np.savez_compressed(os.path.join(GOLD, "magvit_256.npz"), seed=21, x_seed=31, z=z.numpy(), ids=ids.numpy(),
+                        image_s4=img[:, :, ::4, ::4].contiguous().numpy(), image_absmax=float(img.abs().max()),
+                        image_rms=float(img.pow(2).mean().sqrt()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
@@ -522,6 +621,10 @@ if __name__ == "__main__":
         make_clip()
     if a.only in ("", "prompting"):
         make_prompting()
+    if a.only in ("", "inpaint"):
+        make_tiny_inpaint()
+    if a.only in ("", "magvit256"):
+        make_magvit_256()
     if a.full or a.only == "full":
         make_full_showo()
     print("done")

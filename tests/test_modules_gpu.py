@@ -13,7 +13,9 @@ fp32 residual stream after every transformer block; each block (and the final La
 oracle evaluated on the block's OWN input as the GPU computed it, with the HIP path's bf16 rounding points (oracle `Bf16Points`:
 weights, LayerNorm output, q/k/v, P, attention output, GELU output, final hidden state).  What remains is fp32 accumulation order,
 fast-math intrinsics and the occasional flipped bf16 rounding, none of it amplified by later blocks:
-    max|d| / max|ref| <= 1e-3  (BF16_POINTS_TOL)  on every block's update  x_out - x_in  and on the logits.
+    max|d| / max|ref| <= 1e-3  (BF16_POINTS_TOL)  on every block's update  x_out - x_in  and on the logits, at the model's real
+    width (K = 2048; measured at full size: worst block 9.4e-4, logits 3.2e-4).  A flipped rounding costs 2^-8 / sqrt(K) of a row's
+    scale, so the tiny K = 128 test model sits sqrt(2048 / 128) = 4x higher (measured 1.4e-3) and is gated at 4e-3.
 End to end, the rounding-point oracle is NOT closer to the GPU than the fp32 reference is (measured at full size: 5.8e-3 vs
 7.2e-3): one flipped rounding (2^-8 on one element) reaches every element of the next GEMM's output at ~2^-8 / sqrt(K) of its
 scale and flips more roundings downstream; 24 random-init blocks amplify any 1e-4 difference to the level of the bf16 operand
@@ -59,6 +61,7 @@ def test_tiny_forward_matches_reference_golden():
 
 def _blockwise_bf16_points(m, d, sdt, ids, mask, what, qkv_round, blocks=None):
     """every transformer block and the head, each against the rounding-point oracle on the GPU's own block input"""
+    tol = BF16_POINTS_TOL * max(1.0, (2048.0 / d.hidden) ** 0.5)  # the flip floor scales with 1 / sqrt(K)
     L = util.lib()
     B, Lq = ids.shape
     H = d.hidden
@@ -77,12 +80,12 @@ def _blockwise_bf16_points(m, d, sdt, ids, mask, what, qkv_round, blocks=None):
         want = O.phi_layer(sdt, d, i, xs[i], mask.float(), cos, sin, pts) - xs[i]
         err = float(((xs[i + 1] - xs[i]) - want).abs().max() / want.abs().max())
         worst = max(worst, err)
-        assert err <= BF16_POINTS_TOL, (what, "block", i, err)
+        assert err <= tol, (what, "block", i, err)
     want = O.phi_head(sdt, d, xs[d.layers], pts)
     err_head = float((got - want).abs().max() / want.abs().max())
     print(f"[parity] {what}: per-block update vs rounding-point oracle, worst rel_max={worst:.3e}; logits from the GPU's last residual "
-          f"stream rel_max={err_head:.3e} (gate {BF16_POINTS_TOL:.0e})")
-    assert err_head <= BF16_POINTS_TOL, (what, "head", err_head)
+          f"stream rel_max={err_head:.3e} (gate {tol:.0e})")
+    assert err_head <= tol, (what, "head", err_head)
     return got
 
 
@@ -505,3 +508,54 @@ def test_quantizer_module_methods_match_reference_golden():
     assert tuple(back2.shape) == (B, 13, 2, 4)
     assert torch.equal(q.embedding[dev(g["ids"][:, :8])].permute(0, 2, 1).reshape(B, 13, 2, 4), back2)  # = embedding lookup
     assert isinstance(v.quantize, type(q))
+
+
+def test_magvit_256_get_code_and_decode_code_vs_reference_golden():
+    """config-size VQ parity (the headline bench decodes at 256x256; cfg3 / training encode there too): the REFERENCE's ids, latents
+    and decoded pixels of one 256x256 image (tests/golden/magvit_256.npz, oracle/make_golden.py::make_magvit_256) against the HIP
+    path at the same shape -- the tile counts / block maps of the split-precision conv kernels differ from the 64x64 fixture's"""
+    g = util.golden("magvit_256.npz")
+    v = util.pkg().MAGVITv2(max_batch=1, max_res=256)
+    v.load_state_dict(O.to_torch(Wt.make_magvit_state(seed=int(g["seed"]))), strict=True)
+    v = v.cuda().eval()
+    x = torch.from_numpy(np.random.RandomState(int(g["x_seed"])).uniform(-1, 1, size=(1, 3, 256, 256)).astype(np.float32))
+    ids, z = v.get_code_and_latents(x.cuda())
+    zr, idr = torch.from_numpy(g["z"]), torch.from_numpy(g["ids"])
+    rmax, rrms = util.relerr(z, zr)
+    agree = float((ids.cpu() == idr).float().mean())
+    print(f"[parity] magvit get_code 256x256: latent rel_max={rmax:.3e} rel_rms={rrms:.3e}; token agreement {agree:.4f}")
+    assert tuple(ids.shape) == (1, 256) and np.array_equal(ids.cpu().numpy(), O.lfq_pack_np(z.cpu().numpy()))
+    flipped = (z.cpu() > 0) != (zr > 0)
+    assert (zr.abs()[flipped] <= 4 * float((z.cpu() - zr).abs().max())).all()  # a differing bit sits on an unresolvable latent
+    assert rrms <= 2e-4 and agree >= 0.99
+    img = v.decode_code(idr.cuda())
+    ref = torch.from_numpy(g["image_s4"])
+    d = (img.cpu()[:, :, ::4, ::4] - ref).double()
+    rel_rms, rel_max = float(d.pow(2).mean().sqrt() / float(g["image_rms"])), float(d.abs().max() / float(g["image_absmax"]))
+    print(f"[parity] magvit decode_code 256x256 (every 4th pixel): rel_max={rel_max:.3e} rel_rms={rel_rms:.3e}")
+    assert tuple(img.shape) == (1, 3, 256, 256) and rel_rms <= 2e-4 and rel_max <= 1e-3
+
+
+def test_tiny_inpainting_trajectory_cfg3_shape():
+    """cfg3-shaped t2i_generate (batch 4, N = 64, centred block generated, everything else pre-filled, CFG 5.0, 18 steps) with the
+    reference's recorded noise: every sampled id of every step is the reference's, known tokens come back untouched.  [8,75] = 600
+    token rows: the fused two-GEMM layer, prefix reuse and the cached hipGraph are all on this path."""
+    g = util.golden("showo_tiny_inpaint.npz")
+    d = Wt.ShowoDims(**dict(Wt.TINY, num_vq_tokens=int(g["num_vq_tokens"])))
+    sd = Wt.make_showo_state(d, seed=11)
+    steps, B, N, V = int(g["steps"]), g["ids_cond"].shape[0], d.num_vq_tokens, d.codebook
+    m = util.build_showo(d, sd, max_batch=2 * B, max_seq=g["ids_cond"].shape[1])
+    en = dev(g["exp_noise"].reshape(steps, B * N, V))
+    un = dev(g["uniform"].reshape(steps, B, N))
+    want = torch.from_numpy(g["result"])
+    hole = torch.from_numpy(g["hole"])
+    for ug in (1, 0):
+        ids = dev(g["ids_cond"]).clone()
+        out = m.t2i_generate(input_ids=ids, uncond_input_ids=dev(g["ids_uncond"]), attention_mask=dev(g["mask"]), temperature=1.0,
+                             timesteps=steps, guidance_scale=float(g["guidance"]), config=util.gen_config(d), _exp_noise=en, _uniform=un,
+                             use_graph=ug)
+        agree = float((out.cpu() == want).float().mean())
+        print(f"[parity] tiny inpainting trajectory (use_graph={ug}): id agreement {agree:.4f}")
+        assert agree == 1.0 and torch.equal(ids.cpu(), torch.from_numpy(g["final_input_ids"]))
+        known = torch.from_numpy(g["ids_cond"])[:, -(N + 1):-1][:, ~hole] - d.image_offset
+        assert torch.equal(out.cpu()[:, ~hole], known)
