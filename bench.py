@@ -259,6 +259,13 @@ def main():
             traffic_src = f"profiles/pmc/bench_traffic.json ({tj['tag']}: {tj['corrections']})"
         except (OSError, KeyError, TypeError, ValueError):
             pass
+        # ceilings measured on an MI355X by tools/ceiling.py (hipBLASLt through torch.matmul and a float4 copy kernel, random / zero
+        # operands, same process as gemm2p): printed next to the spec peak the fraction is taken against
+        measured_peak = None
+        try:
+            measured_peak = dict(json.load(open(os.path.join(ROOT, "profiles", "r2_ceiling.json")))["measured_peak"], source="profiles/r2_ceiling.json")
+        except (OSError, KeyError, TypeError, ValueError):
+            pass
         ach = fl_gemm.value / (ms_gemm.value * 1e-3) / 1e12 if ms_gemm.value > 0 else 0.0
         out = {
             "metric": "t2i images/sec @256x256 (18 denoise steps)", "value": value, "unit": "images/s", "n_gpus": world,
@@ -272,8 +279,8 @@ def main():
                        # SURVEY.md §8d counts the reference's flops (38.4 TFLOP per image, text rows recomputed every step); the
                        # path executes fewer (prefix reuse), so the whole-job rate in the reference's units is also given
                        "end_to_end_algorithmic_frac_of_mfma_peak": value * 38.4 / 2500.0},
-            "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM, all epilogues: fused-QKV / dense / fc1+GELU / fc2 / lm_head rows)",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM; per layer ONE [Wqkv;W1] projection with the QKV / GELU split epilogue and ONE K-concatenated dense|fc2 residual GEMM; lm_head rows)",
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "measured_peak": measured_peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "launches": int(n_all.value), "timed_launches": int(n_gemm.value),
                          "avg_launch_ms": ms_gemm.value / max(1, n_gemm.value),

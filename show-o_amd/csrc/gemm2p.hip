@@ -316,8 +316,10 @@ int launch2p(const GemmArgs& g, hipStream_t s) {
 // Tile variants: code = rows (+ 1000 for the n-split phase program).
 //   m-split: 256 (8+8), 240 (8+7), 224 (7+7), 208 (7+6), 176 (6+5), 160 (5+5), 144 (5+4)
 //   n-split: 1192 (6+6), 1176 (6+5), 1160 (5+5), 1144 (5+4), 1128 (4+4)
-constexpr int N_VARIANTS = 12;
-const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128};
+//   m-split with a 3-deep weight ring (gemm3w.hip): 2256 (8+8), 2240 (8+7), 2224 (7+7), 2208 (7+6)
+//   n-split on the ring: 3192 (6+6), 3176 (6+5), 3160 (5+5), 3144 (5+4)
+constexpr int N_VARIANTS = 20;
+const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144};
 bool is_variant(int v) {
     for (int i = 0; i < N_VARIANTS; ++i)
         if (k_variants[i] == v) return true;
@@ -326,6 +328,7 @@ bool is_variant(int v) {
 
 template <int EPI>
 int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
+    if (h >= 2000) return gemm3w_launch(g, EPI, h - 2000, s);
     switch (h) {
         case 240: return launch2p<EPI, 8, 7, false>(g, s);
         case 224: return launch2p<EPI, 7, 7, false>(g, s);
@@ -366,7 +369,7 @@ int pick_bm(int M, int N) {
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
     }
     const int tilesN = (N + B2 - 1) / B2;
-    const int cand[8] = {256, 240, 224, 208, 1192, 1176, 1160, 1144};
+    const int cand[8] = {256, 240, 224, 208, 1192, 1176, 1160, 1144};  // (the ring variants are only chosen by measurement)
     long best_cost = -1;
     int best = 256;
     for (int c : cand) {
@@ -414,9 +417,12 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     // run on a GPU that is still ramping its clocks, and a single sample mis-ranks tiles that differ by ~10 %
     float cand_ms[N_VARIANTS];
     for (int ci = 0; ci < N_VARIANTS; ++ci) cand_ms[ci] = 1e30f;
+    static int ring_ok = -1;  // SHOWO_GEMM_RING=0 keeps the 3-deep-ring variants (gemm3w.hip) out of the tuner (A/B runs)
+    if (ring_ok < 0) { const char* e = getenv("SHOWO_GEMM_RING"); ring_ok = e ? (atoi(e) != 0) : 1; }
     for (int pass = 0; pass < 2; ++pass) {
         for (int ci = 0; ci < N_VARIANTS; ++ci) {
             const int h = k_variants[ci];
+            if (h >= 2000 && !ring_ok) continue;
             int rc = launch2p_h<EPI>(t, h, s);  // warm-up (instruction cache, attribute set)
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, h, s);

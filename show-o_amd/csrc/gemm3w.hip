@@ -1,0 +1,314 @@
+// gemm3w: the m-split 2-phase GEMM of gemm2p.hip with a THREE-deep LDS ring for the weight operand.
+//
+// Why: in gemm2p's m-split program the load segment of ph0 issues 6 of the 8 DMA pieces of a k-tile (all of W + A-lo) next to its
+// 16 ds_read_b128, ph1 only 2 (A-hi) next to 8 reads.  A DMA issue costs 100-185 cycles in such a segment (MI355X_MICROARCH.md,
+// "LDS-DMA piece issue cost"), so ph0's load segment (~1000 cycles) is twice as long as the partner group's 32-MFMA segment
+// (~544 cycles) it is supposed to hide behind, and every k-tile pays the difference twice.  With one more weight buffer the weight
+// pieces of tile T+2 can be issued in EITHER phase of tile T (their data is not needed before ph0 of T+2), which balances the two
+// load segments at 4 DMA pieces each and gives the weight stream -- the operand that comes cold from HBM in the 24-layer stack -- a
+// lead of 1.5 k-tiles instead of half a phase.
+//
+// LDS: W ring 3 x 32 KiB at 0 / 32 / 64 KiB, A double buffer 2 x 32 KiB at 96 / 128 KiB = 160 KiB (all of a CU's LDS).
+// Tile T reads W[T % 3] and A[T % 2].  Phase program (group 1 runs one barrier behind group 0, as in gemm2p):
+//   ph0(T): ds_read all W fragments + the 4 lo A fragments | DMA A-lo(T+1) (2 pieces), W rows 0..127 of tile T+2 (2) | vmcnt(6)
+//   ph1(T): ds_read the hi A fragments                     | DMA A-hi(T+1) (2),        W rows 128..255 of tile T+2 (2) | vmcnt(6)
+//   (A pieces are issued BEFORE the W pieces of the same phase: VMEM returns in order, so vmcnt(6) after the 4 new pieces retires
+//    everything up to and including the A pieces of the PREVIOUS phase and leaves that phase's 2 W pieces + these 4 in flight.)
+// Hazards:
+//   RAW  A-lo(T+1): issued ph0(T), retired by ph1(T)'s wait, read in ph0(T+1)  (2 barriers after every wave's wait)
+//        A-hi(T+1): issued ph1(T), retired by ph0(T+1)'s wait, read in ph1(T+1)
+//        W(T+2):    halves issued ph0(T) / ph1(T), retired by the waits of ph0(T+1) / ph1(T+1), read in ph0(T+2)
+//   WAR  W[(T+2) % 3] = W[(T-1) % 3] was last read in ph0(T-1): its reads retire at the head of that phase's MFMA segment, at least
+//        three barriers before any wave's ph0(T) DMA issue.  A: as in gemm2p (re-staged two phases after its last read).
+// The last two tiles issue fewer pieces; their waits fall back to vmcnt(0) (over-waiting is safe).
+// n-split form (NS = true, 8..12 fragments; gemm2p's balanced program for short tiles) on the same ring:
+//   ph0(T): ds_read W fragments 0,1 + ALL A fragments | DMA A(T+1) (NPW pieces)                       | no wait needed
+//   ph1(T): ds_read W fragments 2,3                   | DMA all of W(T+2) (4 pieces)                  | vmcnt(4)
+//   vmcnt(4) after the 4 new W pieces retires A(T+1) and every piece of W(T+1): both are read from ph0(T+1) on; W(T+2) has a
+//   full k-tile of lead.  WAR: W[(T+2) % 3] = W[(T-1) % 3] was last read in ph1(T-1), three barriers before ph1(T)'s issue.
+// K-concatenated A operand, tiled weights, XCD-aware tile order, epilogues: identical to gemm2p (gemm_common.h).
+#include "gemm_common.h"
+
+namespace showo {
+namespace {
+
+template <int EPI, int MF0, int MF1, bool NS>
+__global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
+    static_assert(NS ? (MF0 >= MF1 && MF1 >= 3 && MF0 <= 6) : (MF0 >= 5 && MF0 <= 8 && MF1 >= 4 && MF1 <= 8),
+                  "m-split: each group needs 4 lo fragments, group 0 at least one hi fragment; n-split: at most 6 fragments per group");
+    constexpr int BK = GEMM_BK;
+    constexpr int BMT = 16 * (MF0 + MF1);
+    constexpr int NA = 2 * (MF0 + MF1);
+    constexpr int NPW = (NA + 7) / 8;
+    constexpr int NAO = NS ? NPW : 4;
+    constexpr int NHI = NS ? 1 : 2 * (MF0 - 4) + 2 * (MF1 - 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int tn, tm;
+    {
+        const int per = g.gn * tilesM;
+        const int grp = bid / per, rem = bid - grp * per;
+        const int first = grp * g.gn;
+        const int gsz = min(tilesN - first, g.gn);
+        tm = rem / gsz;
+        tn = first + (rem - tm * gsz);
+    }
+    const int m0 = tm * BMT, n0 = tn * B2;
+    const int nk = g.K / BK;
+    const int wn = wave & 3, wm = wave >> 2;
+    const int gbase = wm * 16 * MF0;
+
+    const int srow = lane >> 3;
+    const int coff = ((lane & 7) ^ srow) << 3;
+    constexpr bool KC = (EPI == SHOWO_EPI_RESID_F32);
+    const int Ks = KC ? g.Ksplit : (1 << 30);
+    const int wks = g.wtiled ? 8 : 0;
+    const char* wbase = reinterpret_cast<const char*>(g.W) + (g.wtiled ? (size_t)tn * (size_t)(g.K / BK) * 32768 : (size_t)0);
+    const char* abase0 = reinterpret_cast<const char*>(g.A);
+    const char* abase1 = (KC && g.A2) ? reinterpret_cast<const char*>(g.A2) - (int64_t)Ks * 2 : abase0;
+    const int lda1 = (KC && g.A2) ? g.lda2 : g.lda;
+    constexpr int WBUF = 256 * 64;          // elements per W buffer (32 KiB)
+    constexpr int AOFF = 3 * WBUF;          // A buffers behind the W ring
+    uint32_t woff[2][2], aoff[KC ? 2 : 1][NAO];
+    int arowl[NAO], wrowl[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row;
+            if (NS) { const int q = wave * 2 + i; row = (q >> 2) * 64 + h * 32 + (q & 3) * 8; }  // half h = fragments 2h, 2h+1 of every wave column
+            else row = h * 128 + i * 64 + wave * 8;
+            wrowl[h][i] = row;
+            int n = n0 + row + srow;
+            n = n < g.N ? n : g.N - 1;
+            woff[h][i] = g.wtiled ? (uint32_t)(row * 128 + lane * 16) : (uint32_t)(((int64_t)n * g.ldw + coff) * 2);
+        }
+#pragma unroll
+    for (int j = 0; j < NAO; ++j) {
+        int row;
+        if (NS) { int p = wave + 8 * j; p = p < NA ? p : p % NA; row = 8 * p; }
+        else if (j < 2) row = j * 16 * MF0 + wave * 8;
+        else {
+            int p = wave + 8 * (j - 2);
+            p = p < NHI ? p : p % NHI;
+            row = p < 2 * (MF0 - 4) ? 64 + 8 * p : 16 * MF0 + 64 + 8 * (p - 2 * (MF0 - 4));
+        }
+        arowl[j] = row;
+        int m = m0 + row + srow;
+        m = m < g.M ? m : g.M - 1;
+        aoff[0][j] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
+        if (KC) aoff[KC ? 1 : 0][j] = (uint32_t)(((int64_t)m * lda1 + coff) * 2);
+    }
+    // W piece (H, i) of k-tile at element offset K0 into ring slot WB
+#define R_DMA_W(WB, H, K0)                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                              \
+        glds16(reinterpret_cast<const bf16_t*>(wbase + (((size_t)(K0) * 2) << wks) + (size_t)woff[H][i_]),       \
+               smem + (WB) * WBUF + wrowl[H][i_] * 64)
+#define R_DMA_A(AB, J0, J1, K0)                                                                                   \
+    do {                                                                                                          \
+        const bool s1_ = KC && (K0) >= Ks;                                                                        \
+        const char* ab_ = (s1_ ? abase1 : abase0) + (size_t)(K0) * 2;                                             \
+        _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_)                                                    \
+            glds16(reinterpret_cast<const bf16_t*>(ab_ + (size_t)(s1_ ? aoff[KC ? 1 : 0][j_] : aoff[0][j_])),     \
+                   smem + AOFF + (AB) * WBUF + arowl[j_] * 64);                                                   \
+    } while (0)
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int lsw0 = fr * 64 + ((fg ^ (fr & 7)) << 3);
+    const int lsw1 = fr * 64 + (((fg + 4) ^ (fr & 7)) << 3);
+    const bf16_t* ldsW = smem + (wn * 64) * 64;
+    const bf16_t* ldsA = smem + AOFF + gbase * 64;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NAF = NS ? MF0 : 4;
+    bf16x8 wf[2][4], af[2][NAF];
+
+#define R_READ_W(WB)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        wf[0][i] = *reinterpret_cast<const bf16x8*>(ldsW + (WB) * WBUF + i * 16 * 64 + lsw0);                     \
+        wf[1][i] = *reinterpret_cast<const bf16x8*>(ldsW + (WB) * WBUF + i * 16 * 64 + lsw1);                     \
+    }
+#define R_READ_A(AB, MB, CNT)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < (CNT); ++j) {                                                           \
+        af[0][j] = *reinterpret_cast<const bf16x8*>(ldsA + (AB) * WBUF + ((MB) + j) * 16 * 64 + lsw0);            \
+        af[1][j] = *reinterpret_cast<const bf16x8*>(ldsA + (AB) * WBUF + ((MB) + j) * 16 * 64 + lsw1);            \
+    }
+#define R_MFMA(MB, CNT)                                                                                           \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < (CNT); ++j)                                                 \
+                    acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[kk][j], acc[i][(MB) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+#define R_READ_W2(WB, I0)                                                                                         \
+    _Pragma("unroll") for (int i = (I0); i < (I0) + 2; ++i) {                                                     \
+        wf[0][i] = *reinterpret_cast<const bf16x8*>(ldsW + (WB) * WBUF + i * 16 * 64 + lsw0);                     \
+        wf[1][i] = *reinterpret_cast<const bf16x8*>(ldsW + (WB) * WBUF + i * 16 * 64 + lsw1);                     \
+    }
+#define R_MFMA_N(I0, CNT)                                                                                         \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+            _Pragma("unroll") for (int i = (I0); i < (I0) + 2; ++i)                                               \
+                _Pragma("unroll") for (int j = 0; j < (CNT); ++j)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+#define R_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+    // n-split k-tile on the ring
+#define RN_TILE(WB, AB, T, MFG)                                                                                   \
+    do {                                                                                                          \
+        const int kA = ((T) + 1) * BK, kW = ((T) + 2) * BK;                                                       \
+        const bool hasA = (T) + 1 < nk, hasW = (T) + 2 < nk;                                                      \
+        /* ph0 */                                                                                                 \
+        R_READ_W2(WB, 0)                                                                                          \
+        R_READ_A(AB, 0, MFG)                                                                                      \
+        if (hasA) R_DMA_A((AB) ^ 1, 0, NPW, kA);                                                                  \
+        bar_raw_fn();                                                                                             \
+        R_MFMA_N(0, MFG);                                                                                         \
+        bar_raw_fn();                                                                                             \
+        /* ph1 */                                                                                                 \
+        R_READ_W2(WB, 2)                                                                                          \
+        if (hasW) { R_DMA_W(((WB) + 2) % 3, 0, kW); R_DMA_W(((WB) + 2) % 3, 1, kW); R_WAIT(4); } else { R_WAIT(0); } \
+        bar_raw_fn();                                                                                             \
+        R_MFMA_N(2, MFG);                                                                                         \
+        bar_raw_fn();                                                                                             \
+    } while (0)
+    // one k-tile: ring slot WB = T % 3, A buffer AB = T % 2 (literals)
+#define R_TILE(WB, AB, T, MFG)                                                                                    \
+    do {                                                                                                          \
+        const int kA = ((T) + 1) * BK, kW = ((T) + 2) * BK;                                                       \
+        const bool hasA = (T) + 1 < nk, hasW = (T) + 2 < nk;                                                      \
+        /* ph0 */                                                                                                 \
+        R_READ_W(WB)                                                                                              \
+        R_READ_A(AB, 0, 4)                                                                                        \
+        if (hasA) R_DMA_A((AB) ^ 1, 0, 2, kA);                                                                    \
+        if (hasW) { R_DMA_W(((WB) + 2) % 3, 0, kW); R_WAIT(6); } else { R_WAIT(0); }                              \
+        bar_raw_fn();                                                                                             \
+        R_MFMA(0, 4);                                                                                             \
+        bar_raw_fn();                                                                                             \
+        /* ph1 */                                                                                                 \
+        R_READ_A(AB, 4, NS ? 0 : (MFG) - 4)                                                                       \
+        if (hasA) R_DMA_A((AB) ^ 1, 2, 4, kA);                                                                    \
+        if (hasW) { R_DMA_W(((WB) + 2) % 3, 1, kW); R_WAIT(6); } else { R_WAIT(0); }                              \
+        bar_raw_fn();                                                                                             \
+        R_MFMA(4, NS ? 0 : (MFG) - 4);                                                                            \
+        bar_raw_fn();                                                                                             \
+    } while (0)
+
+    // ---- prologue: all of tile 0 and the weights of tile 1 (the latter may still be in flight: retired by ph1(0)'s wait)
+    R_DMA_W(0, 0, 0);
+    R_DMA_W(0, 1, 0);
+    R_DMA_A(0, 0, NAO, 0);
+    if (nk > 1) {
+        R_DMA_W(1, 0, BK);
+        R_DMA_W(1, 1, BK);
+        R_WAIT(4);
+    } else {
+        R_WAIT(0);
+    }
+    bar_raw_fn();
+    if (wm == 1) bar_raw_fn();  // group 1 runs one barrier behind group 0
+
+#define R_ANY(WB, AB, T, MFG) do { if constexpr (NS) { RN_TILE(WB, AB, T, MFG); } else { R_TILE(WB, AB, T, MFG); } } while (0)
+#define R_RUN(MFG)                                                                                                \
+    do {                                                                                                          \
+        int t = 0;                                                                                                \
+        for (; t + 5 < nk; t += 6) {                                                                              \
+            R_ANY(0, 0, t, MFG);                                                                                  \
+            R_ANY(1, 1, t + 1, MFG);                                                                              \
+            R_ANY(2, 0, t + 2, MFG);                                                                              \
+            R_ANY(0, 1, t + 3, MFG);                                                                              \
+            R_ANY(1, 0, t + 4, MFG);                                                                              \
+            R_ANY(2, 1, t + 5, MFG);                                                                              \
+        }                                                                                                         \
+        if (t < nk) R_ANY(0, 0, t, MFG);                                                                          \
+        if (t + 1 < nk) R_ANY(1, 1, t + 1, MFG);                                                                  \
+        if (t + 2 < nk) R_ANY(2, 0, t + 2, MFG);                                                                  \
+        if (t + 3 < nk) R_ANY(0, 1, t + 3, MFG);                                                                  \
+        if (t + 4 < nk) R_ANY(1, 0, t + 4, MFG);                                                                  \
+    } while (0)
+    if (MF0 == MF1 || wm == 0) {
+        R_RUN(MF0);
+        if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
+        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg);
+    } else {
+        R_RUN(MF1);
+        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg);
+    }
+#undef R_RUN
+#undef R_ANY
+#undef RN_TILE
+#undef R_MFMA_N
+#undef R_READ_W2
+#undef R_TILE
+#undef R_WAIT
+#undef R_MFMA
+#undef R_READ_A
+#undef R_READ_W
+#undef R_DMA_A
+#undef R_DMA_W
+}
+
+constexpr int SMEM3W_BYTES = 5 * 256 * 64 * 2;  // 160 KiB
+
+template <int EPI, int MF0, int MF1, bool NS>
+int launch3w(const GemmArgs& g, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = gemm3w_kernel<EPI, MF0, MF1, NS>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3W_BYTES);
+        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm3w)", __FILE__, __LINE__);
+        attr_set = true;
+    }
+    constexpr int BMT = 16 * (MF0 + MF1);
+    int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
+    kfn<<<dim3(tilesM * tilesN), dim3(512), SMEM3W_BYTES, s>>>(g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "gemm3w launch", __FILE__, __LINE__);
+    return 0;
+}
+
+template <int EPI>
+int launch3w_h(const GemmArgs& g, int rows, hipStream_t s) {
+    switch (rows) {
+        case 240: return launch3w<EPI, 8, 7, false>(g, s);
+        case 224: return launch3w<EPI, 7, 7, false>(g, s);
+        case 208: return launch3w<EPI, 7, 6, false>(g, s);
+        case 1192: return launch3w<EPI, 6, 6, true>(g, s);
+        case 1176: return launch3w<EPI, 6, 5, true>(g, s);
+        case 1160: return launch3w<EPI, 5, 5, true>(g, s);
+        case 1144: return launch3w<EPI, 5, 4, true>(g, s);
+    }
+    return launch3w<EPI, 8, 8, false>(g, s);
+}
+
+}  // namespace
+
+// variant codes 2256 / 2240 / 2224 / 2208 (m-split) and 3192 / 3176 / 3160 / 3144 (n-split) of gemm2p's tile table
+int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s) {
+    switch (epilogue) {
+        case SHOWO_EPI_BF16: return launch3w_h<SHOWO_EPI_BF16>(g, rows, s);
+        case SHOWO_EPI_GELU_BF16: return launch3w_h<SHOWO_EPI_GELU_BF16>(g, rows, s);
+        case SHOWO_EPI_F32: return launch3w_h<SHOWO_EPI_F32>(g, rows, s);
+        case SHOWO_EPI_RESID_F32: return launch3w_h<SHOWO_EPI_RESID_F32>(g, rows, s);
+        case EPI_QKV: return launch3w_h<EPI_QKV>(g, rows, s);
+    }
+    return set_error_msg(1, "gemm3w: unknown epilogue");
+}
+
+}  // namespace showo

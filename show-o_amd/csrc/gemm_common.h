@@ -222,5 +222,7 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 // production kernel (gemm2p.hip)
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf;
+// m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
+int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);
 
 }  // namespace showo

@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         std::vector<float> r0((size_t)Mx * H), r1((size_t)Mx * H);
         CK(hipMemcpy(r0.data(), x0, r0.size() * 4, hipMemcpyDeviceToHost));
-        const int vars[] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128};
+        const int vars[] = {240, 2240, 208, 2208, 1192, 3192, 1176, 3176, 1160, 3160, 1144, 3144};
         uint16_t* WcatT; CK(hipMalloc(&WcatT, (size_t)RW * showo_gemm_tiled_elems(H, H + F) * 2));
         for (int r = 0; r < RW; ++r) RC(showo_gemm_tile_weight(Wcat, H + F, H, H + F, WcatT + (size_t)r * showo_gemm_tiled_elems(H, H + F), st));
         for (int tl : {0, 1}) {
