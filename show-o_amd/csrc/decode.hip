@@ -141,11 +141,17 @@ struct OutGemvArgs {
     const float* b1;
     int K1;
     int N;
+    float* y2;          // [N] fp32: fc2 + b2 of the forked layer (MODE 1 writes it, MODE 2 adds it)
 };
 
 // C = 2048-element chunks per output column (dense chunks first, then fc2 chunks), ALL of them in flight per wave: a wave
 // streams 20 KB per column at the real shape and only 8 waves per CU exist, so depth is what hides the HBM latency.
-template <int C>
+// MODE 0: x[n] = (x[n] + (dense + bd)) + (fc2 + b2) in one launch.  The forked decode layer (engine.hip) splits it so that fc2 --
+// which does not depend on the attention -- streams its 33.5 MB of weights WHILE the attention kernel runs:
+//   MODE 1 (K0 = 0): y2[n] = fc2 + b2            (side stream, next to the attention kernel)
+//   MODE 2 (K1 = 0): x[n] = (x[n] + (dense + bd)) + y2[n]   (after the join)
+// Same lane split, accumulation order and parenthesisation in every mode: the three forms agree bit for bit.
+template <int C, int MODE>
 __global__ __launch_bounds__(512) void out_gemv2_kernel(OutGemvArgs g) {
     extern __shared__ bf16_t sa[];  // [K0] attention row, [K1] gelu(fc1) row: read once per block instead of once per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -178,11 +184,15 @@ __global__ __launch_bounds__(512) void out_gemv2_kernel(OutGemvArgs g) {
         acc0 = wave_sum(acc0);
         acc1 = wave_sum(acc1);
         if (lane == 0) {
-            float v = acc0 + g.b0[n];   // x1 = x + (dense + bd)         (RESID epilogue order of gemv_kernel)
-            v += g.x[n];
-            float v2 = acc1 + g.b1[n];  // x2 = x1 + (fc2 + b2)
-            v2 += v;
-            g.x[n] = v2;
+            if (MODE == 1) {
+                g.y2[n] = acc1 + g.b1[n];
+            } else {
+                float v = acc0 + g.b0[n];   // x1 = x + (dense + bd)         (RESID epilogue order of gemv_kernel)
+                v += g.x[n];
+                float v2 = MODE == 2 ? g.y2[n] : acc1 + g.b1[n];  // x2 = x1 + (fc2 + b2)
+                v2 += v;
+                g.x[n] = v2;
+            }
         }
         n = nn;
     }
@@ -211,16 +221,23 @@ int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float ep
 
 // x[n] += (W0[n,:] a0 + b0[n]);  x[n] += (W1[n,:] a1 + b1[n])
 int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* b0, int K0, const bf16_t* W1, const bf16_t* a1,
-                     const float* b1, int K1, int N, hipStream_t s) {
-    OutGemvArgs g{x, W0, a0, b0, K0, W1, a1, b1, K1, N};
-    const int C = (K0 + 2047) / 2048 + (K1 + 2047) / 2048;
+                     const float* b1, int K1, int N, hipStream_t s, int mode, float* y2) {
+    OutGemvArgs g{x, W0, a0, b0, K0, W1, a1, b1, K1, N, y2};
+    if (mode == 1) g.K0 = 0;
+    if (mode == 2) g.K1 = 0;
+    if (mode && !y2) return set_error_msg(1, "decode_out_gemv2: y2 required");
+    const int C = (g.K0 + 2047) / 2048 + (g.K1 + 2047) / 2048;
     const dim3 grid(pick_blocks(N, 8, 256));
-    const size_t smem = (size_t)(K0 + K1) * sizeof(bf16_t);
-    switch (C) {
-        case 2: out_gemv2_kernel<2><<<grid, dim3(512), smem, s>>>(g); break;
-        case 3: out_gemv2_kernel<3><<<grid, dim3(512), smem, s>>>(g); break;
-        case 4: out_gemv2_kernel<4><<<grid, dim3(512), smem, s>>>(g); break;
-        case 5: out_gemv2_kernel<5><<<grid, dim3(512), smem, s>>>(g); break;
+    const size_t smem = (size_t)(g.K0 + g.K1) * sizeof(bf16_t);
+    if (mode == 1 && C == 4) out_gemv2_kernel<4, 1><<<grid, dim3(512), smem, s>>>(g);
+    else if (mode == 1 && C >= 1 && C <= 3) out_gemv2_kernel<3, 1><<<grid, dim3(512), smem, s>>>(g);
+    else if (mode == 2 && C == 1) out_gemv2_kernel<1, 2><<<grid, dim3(512), smem, s>>>(g);
+    else if (mode != 0) return set_error_msg(1, "decode_out_gemv2: unsupported K0/K1 for the forked layer");
+    else switch (C) {
+        case 2: out_gemv2_kernel<2, 0><<<grid, dim3(512), smem, s>>>(g); break;
+        case 3: out_gemv2_kernel<3, 0><<<grid, dim3(512), smem, s>>>(g); break;
+        case 4: out_gemv2_kernel<4, 0><<<grid, dim3(512), smem, s>>>(g); break;
+        case 5: out_gemv2_kernel<5, 0><<<grid, dim3(512), smem, s>>>(g); break;
         default: return set_error_msg(1, "decode_out_gemv2: unsupported K0/K1 (decode_fused_shapes_ok)");
     }
     hipError_t e = hipGetLastError();

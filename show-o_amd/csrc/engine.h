@@ -31,7 +31,7 @@ bool decode_fused_shapes_ok(int H, int F);
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
                     bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s);
 int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* b0, int K0, const bf16_t* W1, const bf16_t* a1,
-                     const float* b1, int K1, int N, hipStream_t s);
+                     const float* b1, int K1, int N, hipStream_t s, int mode = 0, float* y2 = nullptr);
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s);
@@ -86,6 +86,7 @@ struct showo_engine {
     // second stream for the two independent branches of a Phi block (attention branch | fc1): see run_layers
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fc1 = nullptr;
+    float* y2 = nullptr;  // forked decode layer: fc2 + b2 of the current layer
     // hipGraph replay of the denoise step: the instantiated graph of one active-rows step is cached, keyed by everything baked
     // into its launches (shapes, scalars, every pointer that is not engine-owned-and-fixed)
     struct T2IGraphKey {

@@ -320,16 +320,50 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
     const int Lk = pos0 + L;
     const int Lcap = kv.Lcap, Lp = kv.Lp;
     if (T == 1 && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
-        // AR decode step: three launches per layer (decode.hip)
+        // AR decode step (decode.hip): three launches per layer.  Forked layer (opt-in, SHOWO_DECODE_FORK=1; measured SLOWER: 705-711 vs
+        // 843-846 tokens/s in one box, gpurun_out/bench_mmu_r2k_*: every fork / join edge of the per-token graph costs more than the
+        // overlap buys, like the side-stream weight prefetch of round 1): fc1 and fc2 do not depend on the attention, so their 67 MB
+        // of weights can stream on a second stream while the latency-bound single-query attention (32 blocks on 256 CUs) runs:
+        //   s:    LN + qkv GEMV ------> attention (prep + cache append + softmax) ----join--> dense GEMV + both residual adds
+        //   side:                  \--> LN + fc1 GEMV + GELU --> fc2 GEMV (-> y2) --------/
+        // Same arithmetic and parenthesisation as the chain (x = (x + (dense + bd)) + (fc2 + b2)): bit-identical results.
+        static int fork_on = -1;
+        if (fork_on < 0) { const char* env = getenv("SHOWO_DECODE_FORK"); fork_on = env ? (atoi(env) != 0) : 0; }
+        bool fork = fork_on != 0;
+        if (fork && !e->side) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            hipStreamIsCapturing(s, &cs);
+            if (cs != hipStreamCaptureStatusNone) fork = false;  // never create the stream inside a capture
+            else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_fc1, hipEventDisableTiming) != hipSuccess)
+                return set_error_msg(7, "engine: cannot create the side stream");
+        }
+        if (fork && !e->y2) TRY(e->alloc(&e->y2, H));
         for (int li = 0; li < e->nL; ++li) {
             showo::Layer& l = e->layers[li];
             bf16_t* Kd = kv.k + li * kv.k_lstride;
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
-            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
-                                       e->ffn, F, s));
+            if (!fork) {
+                TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
+                                           e->ffn, F, s));
+                TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
+                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s));
+                continue;
+            }
+            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));  // x of this layer is final
+            SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, nullptr, nullptr,
+                                       nullptr, 0, s));
+            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, nullptr, nullptr, nullptr, nullptr, 0, l.w1, l.b1, e->ffn, F,
+                                       e->side));
+            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, e->side, 1, e->y2));
+            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
             TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
                                          e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
-            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s));
+            SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
+            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2));
         }
         return 0;
     }
