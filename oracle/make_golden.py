@@ -576,6 +576,7 @@ def make_tiny_inpaint():
     np.savez_compressed(os.path.join(GOLD, "showo_tiny_inpaint.npz"), ids_cond=ids_c0.numpy(), ids_uncond=ids_u.numpy(),
                         mask=mask.numpy().astype(np.float32), steps=steps, guidance=w, num_vq_tokens=64, hole=grid.reshape(-1),
                         exp_noise=torch.stack(rec["exp"]).numpy().astype(np.float32), uniform=torch.stack(rec["uni"]).numpy(),
+                        fwd_in=torch.stack(rec["fwd_in"]).numpy(), multinomial=torch.stack(rec["multi"]).numpy(),
                         result=res.numpy(), final_input_ids=ids_run.numpy())
 
 

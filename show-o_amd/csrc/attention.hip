@@ -305,10 +305,13 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
-template <bool DENSE>
+// WPB = waves (32-row query tiles) per block: 4, or 5 when that saves a block per (batch, head) -- at Lq = 258 (the 18-step t2i
+// loop: <soi> + 256 image tokens + <eoi>) the ninth query tile would otherwise get a block of its own that streams every K / V^T
+// tile for 2 rows.  Waves 0..3 stage the tiles; a fifth wave only consumes them.
+template <bool DENSE, int WPB>
 __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int* s_hull) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qblk = blockIdx.x * 4 + wave;
+    const int qblk = blockIdx.x * WPB + wave;
     const bool wactive = qblk * 32 < a.Lq;
     const int head = blockIdx.y, b = blockIdx.z;
     const int qi = lane & 31, hh = lane >> 5;
@@ -338,10 +341,11 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     // key hull of the wave and of the block
     const int wmin = wave_min_i(min(lo1 < hi1 ? lo1 : 0x7fffffff, lo2 < hi2 ? lo2 : 0x7fffffff));
     const int wmax = wave_max_i(max(lo1 < hi1 ? hi1 : 0, lo2 < hi2 ? hi2 : 0));
-    if (lane == 0) { s_hull[wave] = wmin; s_hull[4 + wave] = wmax; }
+    if (lane == 0) { s_hull[wave] = wmin; s_hull[WPB + wave] = wmax; }
     __syncthreads();
-    const int bmin = min(min(s_hull[0], s_hull[1]), min(s_hull[2], s_hull[3]));
-    const int bmax = max(max(s_hull[4], s_hull[5]), max(s_hull[6], s_hull[7]));
+    int bmin = s_hull[0], bmax = s_hull[WPB];
+#pragma unroll
+    for (int w = 1; w < WPB; ++w) { bmin = min(bmin, s_hull[w]); bmax = max(bmax, s_hull[WPB + w]); }
     const float* drow = dense ? a.dense + ((int64_t)b * a.Lq + qrow) * a.Lk : nullptr;
 
     // ---- staging by DMA (global_load_lds, 16 B/lane, no VGPR round trip).  One wave-instruction fills 8 rows x 128 B
@@ -354,7 +358,7 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     int64_t voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int r = 8 * (wave + 4 * i) + prow;
+        const int r = 8 * ((wave & 3) + 4 * i) + prow;
         const int f = (r >> 1) & 7;
         const int blk = (r >> 2) & 3;
         pik[i] = (r & ~15) + 4 * (((blk & 1) << 1) | (blk >> 1)) + (r & 3);
@@ -362,7 +366,7 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
         voff[i] = (int64_t)r * a.Lp + kch[i];
     }
 #define AT_STAGE(KT, BUF)                                                                              \
-    do {                                                                                               \
+    if (WPB == 4 || wave < 4) {                                                                        \
         bf16_t* sK_ = sm + (BUF) * 2 * AT_TILE;                                                        \
         bf16_t* sV_ = sK_ + AT_TILE;                                                                   \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
@@ -371,7 +375,7 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             glds16(Kg + (int64_t)key_ * 64 + kch[i], sK_ + (wave + 4 * i) * 512);                      \
             glds16(Vg + voff[i] + (KT), sV_ + (wave + 4 * i) * 512);                                   \
         }                                                                                              \
-    } while (0)
+    }
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 o0, o1;
@@ -480,13 +484,13 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
 }
 
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
+template <int MINW, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sm[4 * AT_TILE];  // [buf][K | Vt]
-    __shared__ int s_hull[8];
+    __shared__ int s_hull[2 * WPB];
     const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);  // block-uniform
-    if (dense) attn_lds_body<true>(a, sm, s_hull);
-    else attn_lds_body<false>(a, sm, s_hull);
+    if (dense) attn_lds_body<true, WPB>(a, sm, s_hull);
+    else attn_lds_body<false, WPB>(a, sm, s_hull);
 }
 
 }  // namespace
@@ -700,6 +704,9 @@ extern "C" int showo_attn_set_impl(int impl) {
     return 0;
 }
 
+static int g_attn_wpb5 = -1;  // SHOWO_ATTN_WPB5=1: five query tiles per block where that saves a block per (b, head).  Opt-in: measured
+                              // SLOWER in one box (attention 214-217 vs 286-294 TF/s, 32.0 vs 33.1 images/s): the fifth wave shares a SIMD
+
 static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                          const float* dense_mask, uint16_t* O, float* lse, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                          void* stream) {
@@ -712,6 +719,7 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
     int qblocks = (Lq + 31) / 32;
     ProfScope prof(PROF_ATTN, 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // dense QK^T + PV flops
     if (g_attn_forced < 0) { const char* e = getenv("SHOWO_ATTN_IMPL"); g_attn_forced = e ? atoi(e) : 0; }
+    if (g_attn_wpb5 < 0) { const char* e = getenv("SHOWO_ATTN_WPB5"); g_attn_wpb5 = e ? (atoi(e) != 0) : 0; }
     const int forced = g_attn_forced;  // 1 = gather form, 2 = LDS-tiled form, else by shape
     const bool tiled = lse != nullptr || forced >= 2 || (forced != 1 && Lq >= 64);  // only the tiled form writes lse  // decode steps (a few query rows) keep the gather form
     if (Lq == 1 && forced != 1 && !lse) {  // AR decode step
@@ -724,6 +732,8 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
         }
     }
     if (tiled && forced == 3) attn_fwd_lds_kernel<3><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    else if (tiled && (qblocks + 4) / 5 < (qblocks + 3) / 4 && g_attn_wpb5)  // five query tiles per block save a block per (b, head)
+        attn_fwd_lds_kernel<3, 5><<<dim3((qblocks + 4) / 5, nH, B), dim3(320), 0, (hipStream_t)stream>>>(a);
     else if (tiled) attn_fwd_lds_kernel<4><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     else attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
