@@ -716,7 +716,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs g) {
         if (blockIdx.x == 0 && g.dbg) g.dbg[tid] = dbgl[lane];
     }
 
-    epilogue8p<EPI, 8>(g, acc, n0, wn, m0 + wm * 128, fr, fg);
+    epilogue8p<EPI, 8>(g, acc, n0, wn, m0 + wm * 128, fr, fg, nullptr);
 #undef bar_raw
 #undef P3_TILE
 #undef P2_TILE
@@ -898,6 +898,8 @@ extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
     g_gemm_bm = (flags >> 8) ? (flags >> 8) : -1;  // impl 5: tile variant code (0 = automatic)
     if (flags & 2) g_gemm_pf = 1;       // impl 5: L2 prefetch of the weight panel on ...
     else if (flags & 4) g_gemm_pf = 0;  // ... off; neither bit: unchanged (SHOWO_GEMM_PF, default off)
+    if (flags & 8) g_gemm_stage = 0;    // impl 5: bf16 epilogue stores direct (8) or staged through LDS (16); neither: unchanged
+    else if (flags & 16) g_gemm_stage = 1;
     return 0;
 }
 

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     }
     const int m0 = tm * BMT, n0 = tn * B2;
     const int nk = g.K / BK;
+    const bool g_stage = !(g.flags & 8);  // bf16 epilogues store through LDS (full 128-B lines); flags bit 3 = direct stores (A/B)
     const int wn = wave & 3, wm = wave >> 2;
     const int gbase = wm * 16 * MF0;  // first tile row of this wave's group
 
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     if (MF0 == MF1 || wm == 0) {
         Q2_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg);
+        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         Q2_RUN(MF1);
-        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg);
+        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef Q2_RUN
     asm volatile("" ::"v"(pfreg));  // keeps the prefetch destination register reserved for the whole loop
@@ -318,8 +319,10 @@ int launch2p(const GemmArgs& g, hipStream_t s) {
 //   n-split: 1192 (6+6), 1176 (6+5), 1160 (5+5), 1144 (5+4), 1128 (4+4)
 //   m-split with a 3-deep weight ring (gemm3w.hip): 2256 (8+8), 2240 (8+7), 2224 (7+7), 2208 (7+6)
 //   n-split on the ring: 3192 (6+6), 3176 (6+5), 3160 (5+5), 3144 (5+4)
-constexpr int N_VARIANTS = 20;
-const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144};
+//   the same with buffer-descriptor DMAs: 4192, 4176, 4160, 4144
+constexpr int N_VARIANTS = 24;
+const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144,
+                                    4192, 4176, 4160, 4144};
 bool is_variant(int v) {
     for (int i = 0; i < N_VARIANTS; ++i)
         if (k_variants[i] == v) return true;
@@ -349,6 +352,7 @@ int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
 
 int g_gemm_gn = 4;  // n-panels per XCD tile group (same-process sweep on the bench workload: 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s)
 int g_gemm_bm = 0;  // 0 = read SHOWO_GEMM_BM once; -1 = choose per shape; a variant code = force it
+int g_gemm_stage = -1;  // bf16 epilogue stores staged through LDS: -1 = read SHOWO_GEMM_STAGE once (default on), 0 / 1 = forced
 int g_gemm_pf = -1; // L2 prefetch of the weight panel: -1 = read SHOWO_GEMM_PF once (default OFF: measured -3...-8 % in the harness
                     // with cold weights and within noise in the pipeline, profiles/r2_gemm_harness.txt), 0 / 1 = forced (showo_gemm_tune)
 
@@ -469,7 +473,8 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
     g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
     if (g_gemm_pf < 0) { const char* e = getenv("SHOWO_GEMM_PF"); g_gemm_pf = e ? (atoi(e) != 0) : 0; }
-    g.flags = g_gemm_pf ? 2 : 0;
+    if (g_gemm_stage < 0) { const char* e = getenv("SHOWO_GEMM_STAGE"); g_gemm_stage = e ? atoi(e) : 1; }
+    g.flags = (g_gemm_pf ? 2 : 0) | (g_gemm_stage ? 0 : 8) | (g_gemm_stage == 2 ? 32 : 0);  // SHOWO_GEMM_STAGE: 0 direct stores, 1 (default) staged except Q / K, 2 all
     g.dbg = nullptr;
     switch (epilogue) {
         case SHOWO_EPI_BF16: return launch2p_bm<SHOWO_EPI_BF16>(g, s);

@@ -32,7 +32,14 @@
 namespace showo {
 namespace {
 
-template <int EPI, int MF0, int MF1, bool NS>
+// BL: the DMAs are `buffer_load_dwordx4 ... offen lds` through wave-uniform buffer descriptors (operand base in SGPRs, the
+// per-lane 32-bit offset as voffset, the k advance as soffset): no 64-bit address VALU per DMA (three v_lshl_add_u64 each with
+// global_load_lds) -- the load segment is the critical path of the phase program.
+__device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, bf16_t* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+template <int EPI, int MF0, int MF1, bool NS, bool BL>
 __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
     static_assert(NS ? (MF0 >= MF1 && MF1 >= 3 && MF0 <= 6) : (MF0 >= 5 && MF0 <= 8 && MF1 >= 4 && MF1 <= 8),
                   "m-split: each group needs 4 lo fragments, group 0 at least one hi fragment; n-split: at most 6 fragments per group");
@@ -63,6 +70,7 @@ __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
     }
     const int m0 = tm * BMT, n0 = tn * B2;
     const int nk = g.K / BK;
+    const bool g_stage = !(g.flags & 8);  // bf16 epilogues store through LDS (full 128-B lines); flags bit 3 = direct stores (A/B)
     const int wn = wave & 3, wm = wave >> 2;
     const int gbase = wm * 16 * MF0;
 
@@ -107,18 +115,26 @@ __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
         aoff[0][j] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
         if (KC) aoff[KC ? 1 : 0][j] = (uint32_t)(((int64_t)m * lda1 + coff) * 2);
     }
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase1), 0, -1, 0x00020000);
     // W piece (H, i) of k-tile at element offset K0 into ring slot WB
 #define R_DMA_W(WB, H, K0)                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                              \
-        glds16(reinterpret_cast<const bf16_t*>(wbase + (((size_t)(K0) * 2) << wks) + (size_t)woff[H][i_]),       \
-               smem + (WB) * WBUF + wrowl[H][i_] * 64)
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
+        if constexpr (BL) bufl16(rsW, woff[H][i_], (uint32_t)(((K0) * 2) << wks), smem + (WB) * WBUF + wrowl[H][i_] * 64); \
+        else glds16(reinterpret_cast<const bf16_t*>(wbase + (((size_t)(K0) * 2) << wks) + (size_t)woff[H][i_]),  \
+                    smem + (WB) * WBUF + wrowl[H][i_] * 64);                                                      \
+    }
 #define R_DMA_A(AB, J0, J1, K0)                                                                                   \
     do {                                                                                                          \
         const bool s1_ = KC && (K0) >= Ks;                                                                        \
         const char* ab_ = (s1_ ? abase1 : abase0) + (size_t)(K0) * 2;                                             \
-        _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_)                                                    \
-            glds16(reinterpret_cast<const bf16_t*>(ab_ + (size_t)(s1_ ? aoff[KC ? 1 : 0][j_] : aoff[0][j_])),     \
-                   smem + AOFF + (AB) * WBUF + arowl[j_] * 64);                                                   \
+        _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) {                                                  \
+            if constexpr (BL) bufl16(s1_ ? rsA1 : rsA0, s1_ ? aoff[KC ? 1 : 0][j_] : aoff[0][j_], (uint32_t)((K0) * 2), \
+                                     smem + AOFF + (AB) * WBUF + arowl[j_] * 64);                                 \
+            else glds16(reinterpret_cast<const bf16_t*>(ab_ + (size_t)(s1_ ? aoff[KC ? 1 : 0][j_] : aoff[0][j_])), \
+                        smem + AOFF + (AB) * WBUF + arowl[j_] * 64);                                              \
+        }                                                                                                         \
     } while (0)
 
     const int fr = lane & 15, fg = lane >> 4;
@@ -245,10 +261,10 @@ __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
     if (MF0 == MF1 || wm == 0) {
         R_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg);
+        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         R_RUN(MF1);
-        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg);
+        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef R_RUN
 #undef R_ANY
@@ -266,10 +282,10 @@ __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
 
 constexpr int SMEM3W_BYTES = 5 * 256 * 64 * 2;  // 160 KiB
 
-template <int EPI, int MF0, int MF1, bool NS>
+template <int EPI, int MF0, int MF1, bool NS, bool BL = false>
 int launch3w(const GemmArgs& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm3w_kernel<EPI, MF0, MF1, NS>;
+    auto kfn = gemm3w_kernel<EPI, MF0, MF1, NS, BL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3W_BYTES);
         if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm3w)", __FILE__, __LINE__);
@@ -293,13 +309,18 @@ int launch3w_h(const GemmArgs& g, int rows, hipStream_t s) {
         case 1176: return launch3w<EPI, 6, 5, true>(g, s);
         case 1160: return launch3w<EPI, 5, 5, true>(g, s);
         case 1144: return launch3w<EPI, 5, 4, true>(g, s);
+        case 2192: return launch3w<EPI, 6, 6, true, true>(g, s);   // 4xxx: n-split on the ring with buffer-descriptor DMAs
+        case 2176: return launch3w<EPI, 6, 5, true, true>(g, s);
+        case 2160: return launch3w<EPI, 5, 5, true, true>(g, s);
+        case 2144: return launch3w<EPI, 5, 4, true, true>(g, s);
     }
     return launch3w<EPI, 8, 8, false>(g, s);
 }
 
 }  // namespace
 
-// variant codes 2256 / 2240 / 2224 / 2208 (m-split) and 3192 / 3176 / 3160 / 3144 (n-split) of gemm2p's tile table
+// variant codes 2256 / 2240 / 2224 / 2208 (m-split), 3192 / 3176 / 3160 / 3144 (n-split) and 4192 / 4176 / 4160 / 4144 (n-split,
+// buffer-descriptor DMAs) of gemm2p's tile table
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s) {
     switch (epilogue) {
         case SHOWO_EPI_BF16: return launch3w_h<SHOWO_EPI_BF16>(g, rows, s);

@@ -102,16 +102,38 @@ static __device__ __forceinline__ void bar_raw_fn() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- coalesced epilogue stores through LDS (bf16 outputs).  An MFMA C fragment leaves a lane with 4 consecutive columns of ONE row:
+// stored directly, a wave instruction writes 16 rows x 32 B (8-byte stores, every 128-B line in four separate instructions) and the
+// store tail of a tile is issue-bound (~7 us for the 24-32 dwordx2 per lane of a 192-256-row tile: MI355X_MICROARCH.md, "attention
+// epilogue store tail"; measured here as ~12 us of fixed cost per 34-us K = 2048 tile, profiles/r2_gemm_harness.txt).  After the
+// k-loop the operand buffers in LDS are dead, so each wave stages its own 64-column x (16 MF)-row tile in a private 16 KiB slice as
+// [row][64] bf16 (16-B chunk c of row r at position c ^ (r & 7): two-way write conflicts at most), reads it back row-major and stores
+// 16 B per lane: one instruction = 8 rows x 128 B = FULL lines.  No block barrier: only this wave touches its slice.
+static __device__ __forceinline__ void stage_frag_bf16(bf16_t* sc, int row, int i, int fg, uint2 pk) {
+    const int c = i * 2 + (fg >> 1);
+    *reinterpret_cast<uint2*>(sc + row * 64 + ((c ^ (row & 7)) << 3) + ((fg & 1) << 2)) = pk;
+}
+static __device__ __forceinline__ uint4 unstage_row16(const bf16_t* sc, int row, int chunk) {
+    return *reinterpret_cast<const uint4*>(sc + row * 64 + ((chunk ^ (row & 7)) << 3));
+}
+
 // epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
 // the wave's m range, n0 + wn*64 = its first column.
 template <int EPI, int MF>
-static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg) {
+static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg,
+                                                   bf16_t* stg = nullptr) {  // stg: this wave's 16 KiB LDS slice (or nullptr: direct stores)
+    const int lane_ = fg * 16 + fr;
+    const int rrow = lane_ >> 3, rchunk = lane_ & 7;  // read-back role: row inside an 8-row group, 16-B chunk of the 128-B row
+    // Q / K rows keep their direct stores unless flags bit 5 is set: staging them measured -3...-5 % on the fused projection (the
+    // per-token LayerNorm / RoPE math, not the stores, dominates those tiles; profiles/r2_gemm_harness.txt, r2n)
+    bf16_t* stg_qk = (g.flags & 32) ? stg : nullptr;
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
         // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
         // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
         const int nbase = n0 + wn * 64;
         if (n0 >= g.Nq) {  // fc1 tail of the fused [Wqkv ; W1] projection (block-uniform: Nq is a multiple of the tile width)
+            const bool staged = stg != nullptr && (g.ldo2 % 8) == 0 && ((g.N - g.Nq) % 8) == 0 && ((((uintptr_t)g.out2) & 15) == 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = nbase + i * 16 + fg * 4;
@@ -120,11 +142,19 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 #pragma unroll
                 for (int j = 0; j < MF; ++j) {
                     const int m = mrow0 + j * 16 + fr;
-                    if (m >= g.M || n >= g.N) continue;
                     uint2 pk;
                     pk.x = pack_bf2(gelu_new_fast(acc[i][j][0] + bn[0]), gelu_new_fast(acc[i][j][1] + bn[1]));
                     pk.y = pack_bf2(gelu_new_fast(acc[i][j][2] + bn[2]), gelu_new_fast(acc[i][j][3] + bn[3]));
-                    *reinterpret_cast<uint2*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
+                    if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
+                    else if (m < g.M && n < g.N) *reinterpret_cast<uint2*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
+                }
+            }
+            if (staged) {
+#pragma unroll
+                for (int t = 0; t < 2 * MF; ++t) {
+                    const int row = t * 8 + rrow, m = mrow0 + row, n = nbase + rchunk * 8;
+                    const uint4 v = unstage_row16(stg, row, rchunk);
+                    if (m < g.M && n < g.N) *reinterpret_cast<uint4*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = v;
                 }
             }
         } else if (nbase < g.N) {
@@ -195,8 +225,18 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     x[0][r] = y0 * cc0[r] - y1 * ss0[r];
                     x[1][r] = y1 * cc1[r] + y0 * ss1[r];
                 }
-                if (!valid) continue;
                 const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact in bf16)
+                if (stg_qk) {  // staged: the token's 64 values go to row j * 16 + fr of the wave's slice, stored as full 128-B rows below
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint2 pk;
+                        pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
+                        pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
+                        stage_frag_bf16(stg_qk, j * 16 + fr, i, fg, pk);
+                    }
+                    continue;
+                }
+                if (!valid) continue;
                 bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + pos) * 64;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -206,8 +246,52 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
                 }
             }
+            if (stg_qk && which < 2) {  // one (token, head) row = 128 B contiguous in Q / K: a wave instruction stores 8 of them
+#pragma unroll
+                for (int t = 0; t < 2 * MF; ++t) {
+                    const int row = t * 8 + rrow, m = mrow0 + row;
+                    const uint4 v = unstage_row16(stg_qk, row, rchunk);
+                    if (m < g.M) {
+                        const int b = m / g.L, l = m - b * g.L;
+                        const int64_t bh = (int64_t)b * g.nH + head;
+                        bf16_t* dst = which == 0 ? g.Q + (bh * g.L + l) * 64 : g.Kd + (bh * g.Lcap + g.pos0 + l) * 64;
+                        *reinterpret_cast<uint4*>(dst + rchunk * 8) = v;
+                    }
+                }
+            }
         }
     } else {
+        if constexpr (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
+            if (stg != nullptr && g.vec_out && !g.bias_per_row && (g.ldo % 8) == 0 && (g.N % 8) == 0 && ((((uintptr_t)g.out) & 15) == 0)) {
+                const int nbase = n0 + wn * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float bn[4];
+                    load_bias4(g, nbase + i * 16 + fg * 4, bn);
+#pragma unroll
+                    for (int j = 0; j < MF; ++j) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[i][j][r] + bn[r] + 0.f;  // same expression as store_frag (bias per row = 0)
+                            if (EPI == SHOWO_EPI_GELU_BF16) v[r] = gelu_new_fast(v[r]);
+                        }
+                        uint2 pk;
+                        pk.x = pack_bf2(v[0], v[1]);
+                        pk.y = pack_bf2(v[2], v[3]);
+                        stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
+                    }
+                }
+                bf16_t* o = reinterpret_cast<bf16_t*>(g.out);
+#pragma unroll
+                for (int t = 0; t < 2 * MF; ++t) {
+                    const int row = t * 8 + rrow, m = mrow0 + row, n = nbase + rchunk * 8;
+                    const uint4 v = unstage_row16(stg, row, rchunk);
+                    if (m < g.M && n < g.N) *reinterpret_cast<uint4*>(o + (int64_t)m * g.ldo + n) = v;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + i * 16 + fg * 4;
@@ -221,7 +305,7 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 
 // production kernel (gemm2p.hip)
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
-extern int g_gemm_gn, g_gemm_bm, g_gemm_pf;
+extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);
 

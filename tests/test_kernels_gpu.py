@@ -535,7 +535,7 @@ def test_softmax_rows_and_small_conv():
     assert (out.cpu() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5] + [5 + (v << 16) for v in (256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144)])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5] + [5 + (v << 16) for v in (256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144, 4192, 4176, 4160, 4144)])
 def test_gemm_both_tile_kernels(impl):
     """the 128^2 register-staged kernel and the 256^2 global_load_lds kernel give the same result on shapes
     with ragged M/N edges (rows/cols beyond the edge are clamped on load and predicated on store)"""
@@ -583,7 +583,7 @@ def test_tile_weight_layout():
 
 
 @pytest.mark.parametrize("tiled", [0, 1])
-@pytest.mark.parametrize("variant", [0, 256, 208, 1176, 1144, 2240, 2208, 3176, 3144])
+@pytest.mark.parametrize("variant", [0, 256, 208, 1176, 1144, 2240, 2208, 3176, 3144, 4176, 4144])
 @pytest.mark.parametrize("M,K0,K1,N", [(700, 128, 512, 384), (1548, 256, 1024, 2048), (300, 64, 64, 256)])
 def test_gemm_kcat_residual(variant, M, K0, K1, N, tiled):
     """showo_gemm_kcat_bf16: x += [A0 | A1] [W0 | W1]^T + bias in one launch (Phi's dense + fc2 into the same residual row,
@@ -610,7 +610,7 @@ def test_gemm_kcat_residual(variant, M, K0, K1, N, tiled):
                  L().ptr(dev(to_bf16_bits(W))), K0 + K1, L().ptr(dev(bias)), L().ptr(xd), N, None, 0, M, N, 2, 0, S())
 
 
-@pytest.mark.parametrize("variant", [256, 224, 1192, 1160, 1128, 2256, 2224, 3192, 3160])
+@pytest.mark.parametrize("variant", [256, 224, 1192, 1160, 1128, 2256, 2224, 3192, 3160, 4192, 4160])
 @pytest.mark.parametrize("B,Lq,nH,F", [(2, 387, 4, 512), (3, 130, 4, 1024)])
 def test_fused_qkv_fc1_equals_separate_launches_bits(variant, B, Lq, nH, F):
     """showo_gemm_qkv_fc1_bf16 ([Wqkv ; W1], column-split epilogue) is bit-identical to showo_gemm_qkv_bf16 + the fc1 GELU GEMM

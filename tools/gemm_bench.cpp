@@ -67,6 +67,13 @@ int main(int argc, char** argv) {
             {4096, 8192, 2048, 2, "lm_head rows"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
         };
     }
+    if (quick == 3) {  // decomposition of the tile time at 192-row tiles (variant x192): exactly 256 tiles per round at N = 2048
+        shapes = {
+            {6144, 2048, 2048, 0, "1 round K2048"}, {6144, 2048, 4096, 0, "1 round K4096"}, {6144, 2048, 8192, 0, "1 round K8192"},
+            {12288, 2048, 2048, 0, "2 rounds K2048"}, {24576, 2048, 2048, 0, "4 rounds K2048"}, {6144, 8192, 2048, 0, "4 rounds(N) K2048"},
+            {6144, 14336, 2048, 0, "7 rounds(N) K2048"},
+        };
+    }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& s : shapes) {
@@ -150,7 +157,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- fused entry points: K-concatenated residual GEMM and the [Wqkv ; W1] projection, checked against the separate launches
-    for (int M : {4128, 6192, 700}) {
+    if (quick != 3) for (int M : {4128, 6192, 700}) {
         const int H = 2048, F = 8192, nH = 32, B = M == 700 ? 2 : 16, L = M / B, Lp = ((L + 63) / 64) * 64;
         const int Mx = B * L;
         uint16_t *attn, *ffn, *Wd, *W2, *Wcat, *h, *Wq1, *Q0, *K0, *V0, *Q1, *K1, *V1, *f0, *f1;
@@ -181,7 +188,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         std::vector<float> r0((size_t)Mx * H), r1((size_t)Mx * H);
         CK(hipMemcpy(r0.data(), x0, r0.size() * 4, hipMemcpyDeviceToHost));
-        const int vars[] = {240, 2240, 208, 2208, 1192, 3192, 1176, 3176, 1160, 3160, 1144, 3144};
+        const int vars[] = {3192, 4192, 3176, 4176, 3160, 4160, 3144, 4144};
         uint16_t* WcatT; CK(hipMalloc(&WcatT, (size_t)RW * showo_gemm_tiled_elems(H, H + F) * 2));
         for (int r = 0; r < RW; ++r) RC(showo_gemm_tile_weight(Wcat, H + F, H, H + F, WcatT + (size_t)r * showo_gemm_tiled_elems(H, H + F), st));
         for (int tl : {0, 1}) {
