@@ -176,9 +176,10 @@ int showo_mask_tokens(const int64_t* tokens, const float* noise, const int32_t* 
  * per 32 query rows, operands straight from L2), 2 = LDS-tiled form (4 waves share 64-key K / V^T tiles staged by
  * global_load_lds; 4 waves/SIMD), 3 = the same at 3 waves/SIMD (no register spill) */
 int showo_attn_set_impl(int impl);
-/* AR decode step (one new token against the KV cache): 0 = fused layer, three launches (LN + qkv/fc1 GEMV, prep +
- * single-query attention, dense + fc2 GEMV with the residual adds; default), 1 = the general seven-launch layer.
- * Both give the same bits; 1 exists so that tests and profiles can compare them. */
+/* AR decode step (one new token against the KV cache): 0 = fused layer, three launches (LN + qkv/fc1 GEMV; prep +
+ * single-query attention with the fc2 GEMV co-scheduled on the CUs the 32 attention blocks leave idle (F = 8192 only);
+ * dense GEMV + both residual adds; default), 1 = the general seven-launch layer, 2 = the fused layer as a plain chain
+ * (fc2 in the third launch).  All three give the same bits; 1 and 2 exist so that tests and profiles can compare them. */
 int showo_decode_set_impl(int impl);
 int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,

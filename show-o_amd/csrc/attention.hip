@@ -14,6 +14,7 @@
 // A-operand of the PV product is two contiguous 8-byte loads per lane.  K/V tiles are read straight from
 // L2 (one head's K+V is 97 KB at L=387), waves of a block are independent (no LDS, no barriers).
 #include "common.h"
+#include "decode_common.h"
 #include "../../include/showo_hip.h"
 #include "prof.h"
 #include <cfloat>
@@ -512,20 +513,15 @@ struct DecPrep {
 };
 
 template <bool FUSED>
-__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f) {
+static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, const int head, const int b) {
     extern __shared__ float sp[];  // probabilities, zero padded to a multiple of 512 keys
     __shared__ float red[32];
     __shared__ float sq[64], sk[64], sv[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.x, b = blockIdx.y;
     const int64_t bh = (int64_t)b * a.nH + head;
-    int pos = -1;  // FUSED: index of the key that lives in LDS
-    if (FUSED) {
-        pos = a.pos_dev ? *a.pos_dev : f.pos;
-        a.Lk = pos + 1;
-    } else if (a.pos_dev) {
-        a.Lk = *a.pos_dev + 1;
-    }
+    // a.Lk from the host is exact for a direct launch and an UPPER BOUND under graph replay (pos_dev set: the engine passes the last
+    // position the captured loop can reach); the cache loads below are predicated on it, so they do not wait for the pos_dev round trip.
+    const int Lhint = a.Lk;
     // Everything the cache contributes is requested up front (the first 1024 key rows: one per thread; the first 1024
     // keys of this wave's four V^T rows), so the launch costs one HBM round trip, not one per phase.
     const bf16_t* Kb = a.K + bh * a.Lcap * 64;
@@ -538,14 +534,23 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int k = (it * 16 + wave) * 8 + r8;
-        ku[it] = (k < a.Lk && k != pos) ? *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+        ku[it] = k < Lhint ? *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            vu[cc][i] = (cc * 512 + 8 * lane < a.Lk) ? *reinterpret_cast<const uint4*>(vr + (int64_t)i * a.Lp + cc * 512 + 8 * lane)
-                                                     : make_uint4(0, 0, 0, 0);
+            vu[cc][i] = (cc * 512 + 8 * lane < Lhint) ? *reinterpret_cast<const uint4*>(vr + (int64_t)i * a.Lp + cc * 512 + 8 * lane)
+                                                      : make_uint4(0, 0, 0, 0);
+    // rows / columns at or beyond the live length (and the row being appended by this launch, k == pos) may hold stale or
+    // uninitialised bits: score() and accum() never let them reach a result
+    int pos = -1;  // FUSED: index of the key that lives in LDS
+    if (FUSED) {
+        pos = a.pos_dev ? *a.pos_dev : f.pos;
+        a.Lk = pos + 1;
+    } else if (a.pos_dev) {
+        a.Lk = *a.pos_dev + 1;
+    }
     float qv[8];  // this lane's 8 query dimensions (chunk ch)
     if (FUSED) {
         const int Hq = a.nH * 64;
@@ -667,10 +672,29 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f
     }
 }
 
+template <bool FUSED>
+__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f) {
+    attn_decode_body<FUSED>(a, f, blockIdx.x, blockIdx.y);
+}
+
+// Co-scheduled decode launch: blocks [0, nH) are the fused single-query attention (32 latency-bound blocks on a 256-CU chip); the
+// remaining blocks stream the fc2 weights (33.5 MB at Phi-1.5's shape) and write y2 = fc2(gelu(fc1)) + b2, which does not depend on
+// the attention (Phi's block is parallel-residual, models/phi.py:806-835).  No synchronisation between the roles: the following
+// out_gemv2_kernel<1, 2> launch adds dense(attn) and y2 into the residual row.  One launch instead of a stream fork / join.
+__global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPrep f, showo::OutGemvArgs g) {
+    if ((int)blockIdx.x >= a.nH) {
+        extern __shared__ float sp[];
+        showo::fc2_columns_role<4>(g, blockIdx.x - a.nH, gridDim.x - a.nH, 16, reinterpret_cast<bf16_t*>(sp));
+        return;
+    }
+    attn_decode_body<true>(a, f, blockIdx.x, 0);
+}
+
 // decode-step graph replay (engine-internal): when set, single-token qk_prep / attention launches take the position from
 // device memory, so the captured launch sequence is the same for every token
 static const int* g_decode_pos_dev = nullptr;
-namespace showo { void attn_set_decode_pos(const int* p) { g_decode_pos_dev = p; } }
+static int g_decode_lk_max = 0;  // upper bound of the key count over the replays of the captured loop (0: cache capacity)
+namespace showo { void attn_set_decode_pos(const int* p, int lk_max) { g_decode_pos_dev = p; g_decode_lk_max = p ? lk_max : 0; } }
 
 extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
                              const float* kln_b, const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K,
@@ -724,6 +748,7 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
     const bool tiled = lse != nullptr || forced >= 2 || (forced != 1 && Lq >= 64);  // only the tiled form writes lse  // decode steps (a few query rows) keep the gather form
     if (Lq == 1 && forced != 1 && !lse) {  // AR decode step
         a.pos_dev = g_decode_pos_dev;
+        if (g_decode_pos_dev) a.Lk = (g_decode_lk_max > 0 && g_decode_lk_max < Lcap) ? g_decode_lk_max : Lcap;  // load bound, see the kernel
         const size_t smem = (size_t)(((g_decode_pos_dev ? Lcap : Lk) + 511) & ~511) * sizeof(float);  // graph replay: Lk grows
         if (smem <= 60000) {
             attn_decode_kernel<false><<<dim3(nH, B), dim3(1024), smem, (hipStream_t)stream>>>(a, DecPrep{});
@@ -759,16 +784,25 @@ extern "C" int showo_attn_fwd_lse(const uint16_t* Q, const uint16_t* K, const ui
 namespace showo {
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
-                      int Lcap, int Lp, hipStream_t s) {
+                      int Lcap, int Lp, hipStream_t s, const bf16_t* W2, const bf16_t* ffn, const float* b2, int F, int Hout, float* y2,
+                      int co_blocks) {
     if ((Lp % 64) || Lp <= pos || Lcap <= pos) return set_error_msg(1, "decode attention: bad Lp/Lcap");
     AttnArgs a;
     a.Q = nullptr; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = nullptr; a.dense = nullptr; a.O = O;
     a.B = 1; a.nH = nH; a.Lq = 1; a.Lk = pos + 1; a.Lcap = Lcap; a.Lp = Lp; a.ldo = nH * 64; a.lse = nullptr;
     a.pos_dev = g_decode_pos_dev;
+    if (g_decode_pos_dev) a.Lk = (g_decode_lk_max > 0 && g_decode_lk_max < Lcap) ? g_decode_lk_max : Lcap;  // load bound, see the kernel
     DecPrep f{qkv, qw, qb, kw, kb, cosT, sinT, rot, pos, eps};
     const size_t smem = (size_t)(((g_decode_pos_dev ? Lcap : pos + 1) + 511) & ~511) * sizeof(float);
     if (smem > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
-    attn_decode_kernel<true><<<dim3(nH, 1), dim3(1024), smem, s>>>(a, f);
+    if (W2) {  // co-scheduled fc2 role (see attn_decode_co_kernel): needs K1 = 4 x 2048
+        if (F != 8192 || !y2 || !ffn || !b2) return set_error_msg(1, "decode attention: co-scheduled fc2 needs F = 8192 and y2");
+        showo::OutGemvArgs g{nullptr, nullptr, nullptr, nullptr, 0, W2, ffn, b2, F, Hout, y2};
+        const size_t smem2 = smem > (size_t)F * sizeof(bf16_t) ? smem : (size_t)F * sizeof(bf16_t);
+        attn_decode_co_kernel<<<dim3(nH + co_blocks, 1), dim3(1024), smem2, s>>>(a, f, g);
+    } else {
+        attn_decode_kernel<true><<<dim3(nH, 1), dim3(1024), smem, s>>>(a, f);
+    }
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

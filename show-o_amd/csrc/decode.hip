@@ -12,6 +12,7 @@
 // lane split, same accumulation order, same epilogue expressions -- so the fused step is bit-identical to the unfused one.
 // The next 4 x 16-B weight loads of a wave are always in flight while the current ones are multiplied.
 #include "common.h"
+#include "decode_common.h"
 #include "../../include/showo_hip.h"
 
 using namespace showo;
@@ -33,29 +34,6 @@ struct LnGemvArgs {
     bf16_t* out1;
     int N1;
 };
-
-__device__ inline void load4(const bf16_t* row, int k0, int K, uint4 (&wv)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * 512;
-        wv[u] = k < K ? ldg_nt16(row + k) : make_uint4(0, 0, 0, 0);
-    }
-}
-// acc += sum over the 4 loaded 8-element groups, in gemv_kernel's order (u ascending, j ascending)
-template <class AP>
-__device__ inline float fma4(const uint4 (&wv)[4], AP act, int k0, int K, float acc) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * 512;
-        if (k >= K) break;
-        const uint4 av = *reinterpret_cast<const uint4*>(act + k);
-        const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
-        const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf(bf2f(ea[j]), bf2f(ew[j]), acc);
-    }
-    return acc;
-}
 
 __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 2048: one 4-load group covers a weight row
     extern __shared__ bf16_t sh[];  // normalised row, bf16 like showo_layernorm_f32_bf16's output
@@ -129,20 +107,6 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
         n += 2 * stride;
     }
 }
-
-struct OutGemvArgs {
-    float* x;           // [N] fp32 residual stream row, updated in place
-    const bf16_t* W0;   // [N, K0] dense weight,  a0 [K0] attention output
-    const bf16_t* a0;
-    const float* b0;
-    int K0;
-    const bf16_t* W1;   // [N, K1] fc2 weight,    a1 [K1] gelu(fc1) row
-    const bf16_t* a1;
-    const float* b1;
-    int K1;
-    int N;
-    float* y2;          // [N] fp32: fc2 + b2 of the forked layer (MODE 1 writes it, MODE 2 adds it)
-};
 
 // C = 2048-element chunks per output column (dense chunks first, then fc2 chunks), ALL of them in flight per wave: a wave
 // streams 20 KB per column at the real shape and only 8 waves per CU exist, so depth is what hides the HBM latency.

@@ -23,7 +23,7 @@ struct Layer {
 namespace showo {
 void sampler_set_device_step(const int* step_dev, const float* sched, int steps);
 int sampler_step_inc(int* step_dev, hipStream_t s);
-void attn_set_decode_pos(const int* p);
+void attn_set_decode_pos(const int* p, int lk_max = 0);
 int sample_topk_launch(const float* logits, int V, int top_k, float temperature, const float* exp_noise, int64_t noise_stride,
                        uint64_t seed, int step, const int* pos_dev, int pos_base, int64_t* tok, hipStream_t s);
 // fused decode layer (decode.hip, attention.hip)
@@ -34,7 +34,8 @@ int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* 
                      const float* b1, int K1, int N, hipStream_t s, int mode = 0, float* y2 = nullptr);
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
-                      int Lcap, int Lp, hipStream_t s);
+                      int Lcap, int Lp, hipStream_t s, const bf16_t* W2 = nullptr, const bf16_t* ffn = nullptr, const float* b2 = nullptr,
+                      int F = 0, int Hout = 0, float* y2 = nullptr, int co_blocks = 0);
 extern int g_decode_impl;  // 0 = fused decode layer (default), 1 = the seven-launch path (showo_decode_set_impl)
 extern bool g_prof_on_query();
 }  // namespace showo

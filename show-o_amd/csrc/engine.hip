@@ -286,9 +286,11 @@ struct KVDest {
 };
 static KVDest kv_workspace(showo_engine* e, int L) { return KVDest{e->K, e->Vt, 0, 0, L, ((L + 63) / 64) * 64}; }
 namespace showo { int g_decode_impl = 0; }
+static int g_decode_chain = 0;  // 1: the fused layer as a plain three-launch chain (no co-scheduled fc2 role)
 extern "C" int showo_decode_set_impl(int impl) {
-    if (impl < 0 || impl > 1) return set_error_msg(1, "decode_set_impl: 0 = fused layer, 1 = unfused");
-    showo::g_decode_impl = impl;
+    if (impl < 0 || impl > 2) return set_error_msg(1, "decode_set_impl: 0 = fused layer (default), 1 = unfused, 2 = fused chain without the co-scheduled fc2 role");
+    showo::g_decode_impl = impl == 1;
+    g_decode_chain = impl == 2;
     return 0;
 }
 
@@ -327,9 +329,21 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         //   s:    LN + qkv GEMV ------> attention (prep + cache append + softmax) ----join--> dense GEMV + both residual adds
         //   side:                  \--> LN + fc1 GEMV + GELU --> fc2 GEMV (-> y2) --------/
         // Same arithmetic and parenthesisation as the chain (x = (x + (dense + bd)) + (fc2 + b2)): bit-identical results.
-        static int fork_on = -1;
-        if (fork_on < 0) { const char* env = getenv("SHOWO_DECODE_FORK"); fork_on = env ? (atoi(env) != 0) : 0; }
-        bool fork = fork_on != 0;
+        // Co-scheduled layer (SHOWO_DECODE_FORK=2): the same overlap WITHOUT graph edges -- the attention launch carries extra blocks
+        // that stream the fc2 weights into y2 (attention.hip, attn_decode_co_kernel), the third launch adds dense(attn) and y2:
+        //   LN + qkv GEMV + fc1 GEMV  ->  [ attention (32 blocks) || fc2 GEMV -> y2 (co_blocks) ]  ->  dense GEMV + both residual adds
+        // Measured (gpurun_out/bench_mmu_r2p_*, one box, cfg4): chain 857-861 tokens/s; co-scheduled 922-928 with 224 fc2 blocks,
+        // 965 with 128, 969 with 96 (fewer, fuller blocks leave the attention blocks' CUs alone) -> default, SHOWO_DECODE_FORK=0 is the chain.
+        static int fork_on = -1, co_blocks = 96;
+        if (fork_on < 0) {
+            const char* env = getenv("SHOWO_DECODE_FORK");
+            fork_on = env ? atoi(env) : 2;
+            const char* cb = getenv("SHOWO_DECODE_CO_BLOCKS");
+            if (cb && atoi(cb) > 0) co_blocks = atoi(cb);
+        }
+        bool fork = fork_on == 1;
+        const bool co = fork_on == 2 && F == 8192 && !g_decode_chain;
+        if (co && !e->y2) TRY(e->alloc(&e->y2, H));
         if (fork && !e->side) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             hipStreamIsCapturing(s, &cs);
@@ -344,6 +358,14 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             showo::Layer& l = e->layers[li];
             bf16_t* Kd = kv.k + li * kv.k_lstride;
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
+            if (co) {
+                TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
+                                           e->ffn, F, s));
+                TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
+                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, l.w2, e->ffn, l.b2, F, H, e->y2, co_blocks));
+                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2));
+                continue;
+            }
             if (!fork) {
                 TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
                                            e->ffn, F, s));
@@ -743,7 +765,7 @@ static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_
     SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv_dev, e->last_iv, 4 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, 4, s));
     SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // P0 / last_iv are host temporaries of this call
-    showo::attn_set_decode_pos(e->pos_dev);
+    showo::attn_set_decode_pos(e->pos_dev, P0 + n_steps);
     auto one = [&]() -> int {
         TRY(showo_embed_f32(tok, e->embed, e->x, 1, e->H, e->V, s));
         decode_iv_kernel<<<1, 64, 0, s>>>(e->last_iv_dev, e->prompt_len, e->pos_dev, e->iv1);

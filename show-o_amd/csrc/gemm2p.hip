@@ -474,7 +474,7 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
     g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
     if (g_gemm_pf < 0) { const char* e = getenv("SHOWO_GEMM_PF"); g_gemm_pf = e ? (atoi(e) != 0) : 0; }
     if (g_gemm_stage < 0) { const char* e = getenv("SHOWO_GEMM_STAGE"); g_gemm_stage = e ? atoi(e) : 1; }
-    g.flags = (g_gemm_pf ? 2 : 0) | (g_gemm_stage ? 0 : 8) | (g_gemm_stage == 2 ? 32 : 0);  // SHOWO_GEMM_STAGE: 0 direct stores, 1 (default) staged except Q / K, 2 all
+    g.flags = (g_gemm_pf ? 2 : 0) | (g_gemm_stage ? 0 : 8) | (g_gemm_stage == 2 ? 32 : 0) | (g_gemm_stage == 3 ? 64 : 0);  // SHOWO_GEMM_STAGE: 0 direct stores, 1 (default) staged except Q / K, 2 all, 3 = 1 with V^T direct
     g.dbg = nullptr;
     switch (epilogue) {
         case SHOWO_EPI_BF16: return launch2p_bm<SHOWO_EPI_BF16>(g, s);

@@ -123,10 +123,12 @@ template <int EPI, int MF>
 static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg,
                                                    bf16_t* stg = nullptr) {  // stg: this wave's 16 KiB LDS slice (or nullptr: direct stores)
     const int lane_ = fg * 16 + fr;
+    constexpr int VRS = MF < 8 ? 16 * MF + 2 : 128;  // row stride (elements) of the transposed V staging image: +2 breaks the 4-way bank conflict
     const int rrow = lane_ >> 3, rchunk = lane_ & 7;  // read-back role: row inside an 8-row group, 16-B chunk of the 128-B row
     // Q / K rows keep their direct stores unless flags bit 5 is set: staging them measured -3...-5 % on the fused projection (the
     // per-token LayerNorm / RoPE math, not the stores, dominates those tiles; profiles/r2_gemm_harness.txt, r2n)
     bf16_t* stg_qk = (g.flags & 32) ? stg : nullptr;
+    bf16_t* stg_v = (g.flags & 64) ? nullptr : stg;  // V^T transpose staging (bit 6 turns it off for A/B runs)
     if constexpr (EPI == EPI_QKV) {
         // The wave's 64 output columns are exactly one head of q, k or v (column tiles and wave tiles are head
         // aligned); a token's 64 values sit in the 4 lanes fr + 16*{0..3} (16 each: dims 16i + 4fg + r).
@@ -185,7 +187,12 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
                 if (which == 2) {  // V^T[bh][d][pos]
-                    if (valid) {
+                    if (stg_v) {  // staged transposed: [d][token] in the wave's LDS slice, stored below with the lanes along `pos`
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) stg_v[(i * 16 + fg * 4 + r) * VRS + j * 16 + fr] = f2bf(x[i][r]);
+                    } else if (valid) {
                         bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -244,6 +251,27 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
                     pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
                     *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
+                }
+            }
+            if (stg_v && which == 2) {
+                // V^T rows are contiguous along `pos`: with the lanes along the tile's tokens one store instruction writes up to 64
+                // consecutive positions of ONE head dimension (1-2 lines) instead of one position of 64 dimensions (64 lines).
+                // `pos` starts at an odd offset in the t2i loop (129 text rows), so the stores stay 2 bytes wide.
+                bf16_t* vb[2];
+                bool vok[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int mt = h * 64 + lane_, m = mrow0 + mt;
+                    vok[h] = mt < 16 * MF && m < g.M;
+                    const int mm = vok[h] ? m : 0;
+                    const int b = mm / g.L, l = mm - b * g.L;
+                    vb[h] = g.Vt + ((int64_t)b * g.nH + head) * 64 * g.Lp + g.pos0 + l;
+                }
+#pragma unroll 8
+                for (int dd = 0; dd < 64; ++dd) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (h * 64 < 16 * MF && vok[h]) vb[h][(int64_t)dd * g.Lp] = stg_v[dd * VRS + h * 64 + lane_];
                 }
             }
             if (stg_qk && which < 2) {  // one (token, head) row = 128 B contiguous in Q / K: a wave instruction stores 8 of them

@@ -271,6 +271,53 @@ def test_fused_decode_layer_equals_unfused_bits():
     assert [t for t, _ in runs[0]][:len(g["tokens"])] == [int(t) for t in g["tokens"]][:6]
 
 
+def test_full_size_decode_layer_forms_equal_bits():
+    """Phi-1.5 shape (H 2048, F 8192): the default decode layer co-schedules the fc2 GEMV with the single-query attention in one
+    launch (attention.hip attn_decode_co_kernel); the plain three-launch chain (impl 2) and the seven-launch layer (impl 1) must
+    give the same logits bits step after step, eager and through the per-token hipGraph (decode_greedy)"""
+    d = Wt.ShowoDims()
+    sd = Wt.make_showo_state(d, seed=11)
+    m = util.build_showo(d, sd, max_batch=1, max_seq=128)
+    del sd
+    lib = util.pkg()._lib
+    eng = m.engine()
+    gen = torch.Generator().manual_seed(3)
+    L = 37
+    ids = torch.randint(0, d.vocab - 20, (1, L), generator=gen).cuda().to(torch.int64).contiguous()
+    mask = torch.zeros((1, 1, L, L), dtype=torch.float32)
+    mask.masked_fill_(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), torch.finfo(torch.float32).min)
+    mask = mask.cuda().contiguous()
+    runs, greedy = [], []
+    side = torch.cuda.Stream()
+    try:
+        for impl in (1, 2, 0):
+            lib.call("showo_decode_set_impl", impl)
+            logits = torch.empty((d.vocab,), dtype=torch.float32, device="cuda")
+            lib.call("showo_engine_prefill", eng, lib.ptr(ids), None, lib.ptr(mask), L, lib.ptr(logits), lib.stream())
+            seq = []
+            for _ in range(4):
+                tok = logits.argmax().reshape(1).to(torch.int64)
+                lib.call("showo_engine_decode_step", eng, lib.ptr(tok), None, lib.ptr(logits), lib.stream())
+                torch.cuda.synchronize()
+                seq.append((int(tok), logits.clone()))
+            runs.append(seq)
+            lib.call("showo_engine_prefill", eng, lib.ptr(ids), None, lib.ptr(mask), L, lib.ptr(logits), lib.stream())
+            tok = logits.argmax().reshape(1).to(torch.int64)
+            out = torch.empty((6,), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):  # the legacy default stream cannot be captured
+                lib.call("showo_engine_decode_greedy", eng, lib.ptr(tok), 6, lib.ptr(out), lib.ptr(logits), 1, lib.stream())
+            torch.cuda.synchronize()
+            greedy.append(out.tolist())
+    finally:
+        lib.call("showo_decode_set_impl", 0)
+    for a, b, c in zip(*runs):
+        assert a[0] == b[0] == c[0]
+        assert torch.isfinite(c[1]).all()
+        assert torch.equal(a[1], b[1]) and torch.equal(a[1], c[1]), (float((a[1] - c[1]).abs().max()), float((a[1] - b[1]).abs().max()))
+    assert greedy[0] == greedy[1] == greedy[2], greedy
+
+
 def test_full_size_logits_vs_reference_subset():
     """1.45 B-parameter model, [2,387] t2i batch: compare with the reference's own logits (committed subset)."""
     g = util.golden("showo_full_logits_subset.npz")
