@@ -399,17 +399,52 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         hipStreamIsCapturing(s, &cs);
         if (!e->fused_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine: fused weight images must be built before a stream capture");
         TRY(fused_sync(e, s));
+        // Infinity-Cache warm-up of the NEXT GEMM's weight image on a side stream (SHOWO_MALL_PF bit 0: [Wd | W2] of this layer next
+        // to the projection GEMM; bit 1: [Wqkv ; W1] of the next layer next to the K-concatenated GEMM).  24 layers x 100 MB of
+        // weights cycle through a 256 MiB cache, so every weight tile is otherwise an HBM first touch (basic.hip, mall_warm).
+        static int mall_pf = -1, mall_blocks = 64;
+        if (mall_pf < 0) {
+            const char* env = getenv("SHOWO_MALL_PF");
+            mall_pf = env ? atoi(env) : 0;
+            const char* eb = getenv("SHOWO_MALL_PF_BLOCKS");
+            if (eb && atoi(eb) > 0) mall_blocks = atoi(eb);
+        }
+        int pf = mall_pf;
+        if (pf && !e->side) {
+            if (cs != hipStreamCaptureStatusNone) pf = 0;  // never create the stream inside a capture
+            else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&e->ev_fc1, hipEventDisableTiming) != hipSuccess)
+                return set_error_msg(7, "engine: cannot create the side stream");
+        }
+        const int64_t wq1_bytes = (int64_t)(3 * H + F) * H * 2, wd2_bytes = (int64_t)H * (H + F) * 2;
         for (int li = 0; li < e->nL; ++li) {
             showo::Layer& l = e->layers[li];
             bf16_t* Kd = kv.k + li * kv.k_lstride;
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
             TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
+            if (pf & 1) {
+                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
+                SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                TRY(showo::mall_warm(l.wd2, wd2_bytes, mall_blocks, nullptr, e->side));
+                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
+            }
             TRY(showo_gemm_qkv_fc1_bf16(e->h, H, e->fused_tiled ? l.wq1t : l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT,
                                         e->sinT, e->Q, Kd, Vd, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp,
                                         e->fused_tiled ? 1 : 0, s));
             TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
+            if (pf & 1) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
+            const bool pf2 = (pf & 2) && li + 1 < e->nL;
+            if (pf2) {
+                showo::Layer& nx = e->layers[li + 1];
+                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
+                SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                TRY(showo::mall_warm(e->fused_tiled ? nx.wq1t : nx.wqkv, wq1_bytes, mall_blocks, nullptr, e->side));
+                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
+            }
             TRY(showo_gemm_kcat_bf16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32,
                                      e->fused_tiled ? 1 : 0, s));
+            if (pf2) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
             TRY(collect_x(e, li + 1, T, s));
         }
         return 0;
