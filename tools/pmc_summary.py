@@ -39,7 +39,7 @@ def main():
                       "fetch_bytes_per_launch": 2.0 * 1024.0 * sf / nf if nf else None,
                       "write_bytes_per_launch": 1024.0 * sw / nw if nw else None}
 
-    def group(prefix):
+    def group(prefix):  # prefix: one name prefix or a tuple of them
         n = sum(v["launches"] for k, v in kernels.items() if k.startswith(prefix))
         if not n:
             return None
@@ -48,7 +48,8 @@ def main():
         return {"launches": n, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "bytes_per_launch": f + w}
     res = {"tag": tag, "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-events (one --pmc pass per counter)",
            "corrections": "fetch = 2 x FETCH_SIZE KiB (gfx950 wide-read halving), write = WRITE_SIZE KiB (uncalibrated)",
-           "gemm2p_kernel": group("gemm2p_kernel"), "attn_fwd_lds_kernel": group("attn_fwd_lds_kernel"),
+           "gemm2p_kernel": group(("gemm2p_kernel", "gemm3w_kernel")),  # the bf16 GEMM family (gemm2p.hip + its weight-ring form gemm3w.hip)
+            "attn_fwd_lds_kernel": group("attn_fwd_lds_kernel"),
            "conv2p_split_kernel": group("conv2p_split_kernel"), "kernels": kernels}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: res[k] for k in ("gemm2p_kernel", "attn_fwd_lds_kernel", "conv2p_split_kernel")}))
