@@ -72,7 +72,9 @@ int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, cons
 int showo_gemm_set_impl(int impl);
 /* development knobs of the 256^2 phase-split kernel (impl 3), used by tools/gemm_bench.cpp: gn = weight panels per
  * tile group of the block->tile map, flags bit0 = run the two wave groups without the one-barrier stagger,
- * dbg = device buffer of 512 uint64 for per-barrier timestamps (NULL = off). */
+ * dbg = device buffer of 512 uint64 for per-barrier timestamps (NULL = off).  flags >> 8 forces a tile variant of the production
+ * kernel (0 = tuned per shape); bits 1/2 weight-panel prefetch on/off, 3/4 direct / LDS-staged bf16 epilogue stores, 6/7 split-K of
+ * launches with few tiles off / on (default on: tiles x splits ~ 256 blocks, partials summed in split order by the last block). */
 int showo_gemm_tune(int gn, int flags, unsigned long long* dbg);
 
 /* Split-precision forms (VQGAN path): every operand is a (hi, lo) bf16 pair, x = hi + lo to ~2^-17; the MFMA

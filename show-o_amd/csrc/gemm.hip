@@ -900,6 +900,8 @@ extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
     else if (flags & 4) g_gemm_pf = 0;  // ... off; neither bit: unchanged (SHOWO_GEMM_PF, default off)
     if (flags & 8) g_gemm_stage = 0;    // impl 5: bf16 epilogue stores direct (8) or staged through LDS (16); neither: unchanged
     else if (flags & 16) g_gemm_stage = 1;
+    if (flags & 64) g_gemm_splitk = 0;  // impl 5: split-K of launches with few tiles off (64) / on (128); neither: unchanged
+    else if (flags & 128) g_gemm_splitk = 1;
     return 0;
 }
 

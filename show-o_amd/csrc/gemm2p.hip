@@ -47,6 +47,8 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
     int nwg = tilesM * tilesN, bid = blockIdx.x;
+    int split = 0;
+    if (g.splits > 1) { split = bid / nwg; bid -= split * nwg; }  // split-K: grid = tiles x splits (gemm_common.h)
     {   // XCD-aware bijective remap: blocks with equal (id % 8) share an L2; give each XCD a contiguous id range
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -61,7 +63,13 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         tn = first + (rem - tm * gsz);
     }
     const int m0 = tm * BMT, n0 = tn * B2;
-    const int nk = g.K / BK;
+    int nk = g.K / BK;
+    int kb = 0;  // first k column of this block's range (split-K)
+    if (g.splits > 1) {
+        const int per = (nk + g.splits - 1) / g.splits;
+        kb = split * per * BK;
+        nk = min(nk - split * per, per);
+    }
     const bool g_stage = !(g.flags & 8);  // bf16 epilogues store through LDS (full 128-B lines); flags bit 3 = direct stores (A/B)
     const int wn = wave & 3, wm = wave >> 2;
     const int gbase = wm * 16 * MF0;  // first tile row of this wave's group
@@ -71,15 +79,16 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     const int srow = lane >> 3;
     const int coff = ((lane & 7) ^ srow) << 3;
     constexpr bool KC = (EPI == SHOWO_EPI_RESID_F32);  // K-concatenated A operand: only the residual epilogue carries the second offset set
-    const int Ks = KC ? g.Ksplit : (1 << 30);
+    const int Ks = KC ? g.Ksplit - kb : (1 << 30);  // relative to this block's first column
     // row-major weights: base + k * 2 + row offset.  Tiled weights ([N/256][K/64][256][64] bf16, showo_gemm_tile_weight): panel base +
     // (k / 64) * 32 KiB + offset inside the block -- every k-tile of a panel is ONE contiguous 32 KiB read (DRAM-page and TLB friendly;
     // a wave-instruction reads 1 KiB contiguous instead of 8 lines 2 ldw bytes apart)
     const int wks = g.wtiled ? 8 : 0;  // tiled: (k * 2) << 8 = (k / 64) * 32768 for k a multiple of 64
-    const char* wbase = reinterpret_cast<const char*>(g.W) + (g.wtiled ? (size_t)tn * (size_t)(g.K / BK) * 32768 : (size_t)0);
-    const char* abase0 = reinterpret_cast<const char*>(g.A);
+    const char* wbase = reinterpret_cast<const char*>(g.W) + (g.wtiled ? (size_t)tn * (size_t)(g.K / BK) * 32768 : (size_t)0) +
+                        (((size_t)kb * 2) << wks);
+    const char* abase0 = reinterpret_cast<const char*>(g.A) + (size_t)kb * 2;
     // segment 1 base is biased by -Ksplit so that base + k * 2 addresses column k - Ksplit
-    const char* abase1 = (KC && g.A2) ? reinterpret_cast<const char*>(g.A2) - (int64_t)Ks * 2 : abase0;
+    const char* abase1 = (KC && g.A2) ? reinterpret_cast<const char*>(g.A2) - ((int64_t)g.Ksplit - kb) * 2 : abase0;
     const int lda1 = (KC && g.A2) ? g.lda2 : g.lda;
     constexpr int AOFF = 2 * 256 * 64;  // LDS (elements): W[buf][256][64] at 0, A[buf][256][64] behind it
     constexpr int NAO = NS ? NPW : 4;
@@ -276,12 +285,16 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
             if (t < nk) Q2_TILE(0, t, MFG);                                                                       \
         }                                                                                                         \
     } while (0)
+    __shared__ int s_last;
+    constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
     if (MF0 == MF1 || wm == 0) {
         Q2_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
+        if (g.splits > 1 && !splitk_exchange<MF0, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
         epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         Q2_RUN(MF1);
+        if (g.splits > 1 && !splitk_exchange<MF1, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
         epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef Q2_RUN
@@ -297,8 +310,36 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
 #undef Q2_DMA_W
 }
 
+// ---- split-K workspace: one per stream that asks for it (at most 4), allocated on first use outside a stream capture.
+// 96 MiB covers tiles x splits <= 256 blocks of the tallest tile (256 x 256 fp32 = 256 KiB per block).
+struct SplitWs { hipStream_t s; float4* ws; unsigned* tick; };
+SplitWs g_sws[4];
+int g_nsws = 0;
+constexpr size_t SPLITK_WS_BYTES = (size_t)96 << 20;
+constexpr int SPLITK_TICKS = 4096;
+
+bool splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
+    if (need > SPLITK_WS_BYTES) return false;
+    for (int i = 0; i < g_nsws; ++i)
+        if (g_sws[i].s == s) { *ws = g_sws[i].ws; *tick = g_sws[i].tick; return true; }
+    if (g_nsws == 4) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;  // never allocate inside a capture
+    SplitWs w{s, nullptr, nullptr};
+    if (hipMalloc(&w.ws, SPLITK_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMalloc(&w.tick, SPLITK_TICKS * sizeof(unsigned)) != hipSuccess || hipMemset(w.tick, 0, SPLITK_TICKS * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(w.ws);
+        return false;
+    }
+    g_sws[g_nsws++] = w;
+    *ws = w.ws; *tick = w.tick;
+    return true;
+}
+
 template <int EPI, int MF0, int MF1, bool NS>
-int launch2p(const GemmArgs& g, hipStream_t s) {
+int launch2p(const GemmArgs& g0, hipStream_t s) {
+    GemmArgs g = g0;
     static bool attr_set = false;
     auto kfn = gemm2p_kernel<EPI, MF0, MF1, NS>;
     if (!attr_set) {
@@ -308,7 +349,25 @@ int launch2p(const GemmArgs& g, hipStream_t s) {
     }
     constexpr int BMT = 16 * (MF0 + MF1);
     int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
-    kfn<<<dim3(tilesM * tilesN), dim3(512), SMEM3_BYTES, s>>>(g);
+    const int tiles = tilesM * tilesN, nk = g.K / GEMM_BK;
+    g.splits = 1;
+    if (g_gemm_splitk < 0) { const char* e = getenv("SHOWO_GEMM_SPLITK"); g_gemm_splitk = e ? atoi(e) : 1; }
+    // few tiles, long K: split until ~one block per CU, >= 16 k-tiles per split.  The exchange costs a tile-sized fp32 write per
+    // split and `splits` such reads in the last block (~5 + 2 x splits us): measured on cfg4 (gpurun_out/bench_mmu_r2x_*), the
+    // M = 631 prefill 6.8 -> 5.9 ms with 8 splits of the K = 10 240 residual GEMM, while 2 splits of the CLIP tower's K = 1 024
+    // GEMMs (8 k-tiles each) cost 0.3 ms more than they saved -- hence the 16 k-tile floor.
+    if (g_gemm_splitk && tiles * 2 <= 256 && nk >= 32) {
+        int S = 256 / tiles;
+        if (S > nk / 16) S = nk / 16;
+        if (S > 16) S = 16;
+        if (S >= 2) {
+            const int per = (nk + S - 1) / S;
+            S = (nk + per - 1) / per;  // no empty split
+            constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
+            if (S >= 2 && splitk_ws(s, (size_t)tiles * S * NFS * 512 * sizeof(float4), &g.ws, &g.tick)) g.splits = S;
+        }
+    }
+    kfn<<<dim3(tiles * g.splits), dim3(512), SMEM3_BYTES, s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "gemm2p launch", __FILE__, __LINE__);
     return 0;
@@ -352,6 +411,7 @@ int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
 
 int g_gemm_gn = 4;  // n-panels per XCD tile group (same-process sweep on the bench workload: 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s)
 int g_gemm_bm = 0;  // 0 = read SHOWO_GEMM_BM once; -1 = choose per shape; a variant code = force it
+int g_gemm_splitk = -1;  // SHOWO_GEMM_SPLITK: 0 = off, 1 (default) = launches with <= 128 tiles split K until ~256 blocks exist
 int g_gemm_stage = -1;  // bf16 epilogue stores staged through LDS: -1 = read SHOWO_GEMM_STAGE once (default on), 0 / 1 = forced
 int g_gemm_pf = -1; // L2 prefetch of the weight panel: -1 = read SHOWO_GEMM_PF once (default OFF: measured -3...-8 % in the harness
                     // with cold weights and within noise in the pipeline, profiles/r2_gemm_harness.txt), 0 / 1 = forced (showo_gemm_tune)

@@ -31,6 +31,11 @@ struct GemmArgs {
     int Nq = 1 << 30; bf16_t* out2 = nullptr; int ldo2 = 0;
     // gemm2p only: W is in the tiled layout of showo_gemm_tile_weight ([ceil(N/256)][K/64][256][64] bf16, 16-B chunks pre-swizzled)
     int wtiled = 0;
+    // gemm2p only: split-K for launches with few tiles (M = 631 prefill, the CLIP tower).  The grid is tiles x splits; split s of a tile
+    // accumulates k-tiles [s * per, (s + 1) * per), every split writes its fp32 fragments to ws, and the LAST block to arrive at the
+    // tile's ticket sums the `splits` partials IN SPLIT ORDER (its own included, read back from ws) and runs the ordinary epilogue:
+    // the result does not depend on which block arrived last.
+    int splits = 1; float4* ws = nullptr; unsigned* tick = nullptr;
 };
 
 constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
@@ -115,6 +120,45 @@ static __device__ __forceinline__ void stage_frag_bf16(bf16_t* sc, int row, int 
 }
 static __device__ __forceinline__ uint4 unstage_row16(const bf16_t* sc, int row, int chunk) {
     return *reinterpret_cast<const uint4*>(sc + row * 64 + ((chunk ^ (row & 7)) << 3));
+}
+
+// split-K exchange (GemmArgs::splits): returns true in the block that has to run the epilogue, with acc = the sum over all splits.
+// NFS = fragments per thread reserved in ws (4 x the larger group's fragment count); all 512 threads of the block call it.
+template <int MF, int NFS>
+static __device__ __forceinline__ bool splitk_exchange(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int split, int* s_last) {
+    const int tid = threadIdx.x;
+    float4* base = g.ws + (size_t)tile * g.splits * NFS * 512;
+    float4* mine = base + (size_t)split * NFS * 512 + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) mine[(i * MF + j) * 512] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __threadfence();  // release: the partial is visible device-wide (other XCDs' L2s included) before the ticket moves
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = atomicAdd(g.tick + tile, 1u);
+        const int last = old == (unsigned)(g.splits - 1);
+        if (last) atomicExch(g.tick + tile, 0u);  // ready for the next launch on this stream
+        *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return false;
+    __threadfence();  // acquire
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.splits; ++s) {
+        const float4* p = base + (size_t)s * NFS * 512 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const float4 v = p[(i * MF + j) * 512];
+                acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+            }
+    }
+    return true;
 }
 
 // epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
@@ -333,7 +377,7 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 
 // production kernel (gemm2p.hip)
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
-extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage;
+extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);
 

@@ -651,6 +651,101 @@ def test_fused_qkv_fc1_equals_separate_launches_bits(variant, B, Lq, nH, F):
     assert int(outs[1][3].ne(0).sum()) > 0.9 * M * F  # the fc1 tail was written
 
 
+SPLITK_OFF, SPLITK_ON = 64, 128  # showo_gemm_tune flag bits
+
+
+@pytest.mark.parametrize("variant", [0, 256, 208, 176, 144, 1192, 1160, 1128])
+@pytest.mark.parametrize("M,N,K", [(577, 1024, 4096), (631, 2048, 2048), (300, 700, 2048)])
+def test_gemm_splitk_epilogues(variant, M, N, K):
+    """Launches with few tiles and a long K (the M = 631 prefill, the CLIP tower) split K over tiles x splits ~ 256 blocks; the last
+    block to arrive sums the fp32 partials in split order and runs the ordinary epilogue.  Every epilogue against the fp64
+    reference on the same bf16 operands, run-to-run identical bits, and within fp32 re-association noise of the unsplit launch."""
+    torch.manual_seed(M + N + variant)
+    A, W, bias, resid = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N), torch.randn(M, N)
+    ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double()
+    scale = float(ref.abs().max())
+    got = {}
+    try:
+        for mode in (SPLITK_ON, SPLITK_ON, SPLITK_OFF):
+            L().call("showo_gemm_tune", 8, (variant << 8) | mode, None)
+            got.setdefault(mode, []).append((_gemm(A, W, bias, 2), _gemm(A, W, bias, 3, resid=resid), _gemm(A, W, bias, 1), _gemm(A, W, bias, 0)))
+    finally:
+        L().call("showo_gemm_tune", 8, SPLITK_ON, None)
+    a, b = got[SPLITK_ON]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)  # the sum order does not depend on which block arrives last
+    f32, res, gelu, bf = a
+    assert (f32.double() - ref).abs().max() < 2e-5 * scale
+    assert (res.double() - (ref + resid.double())).abs().max() < 2e-5 * scale
+    want = O.gelu_new(ref.float()).double()
+    assert (gelu.double() - want).abs().max() < 2 ** -8 * float(want.abs().max()) + 1e-3 * scale
+    assert (bf.double() - ref).abs().max() < 2 ** -8 * scale
+    off = got[SPLITK_OFF][0]
+    assert (f32 - off[0]).abs().max() < 1e-5 * scale and (res - off[1]).abs().max() < 1e-5 * scale
+
+
+@pytest.mark.parametrize("tiled", [0, 1])
+@pytest.mark.parametrize("variant", [0, 208, 144, 1176, 1128])
+def test_gemm_splitk_kcat_prefill_shape(variant, tiled):
+    """the cfg4 prefill residual GEMM: M = 631, [attn | ffn] K = 2048 + 8192, 8 weight panels -> 32-40 tiles x 8 splits; the split
+    boundaries fall inside both K segments (K-concatenated operand, tiled and row-major weights)"""
+    M, K0, K1, N = 631, 2048, 8192, 2048
+    torch.manual_seed(variant + tiled)
+    A0, A1 = torch.randn(M, K0), torch.randn(M, K1)
+    W = torch.randn(N, K0 + K1) * 0.02
+    bias, x = torch.randn(N), torch.randn(M, N)
+    ref = (bf16_round(torch.cat([A0, A1], 1)).double() @ bf16_round(W).double().T + bias.double() + x.double()).float()
+    Wd = dev(to_bf16_bits(W))
+    if tiled:
+        Wd = _tiled(Wd)
+    A0d, A1d, bd = dev(to_bf16_bits(A0)), dev(to_bf16_bits(A1)), dev(bias)
+    outs = []
+    try:
+        for mode in (SPLITK_ON, SPLITK_ON, SPLITK_OFF):
+            L().call("showo_gemm_tune", 8, (variant << 8) | mode, None)
+            xd = dev(x.clone())
+            L().call("showo_gemm_kcat_bf16", L().ptr(A0d), K0, K0, L().ptr(A1d), K1, K1, L().ptr(Wd), K0 + K1, L().ptr(bd), L().ptr(xd), N,
+                     L().ptr(xd), N, M, N, 3, tiled, S())
+            sync()
+            outs.append(xd.cpu())
+    finally:
+        L().call("showo_gemm_tune", 8, SPLITK_ON, None)
+    scale = float(ref.abs().max())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - ref).abs().max() < 2e-5 * scale and (outs[2] - ref).abs().max() < 2e-5 * scale
+
+
+def test_gemm_splitk_qkv_epilogue():
+    """fused QKV projection with few tiles (K = 2048, 24 weight panels, M = 600 -> 96 tiles x 2 splits): split-K under the LayerNorm +
+    RoPE + relayout epilogue; bf16 outputs within 2 ulp of the unsplit launch, identical from run to run"""
+    B, Lq, nH = 2, 300, 32
+    H, M = nH * 64, B * Lq
+    torch.manual_seed(5)
+    h = dev(to_bf16_bits(torch.randn(M, H)))
+    W = dev(to_bf16_bits(torch.randn(3 * H, H) * 0.03))
+    bias = dev(torch.randn(3 * H) * 0.1)
+    ln = [dev(t) for t in (torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05)]
+    cos, sin = (dev(t) for t in _rope_tables())
+    Lp = ((Lq + 63) // 64) * 64
+    outs = []
+    try:
+        for mode in (SPLITK_ON, SPLITK_ON, SPLITK_OFF):
+            L().call("showo_gemm_tune", 8, (1160 << 8) | mode, None)
+            Q = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
+            K = torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda")
+            Vt = torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda")
+            L().call("showo_gemm_qkv_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos),
+                     L().ptr(sin), L().ptr(Q), L().ptr(K), L().ptr(Vt), B, Lq, nH, 32, 1e-5, 0, Lq, Lp, S())
+            sync()
+            outs.append([from_bf16_bits(t).cpu() for t in (Q, K, Vt)])
+    finally:
+        L().call("showo_gemm_tune", 8, SPLITK_ON, None)
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b)
+        assert float(a.abs().max()) > 0.1
+        assert ((a - c).abs() <= 2 ** -7 * c.abs() + 1e-6).all()
+
+
 # ------------------------------------------------------------------------------------ split-precision (bf16 x3) kernels
 def _split(t):
     """(hi, lo) bf16 bit tensors on the device with t ~= hi + lo"""
