@@ -377,6 +377,67 @@ __global__ __launch_bounds__(64) void argmax_merge_kernel(int64_t* __restrict__ 
 }
 }  // namespace
 
+// Token boundary of the greedy AR loop in ONE launch after argmax_part_kernel: merge the 64 partial arg-maxima -> token, append it
+// to the output, advance the device-side position, write the next step's input embedding row and its mask row.  Replaces
+// argmax_merge + store_token + step_inc + embed + decode_iv (five ~4.5 us launches per token in the per-token graph).
+namespace {
+__global__ __launch_bounds__(256) void greedy_token_seam_kernel(int64_t* __restrict__ tok, int64_t* __restrict__ out_tokens, int* __restrict__ pos,
+                                                               int base, const float* __restrict__ table, float* __restrict__ x, int H, int V,
+                                                               const int32_t* __restrict__ last_iv, int L0, int32_t* __restrict__ iv) {
+    __shared__ int s_tok;
+    const int tid = threadIdx.x;
+    if (tid < 64) {  // argmax_merge_kernel
+        float best = g_argmax_val[tid];
+        int bi = g_argmax_idx[tid];
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (tid == 0) {
+            s_tok = bi;
+            *tok = bi;
+            const int P = *pos;
+            out_tokens[P - base] = bi;  // store_token_kernel
+            *pos = P + 1;               // step_inc_kernel
+            // decode_iv_kernel for the next position: the last prompt row extended by the columns [L0, P + 1]
+            int a = last_iv[0], b = last_iv[1], c = last_iv[2], d = last_iv[3];
+            const int Pn = P + 1;
+            if (b == L0 && a < b) b = Pn + 1;
+            else if (d == L0 && c < d) d = Pn + 1;
+            else if (!(c < d)) { c = L0; d = Pn + 1; }
+            else if (!(a < b)) { a = L0; b = Pn + 1; }
+            iv[0] = a; iv[1] = b; iv[2] = c; iv[3] = d;
+        }
+    }
+    __syncthreads();
+    const int id = s_tok;  // embed_kernel, one row
+    if (id < 0 || id >= V) {
+        for (int i = tid; i < H; i += 256) x[i] = __builtin_nanf("");
+        return;
+    }
+    const float* src = table + (int64_t)id * H;
+    if ((H & 3) == 0) {
+        for (int i = tid * 4; i < H; i += 1024) *reinterpret_cast<float4*>(x + i) = *reinterpret_cast<const float4*>(src + i);
+    } else {
+        for (int i = tid; i < H; i += 256) x[i] = src[i];
+    }
+}
+}  // namespace
+
+namespace showo {
+// returns -1 when the two-stage arg-max does not apply (n < 16384): the caller keeps the separate launches
+int greedy_token_seam(const float* logits, int n, int64_t* tok, int64_t* out_tokens, int* pos, int base, const float* table, float* x, int H,
+                      int V, const int32_t* last_iv, int L0, int32_t* iv, hipStream_t s) {
+    if (n < 16384) return -1;
+    argmax_part_kernel<<<dim3(ARGMAX_PARTS), dim3(1024), 0, s>>>(logits, n);
+    greedy_token_seam_kernel<<<dim3(1), dim3(256), 0, s>>>(tok, out_tokens, pos, base, table, x, H, V, last_iv, L0, iv);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "greedy_token_seam launch", __FILE__, __LINE__);
+    return 0;
+}
+}  // namespace showo
+
 extern "C" int showo_argmax_f32(const float* x, int n, int64_t* out, void* stream) {
     if (n <= 0) return set_error_msg(1, "argmax: n must be > 0");
     if (n >= 16384) {

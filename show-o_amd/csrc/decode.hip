@@ -35,6 +35,9 @@ struct LnGemvArgs {
     int N1;
 };
 
+// R = weight rows in flight per wave (2 by default; R = 4 with a grid of Ntot / 16 blocks requests every row of a layer's 58.7 MB at
+// kernel start -- see decode_ln_gemv2 for the measurement); larger matrices (lm_head) loop and refill.
+template <int R>
 __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 2048: one 4-load group covers a weight row
     extern __shared__ bf16_t sh[];  // normalised row, bf16 like showo_layernorm_f32_bf16's output
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -42,10 +45,11 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
     const int stride = gridDim.x * 4;
     int n = blockIdx.x * 4 + wave;
     auto rowp = [&](int c) { return c < g.N0 ? g.W0 + (int64_t)c * H : g.W1 + (int64_t)(c - g.N0) * H; };
-    // two weight rows per wave are in flight before anything else: they do not depend on the LayerNorm
-    uint4 b0[4], b1[4];
-    if (n < Ntot) load4(rowp(n), lane * 8, H, b0);
-    if (n + stride < Ntot) load4(rowp(n + stride), lane * 8, H, b1);
+    // the first R weight rows of the wave are in flight before anything else: they do not depend on the LayerNorm
+    uint4 br[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (n + r * stride < Ntot) load4(rowp(n + r * stride), lane * 8, H, br[r]);
     {   // every wave repeats layernorm_kernel's statistics (same lane split, same expressions => same bits) on a register
         // copy of the row (one global round trip instead of three), then writes a quarter of the normalised row to LDS.
         // (Measured: a 1024-thread block sharing one wave's statistics is slower, 23 us vs 19 us -- two barriers and a second
@@ -97,14 +101,16 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
         }
     };
     while (n < Ntot) {
-        float acc = fma4(b0, sh, lane * 8, H, 0.f);
-        if (n + 2 * stride < Ntot) load4(rowp(n + 2 * stride), lane * 8, H, b0);
-        finish(n, acc);
-        if (n + stride >= Ntot) break;
-        acc = fma4(b1, sh, lane * 8, H, 0.f);
-        if (n + 3 * stride < Ntot) load4(rowp(n + 3 * stride), lane * 8, H, b1);
-        finish(n + stride, acc);
-        n += 2 * stride;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c = n + r * stride;
+            if (c < Ntot) {
+                const float acc = fma4(br[r], sh, lane * 8, H, 0.f);
+                if (c + R * stride < Ntot) load4(rowp(c + R * stride), lane * 8, H, br[r]);
+                finish(c, acc);
+            }
+        }
+        n += R * stride;
     }
 }
 
@@ -177,7 +183,13 @@ bool decode_fused_shapes_ok(int H, int F) { return (H % 8) == 0 && (F % 8) == 0 
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
                     bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s) {
     LnGemvArgs g{x, lnw, lnb, eps, H, W0, b0, out0, outf, N0, W1, b1, out1, N1};
-    ln_gemv2_kernel<<<dim3(pick_blocks(N0 + N1, 12, 1280)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    // rows in flight per wave: 2 (default: 12 rows per block, a wave's third row is requested behind its first FMA) or 4
+    // (SHOWO_DECODE_LNR=4: the whole layer matrix requested at kernel start; measured SLOWER on cfg4, 0.983-0.992 vs 0.958-0.969 ms per
+    // token in one box, gpurun_out/bench_mmu_r2z_*: 123 VGPRs halve the resident waves and the single burst queues behind itself)
+    static int lnr = 0;
+    if (!lnr) { const char* e = getenv("SHOWO_DECODE_LNR"); lnr = (e && atoi(e) == 4) ? 4 : 2; }
+    if (lnr == 2) ln_gemv2_kernel<2><<<dim3(pick_blocks(N0 + N1, 12, 1280)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    else ln_gemv2_kernel<4><<<dim3(pick_blocks(N0 + N1, 16, 1024)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "ln_gemv2 launch", __FILE__, __LINE__);
     return 0;

@@ -36,6 +36,8 @@ int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s, const bf16_t* W2 = nullptr, const bf16_t* ffn = nullptr, const float* b2 = nullptr,
                       int F = 0, int Hout = 0, float* y2 = nullptr, int co_blocks = 0);
+int greedy_token_seam(const float* logits, int n, int64_t* tok, int64_t* out_tokens, int* pos, int base, const float* table, float* x, int H,
+                      int V, const int32_t* last_iv, int L0, int32_t* iv, hipStream_t s);
 int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t s);
 extern int g_decode_impl;  // 0 = fused decode layer (default), 1 = the seven-launch path (showo_decode_set_impl)
 extern bool g_prof_on_query();

@@ -801,12 +801,27 @@ static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_
     SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, 4, s));
     SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // P0 / last_iv are host temporaries of this call
     showo::attn_set_decode_pos(e->pos_dev, P0 + n_steps);
-    auto one = [&]() -> int {
+    // Greedy loop (top_k == 1, the reference caller's setting): the token boundary -- arg-max merge, token store, position increment, next
+    // embedding row, next mask row -- is one launch (basic.hip, greedy_token_seam_kernel) at the END of a step, so a step is
+    // [layers, lm_head, arg-max partials, boundary] and only the first step embeds its token up front.  SHOWO_DECODE_TOKSEAM=0: the
+    // five separate launches.
+    static int tokseam = -1;
+    if (tokseam < 0) { const char* env = getenv("SHOWO_DECODE_TOKSEAM"); tokseam = env ? (atoi(env) != 0) : 1; }
+    const bool seam_tok = tokseam && top_k == 1 && e->V >= 16384;
+    auto pre = [&]() -> int {
         TRY(showo_embed_f32(tok, e->embed, e->x, 1, e->H, e->V, s));
         decode_iv_kernel<<<1, 64, 0, s>>>(e->last_iv_dev, e->prompt_len, e->pos_dev, e->iv1);
+        return 0;
+    };
+    if (seam_tok) TRY(pre());
+    auto one = [&]() -> int {
+        if (!seam_tok) TRY(pre());
         // host-side P only sizes nothing here (grids depend on L = 1); the kernels read the position from pos_dev
         TRY(run_layers(e, 1, 1, P0, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
         TRY(head_rows(e, nullptr, 1, 0, e->V, logits_ws, s));
+        if (seam_tok)
+            return showo::greedy_token_seam(logits_ws, e->V, tok, out_tokens, e->pos_dev, P0, e->embed, e->x, e->H, e->V, e->last_iv_dev,
+                                            e->prompt_len, e->iv1, s);
         if (top_k == 1) TRY(showo_argmax_f32(logits_ws, e->V, tok, s));
         else TRY(showo::sample_topk_launch(logits_ws, e->V, top_k, temperature, exp_noise, (int64_t)e->V, seed, step0, e->pos_dev, P0,
                                            tok, s));

@@ -316,6 +316,9 @@ def test_full_size_decode_layer_forms_equal_bits():
         assert torch.isfinite(c[1]).all()
         assert torch.equal(a[1], b[1]) and torch.equal(a[1], c[1]), (float((a[1] - c[1]).abs().max()), float((a[1] - b[1]).abs().max()))
     assert greedy[0] == greedy[1] == greedy[2], greedy
+    # the device-side loop (token boundary in one launch: arg-max merge + store + position + next embedding / mask row) follows the
+    # host-driven steps: token j of the loop = arg-max of the logits after step j
+    assert greedy[0][:3] == [runs[0][1][0], runs[0][2][0], runs[0][3][0]], (greedy[0], [t for t, _ in runs[0]])
 
 
 def test_full_size_logits_vs_reference_subset():
