@@ -521,8 +521,15 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (scratch) (void)hipFree(scratch);
     g_bm_cache[key] = best | (best_gn << 16);
-    if (getenv("SHOWO_GEMM_TUNE_LOG"))
+    if (const char* tl = getenv("SHOWO_GEMM_TUNE_LOG")) {
         fprintf(stderr, "[gemm2p tune] M=%d N=%d K=%d epi=%d -> variant %d gn %d (%.1f us)\n", g.M, g.N, g.K, EPI, best, best_gn, best_ms * 1000.f / 3.f);
+        if (atoi(tl) >= 2) {  // every candidate
+            fprintf(stderr, "[gemm2p tune]   ");
+            for (int ci = 0; ci < N_VARIANTS; ++ci)
+                if (cand_ms[ci] < 1e29f) fprintf(stderr, " %d:%.1f", k_variants[ci], cand_ms[ci] * 1000.f / 3.f);
+            fprintf(stderr, "\n");
+        }
+    }
     GemmArgs c = g;
     c.gn = best_gn;
     return launch2p_h<EPI>(c, best, s);

@@ -188,14 +188,17 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         std::vector<float> r0((size_t)Mx * H), r1((size_t)Mx * H);
         CK(hipMemcpy(r0.data(), x0, r0.size() * 4, hipMemcpyDeviceToHost));
-        const int vars[] = {3192, 4192, 3176, 4176, 3160, 4160, 3144, 4144};
+        // GEMM_BENCH_VARS / GEMM_BENCH_GNS: comma lists overriding the tile variants and the tile-group widths of the fused sections
+        std::vector<int> vars = {3192, 4192, 3176, 4176, 3160, 4160, 3144, 4144}, gns = {8};
+        auto parse = [](const char* e, std::vector<int>& v) { if (!e) return; v.clear(); std::string t(e); size_t p0 = 0; while (p0 < t.size()) { size_t q = t.find(',', p0); if (q == std::string::npos) q = t.size(); v.push_back(atoi(t.substr(p0, q - p0).c_str())); p0 = q + 1; } };
+        parse(getenv("GEMM_BENCH_VARS"), vars); parse(getenv("GEMM_BENCH_GNS"), gns);
         uint16_t* WcatT; CK(hipMalloc(&WcatT, (size_t)RW * showo_gemm_tiled_elems(H, H + F) * 2));
         for (int r = 0; r < RW; ++r) RC(showo_gemm_tile_weight(Wcat, H + F, H, H + F, WcatT + (size_t)r * showo_gemm_tiled_elems(H, H + F), st));
         for (int tl : {0, 1}) {
         const uint16_t* Wk = tl ? WcatT : Wcat; const size_t wstride = tl ? (size_t)showo_gemm_tiled_elems(H, H + F) : (size_t)H * (H + F);
         printf("kcat M=%d tiled=%d:", Mx, tl);
-        for (int v : vars) {
-            RC(showo_gemm_tune(8, (v << 8) | 4, nullptr));
+        for (int v : vars) for (int gn : gns) {
+            RC(showo_gemm_tune(gn, (v << 8) | 4, nullptr));
             size_t bad = 0;
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipMemcpy(x1, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
@@ -209,7 +212,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < iters; ++i) RC(showo_gemm_kcat_bf16(attn, H, H, ffn, F, F, Wk + (size_t)(i % RW) * wstride, H + F, bsum, x1, H, x1, H, Mx, H, 3, tl, st));
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf(" %d:%.0fTF%s", v, 2.0 * Mx * H * (H + F) * iters / (ms * 1e-3) / 1e12, bad ? "**MISMATCH**" : "");
+            printf(" %d/gn%d:%.0fTF%s", v, gn, 2.0 * Mx * H * (H + F) * iters / (ms * 1e-3) / 1e12, bad ? "**MISMATCH**" : "");
             fflush(stdout);
         }
         printf("\n");
@@ -235,8 +238,8 @@ int main(int argc, char** argv) {
         for (int tl : {0, 1}) {
         const uint16_t* Wq = tl ? Wq1T : Wq1; const size_t qstride = tl ? q1e : (size_t)(Nq + F) * H;
         printf("qkv|fc1 M=%d tiled=%d:", Mx, tl);
-        for (int v : vars) {
-            RC(showo_gemm_tune(8, (v << 8) | 4, nullptr));
+        for (int v : vars) for (int gn : gns) {
+            RC(showo_gemm_tune(gn, (v << 8) | 4, nullptr));
             CK(hipMemsetAsync(V0, 0, nvt * 2, st)); CK(hipMemsetAsync(V1, 0, nvt * 2, st));
             RC(showo_gemm_qkv_bf16(h, H, Wq1, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q0, K0, V0, B, L, nH, 32, 1e-5f, 0, L, Lp, st));
             RC(showo_gemm_bf16(h, H, Wq1 + (size_t)Nq * H, H, bq1 + Nq, 0, f0, F, nullptr, 0, Mx, F, H, 1, st));
@@ -249,7 +252,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < iters; ++i) RC(showo_gemm_qkv_fc1_bf16(h, H, Wq + (size_t)(i % RW) * qstride, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, f1, F, F, B, L, nH, 32, 1e-5f, 0, L, Lp, tl, st));
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf(" %d:%.0fTF%s", v, 2.0 * Mx * (Nq + F) * H * iters / (ms * 1e-3) / 1e12, ok ? "" : "**MISMATCH**");
+            printf(" %d/gn%d:%.0fTF%s", v, gn, 2.0 * Mx * (Nq + F) * H * iters / (ms * 1e-3) / 1e12, ok ? "" : "**MISMATCH**");
             fflush(stdout);
         }
         printf("\n");
