@@ -120,6 +120,43 @@ def self_launch(gpus, script):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def train_leg(world, rank, steps=4, warmup=2, timeout_s=420):
+    """run `bench_train.py --gpus world` as a child of this rank and return (rank 0) the fields of its JSON line that matter here"""
+    import subprocess
+    env = dict(os.environ)
+    if world > 1:
+        env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 101)
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the children rendezvous on their own TCPStore (child rank 0 hosts it)
+    cmd = [sys.executable, os.path.join(ROOT, "bench_train.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline"]
+    t0 = time.time()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            so, se = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"error": f"training leg timed out after {timeout_s}s"} if rank == 0 else None
+    except OSError as e:
+        return {"error": str(e)} if rank == 0 else None
+    if rank != 0:
+        return None
+    line = None
+    for l in so.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+    if p.returncode != 0 or line is None:
+        return {"error": f"bench_train.py rc={p.returncode}", "stderr_tail": se[-400:]}
+    d = json.loads(line)
+    log(f"training leg: {d['value']:.1f} ms/step on {d['n_gpus']} GPU(s) in {time.time() - t0:.0f}s")
+    return {"metric": d["metric"], "ms_per_step": d["value"], "n_gpus": d["n_gpus"], "steps": d["steps"], "warmup": d["warmup"], "scaling": d["scaling"],
+            "global_batch": d["config"].get("global_batch"), "tokens_per_s": d["config"].get("tokens_per_s"),
+            "gradient_wire": d["config"].get("gradient_wire"), "gemm_tflops": d["roofline"].get("achieved"),
+            "gemm_frac_of_mfma_peak": d["roofline"].get("frac"),
+            "source": "bench_train.py run by this command as child ranks (one process per GPU, RCCL all-reduce of the gradient buckets overlapped with backward)"}
+
+
 def aggregate(dt, units_local, dist=None, device="cpu"):
     """whole-job numbers of a replica-parallel run: (max elapsed time over ranks, units processed by all ranks).
     Independent units, no data-path collective: this MAX / SUM pair is the only communication of the benchmark."""
@@ -154,6 +191,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (A/B of their overhead)")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): the denoise steps replay the engine's cached hipGraph; 0: eager launches")
     ap.add_argument("--roofline-steps", type=int, default=2, help="steps of the separate eager + HIP-event leg that feeds `roofline` (0: skip)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the short training-step leg (bench_train.py in child ranks) that fills `train_step`")
     ap.add_argument("--workload", default="t2i", help="t2i (default, the headline metric) | train (bench_train.py: stage-1 step time) | "
                     "t2i512 | mmu (bench_configs.py: BASELINE configs[2] / configs[3])")
     a = ap.parse_args()
@@ -289,14 +327,24 @@ def main():
                          "attention": {"achieved": fl_attn.value / max(1e-9, ms_attn.value * 1e-3) / 1e12},
                          "vq_conv": {"achieved": fl_conv.value / max(1e-9, ms_conv.value * 1e-3) / 1e12}},
         }
+    # ---- training-step leg: BASELINE.json's metric is "t2i images/sec + train step-time, 1/2/4/8 MI355X", and the t2i replicas above
+    # exchange nothing, so the data-parallel half (RCCL all-reduce of the gradient buckets overlapped with backward) is measured here:
+    # every rank runs bench_train.py as a CHILD process (own process group on MASTER_PORT + 101, bounded by a timeout, so that a
+    # problem in this leg cannot take the headline line down with it); rank 0 attaches the child's line as `train_step`.
+    train_step = None
+    if not a.no_train_leg:
+        del model, vq, img
+        torch.cuda.empty_cache()
+        train_step = train_leg(world, rank)
+    if rank == 0:
+        out["train_step"] = train_step
         if not a.no_cpu_baseline and world == 1:
-            del model, vq
-            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -464,3 +464,50 @@ def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_training_leg_child_launch(monkeypatch):
+    """bench.py's `train_step` leg runs bench_train.py as a child of every rank: own rendezvous port (MASTER_PORT + 101, the
+    launcher's agent store not inherited), bounded by a timeout, only rank 0 reports, a failing child yields an error object
+    instead of taking the headline line down"""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, util.ROOT)
+    import bench
+    seen = {}
+
+    class FakeProc:
+        returncode = 0
+
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"] = cmd, env
+
+        def communicate(self, timeout=None):
+            seen["timeout"] = timeout
+            line = {"metric": "train step-time", "value": 200.0, "n_gpus": 2, "steps": 4, "warmup": 2, "scaling": "weak",
+                    "config": {"global_batch": 58, "tokens_per_s": 1.0, "gradient_wire": "bf16"}, "roofline": {"achieved": 1000.0, "frac": 0.4}}
+            return "noise\n" + json.dumps(line) + "\n", ""
+
+        def kill(self):
+            seen["killed"] = True
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    got = bench.train_leg(2, 0)
+    assert seen["env"]["MASTER_PORT"] == "29612" and "TORCHELASTIC_USE_AGENT_STORE" not in seen["env"]
+    assert seen["cmd"][1].endswith("bench_train.py") and seen["cmd"][2:4] == ["--gpus", "2"] and "--no-cpu-baseline" in seen["cmd"]
+    assert seen["timeout"] and got["ms_per_step"] == 200.0 and got["n_gpus"] == 2 and got["gradient_wire"] == "bf16"
+    assert bench.train_leg(2, 1) is None  # only rank 0 reports
+    FakeProc.returncode = 3
+    assert "error" in bench.train_leg(2, 0)
+
+    class Hung(FakeProc):
+        def communicate(self, timeout=None):
+            if timeout:
+                raise subprocess.TimeoutExpired("x", timeout)
+            return "", ""
+
+    monkeypatch.setattr(subprocess, "Popen", Hung)
+    assert "timed out" in bench.train_leg(2, 0)["error"] and seen.get("killed")
