@@ -353,12 +353,15 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
     g.splits = 1;
     if (g_gemm_splitk < 0) { const char* e = getenv("SHOWO_GEMM_SPLITK"); g_gemm_splitk = e ? atoi(e) : 1; }
     // few tiles, long K: split until ~one block per CU, >= 16 k-tiles per split.  The exchange costs a tile-sized fp32 write per
-    // split and `splits` such reads in the last block (~5 + 2 x splits us): measured on cfg4 (gpurun_out/bench_mmu_r2x_*), the
-    // M = 631 prefill 6.8 -> 5.9 ms with 8 splits of the K = 10 240 residual GEMM, while 2 splits of the CLIP tower's K = 1 024
-    // GEMMs (8 k-tiles each) cost 0.3 ms more than they saved -- hence the 16 k-tile floor.
-    if (g_gemm_splitk && tiles * 2 <= 256 && nk >= 32) {
+    // split, one L2 write-back + ticket per block and `splits` tile reads in the last block.  Measured (profiles/r2_gemm_harness.txt,
+    // r3c / r3d): M = 631, K = 10 240 residual GEMM 168 -> 70 us (6 splits of a 128-row variant); CLIP fc2 (K = 4 096) 65 -> 37-40 us;
+    // cfg4 prefill 6.3 -> 4.5 ms, CLIP tower 5.8 -> 4.9 ms, time to first token 12.1 -> 9.5 ms.  Splits of 8 k-tiles (K = 1 024
+    // GEMMs) measured within noise of none -> floor 16.  Ring variants (gemm3w) do not split: the tuner compares both families.
+    static int min_kt = 0;  // k-tiles per split at least (SHOWO_GEMM_SPLITK_MIN, default 16)
+    if (!min_kt) { const char* e = getenv("SHOWO_GEMM_SPLITK_MIN"); min_kt = (e && atoi(e) >= 2) ? atoi(e) : 16; }
+    if (g_gemm_splitk && tiles * 2 <= 256 && nk >= 2 * min_kt) {
         int S = 256 / tiles;
-        if (S > nk / 16) S = nk / 16;
+        if (S > nk / min_kt) S = nk / min_kt;
         if (S > 16) S = 16;
         if (S >= 2) {
             const int per = (nk + S - 1) / S;

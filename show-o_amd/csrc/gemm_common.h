@@ -133,17 +133,20 @@ static __device__ __forceinline__ bool splitk_exchange(const GemmArgs& g, f32x4 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MF; ++j) mine[(i * MF + j) * 512] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    __threadfence();  // release: the partial is visible device-wide (other XCDs' L2s included) before the ticket moves
+    // release by ONE lane after the block barrier: every wave's stores have reached this XCD's L2 (s_waitcnt vmcnt(0) precedes the
+    // barrier), and a single L2 write-back makes the whole partial visible device-wide before the ticket moves.  (A fence per
+    // thread -- 8 write-backs per block, 2 000 per launch -- made the exchange cost 20-70 us per launch.)
     __syncthreads();
     if (tid == 0) {
+        __threadfence();
         const unsigned old = atomicAdd(g.tick + tile, 1u);
         const int last = old == (unsigned)(g.splits - 1);
         if (last) atomicExch(g.tick + tile, 0u);  // ready for the next launch on this stream
         *s_last = last;
+        if (last) __threadfence();  // acquire: this CU's vector cache and the XCD's L2 drop stale lines of the workspace
     }
     __syncthreads();
     if (!*s_last) return false;
-    __threadfence();  // acquire
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -67,6 +67,13 @@ int main(int argc, char** argv) {
             {4096, 8192, 2048, 2, "lm_head rows"}, {4096, 4096, 4096, 0, "4096^3"}, {8192, 8192, 8192, 0, "8192^3"},
         };
     }
+    if (quick == 4) {  // small-M shapes: the CLIP ViT-L/14-336 tower (577 rows) and the cfg4 prefill (631 rows)
+        shapes = {
+            {577, 3072, 1024, 0, "clip qkv"}, {577, 1024, 1024, 3, "clip out"}, {577, 4096, 1024, 1, "clip fc1"}, {577, 1024, 4096, 3, "clip fc2"},
+            {631, 6144, 2048, 0, "prefill qkv"}, {631, 2048, 2048, 3, "prefill dense"}, {631, 8192, 2048, 1, "prefill fc1"}, {631, 2048, 8192, 3, "prefill fc2"},
+            {631, 2048, 10240, 3, "prefill dense|fc2"}, {631, 14336, 2048, 0, "prefill qkv|fc1"},
+        };
+    }
     if (quick == 3) {  // decomposition of the tile time at 192-row tiles (variant x192): exactly 256 tiles per round at N = 2048
         shapes = {
             {6144, 2048, 2048, 0, "1 round K2048"}, {6144, 2048, 4096, 0, "1 round K4096"}, {6144, 2048, 8192, 0, "1 round K8192"},
@@ -157,7 +164,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- fused entry points: K-concatenated residual GEMM and the [Wqkv ; W1] projection, checked against the separate launches
-    if (quick != 3) for (int M : {4128, 6192, 700}) {
+    if (quick != 3 && quick != 4) for (int M : {4128, 6192, 700}) {
         const int H = 2048, F = 8192, nH = 32, B = M == 700 ? 2 : 16, L = M / B, Lp = ((L + 63) / 64) * 64;
         const int Mx = B * L;
         uint16_t *attn, *ffn, *Wd, *W2, *Wcat, *h, *Wq1, *Q0, *K0, *V0, *Q1, *K1, *V1, *f0, *f1;
