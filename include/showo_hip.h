@@ -126,6 +126,17 @@ int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1
                             uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0, int Lcap,
                             int Lp, int w_tiled, void* stream);
 
+/* Training forward of showo_gemm_qkv_fc1_bf16 (training/train.py:510-628 through models/phi.py:657-694, 208-212): the same launch
+ * also saves what backward reads -- raw_qkv bf16 [B*L, ldraw] = A Wqkv^T + b (pre-LayerNorm q, k and v: the input of
+ * showo_qkln_rope_bwd / showo_attn_bwd) and ffn_pre bf16 [B*L, ldf] = A W1^T + b1 (the input of showo_dgelu_bf16) -- and derives
+ * Q / K / V^T and ffn_out = gelu_new(ffn_pre) from those ROUNDED values: one launch instead of showo_gemm_bf16 + showo_qk_prep +
+ * showo_gemm_bf16 + showo_gelu_bf16, with the forward and the recomputation in backward seeing the same numbers. */
+int showo_gemm_qkv_fc1_save_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
+                                 const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                 const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                                 uint16_t* raw_qkv, int ldraw, uint16_t* ffn_pre, uint16_t* ffn_out, int ldf, int F, int B, int L,
+                                 int nH, int rot, float eps, int pos0, int Lcap, int Lp, int w_tiled, void* stream);
+
 /* K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias) with A0 bf16 [M,K0] (lda0), A1 bf16 [M,K1] (lda1) and
  * weight rows [W0[n,:] | W1[n,:]] bf16 [N, ldw] (ldw >= K0 + K1; K0, K1 multiples of 64).  epilogue must be SHOWO_EPI_RESID_F32
  * (out fp32 = acc + bias + resid, in place allowed).

@@ -82,6 +82,8 @@ _PROTOS = {
     "showo_gemm_qkv_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
     "showo_gemm_qkv_fc1_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                 c_f, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_qkv_fc1_save_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i,
+                                     c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_kcat_bf16": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_tile_weight": [c_p, c_i, c_i, c_i, c_p, c_p],
     "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],

@@ -978,7 +978,8 @@ extern "C" int showo_gemm_tile_weight(const uint16_t* W, int ldw, int N, int K, 
 static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias, const float* qln_w,
                          const float* qln_b, const float* kln_w, const float* kln_b, const float* cos_tab, const float* sin_tab,
                          uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
-                         uint16_t* ffn_out, int ldf, int F, int w_tiled, void* stream) {
+                         uint16_t* ffn_out, int ldf, int F, int w_tiled, void* stream, uint16_t* raw_qkv = nullptr, int ldraw = 0,
+                         uint16_t* ffn_pre = nullptr) {
     const int M = B * L, Nq = 3 * nH * 64, Kd = nH * 64;
     const int N = Nq + (ffn_out ? F : 0);
     if (M <= 0) return 0;
@@ -997,6 +998,14 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
     g.qw = qln_w; g.qb = qln_b; g.kw = kln_w; g.kb = kln_b; g.cosT = cos_tab; g.sinT = sin_tab;
     g.Q = Q; g.Kd = K; g.Vt = Vt; g.L = L; g.nH = nH; g.pos0 = pos0; g.Lcap = Lcap; g.Lp = Lp; g.eps = eps;
     if (ffn_out) { g.Nq = Nq; g.out2 = ffn_out; g.ldo2 = ldf; }
+    if (raw_qkv) {
+        if ((ldraw % 4) || (((uintptr_t)raw_qkv) & 7)) return set_error_msg(1, "gemm_qkv_fc1_save: raw_qkv 8B aligned, ld a multiple of 4");
+        g.raw = raw_qkv; g.ldraw = ldraw;
+    }
+    if (ffn_pre) {
+        if (!ffn_out || (((uintptr_t)ffn_pre) & 7)) return set_error_msg(1, "gemm_qkv_fc1_save: ffn_pre needs ffn_out, 8B aligned");
+        g.pre = ffn_pre;
+    }
     g.wtiled = w_tiled ? 1 : 0;
     ProfScope prof(PROF_GEMM, 2.0 * M * N * Kd, (hipStream_t)stream);
     return gemm2p_dispatch(g, EPI_QKV, (hipStream_t)stream);
@@ -1018,6 +1027,20 @@ extern "C" int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_
     if (!ffn_out) return set_error_msg(1, "gemm_qkv_fc1: ffn_out required");
     return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
                          pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream);
+}
+
+// Training forward of the same launch: additionally saves what backward needs -- raw_qkv[m][0..3 nH 64) = bf16(A Wqkv^T + b) (the values
+// showo_qkln_rope_bwd recomputes the q/k LayerNorm statistics from, and V) and ffn_pre = bf16(A W1^T + b1) (the input of dgelu) -- and
+// derives Q / K / V^T and ffn_out = gelu_new(ffn_pre) from those ROUNDED values, i.e. the bits of showo_gemm_bf16 + showo_qk_prep +
+// showo_gemm_bf16 + showo_gelu_bf16 (training/train.py:510-628 forward through models/phi.py:657-694, 208-212) in one launch.
+extern "C" int showo_gemm_qkv_fc1_save_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
+                                            const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                            const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                                            uint16_t* raw_qkv, int ldraw, uint16_t* ffn_pre, uint16_t* ffn_out, int ldf, int F, int B, int L,
+                                            int nH, int rot, float eps, int pos0, int Lcap, int Lp, int w_tiled, void* stream) {
+    if (!ffn_out || !ffn_pre || !raw_qkv) return set_error_msg(1, "gemm_qkv_fc1_save: raw_qkv, ffn_pre and ffn_out required");
+    return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
+                         pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream, raw_qkv, ldraw, ffn_pre);
 }
 
 // K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias), A0 [M,K0] (lda0), A1 [M,K1] (lda1), weight rows

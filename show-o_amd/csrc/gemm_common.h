@@ -29,6 +29,11 @@ struct GemmArgs {
     // EPI_QKV only: output columns n >= Nq are the fc1 rows of the [Wqkv ; W1] weight: bias + gelu_new -> out2[m][n - Nq] (bf16).
     // q/k/v and fc1 read the same LayerNorm output (models/phi.py:776-790).
     int Nq = 1 << 30; bf16_t* out2 = nullptr; int ldo2 = 0;
+    // EPI_QKV, training forward (showo_gemm_qkv_fc1_save_bf16): what backward needs is saved by the same launch.  raw != nullptr:
+    // raw[m][n] = bf16(A Wqkv^T + b) for n < 3 nH 64 (ldraw), and the LayerNorm / RoPE work on THESE rounded values -- the numbers
+    // showo_qkln_rope_bwd recomputes its statistics from.  pre != nullptr: pre[m][n - Nq] = bf16(A W1^T + b1) (ldo2) and
+    // out2 = gelu_new of that ROUNDED value -- the bits of the separate fc1 GEMM + showo_gelu_bf16 launches.
+    bf16_t* raw = nullptr; int ldraw = 0; bf16_t* pre = nullptr;
     // gemm2p only: W is in the tiled layout of showo_gemm_tile_weight ([ceil(N/256)][K/64][256][64] bf16, 16-B chunks pre-swizzled)
     int wtiled = 0;
     // gemm2p only: split-K for launches with few tiles (M = 631 prefill, the CLIP tower).  The grid is tiles x splits; split s of a tile
@@ -182,16 +187,48 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
         // Replaces the bf16 round trip qkv -> showo_qk_prep: LayerNorm(64) and the rotation see the fp32 accumulators.
         const int nbase = n0 + wn * 64;
         if (n0 >= g.Nq) {  // fc1 tail of the fused [Wqkv ; W1] projection (block-uniform: Nq is a multiple of the tile width)
-            const bool staged = stg != nullptr && (g.ldo2 % 8) == 0 && ((g.N - g.Nq) % 8) == 0 && ((((uintptr_t)g.out2) & 15) == 0);
+            const bool staged = stg != nullptr && (g.ldo2 % 8) == 0 && ((g.N - g.Nq) % 8) == 0 && ((((uintptr_t)g.out2) & 15) == 0) &&
+                                (!g.pre || ((((uintptr_t)g.pre) & 15) == 0));
+            if (g.pre) {  // training forward: save the pre-activation (bf16) and make the accumulators hold its rounded value
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = nbase + i * 16 + fg * 4;
+                    float bn[4];
+                    load_bias4(g, n, bn);
+#pragma unroll
+                    for (int j = 0; j < MF; ++j) {
+                        const int m = mrow0 + j * 16 + fr;
+                        uint2 pk;
+                        pk.x = pack_bf2(acc[i][j][0] + bn[0], acc[i][j][1] + bn[1]);
+                        pk.y = pack_bf2(acc[i][j][2] + bn[2], acc[i][j][3] + bn[3]);
+                        // gelu below sees bf2f(pre) - bias so that (acc + bias) reproduces the rounded value exactly
+                        acc[i][j][0] = bf2f((bf16_t)(pk.x & 0xffffu)); acc[i][j][1] = bf2f((bf16_t)(pk.x >> 16));
+                        acc[i][j][2] = bf2f((bf16_t)(pk.y & 0xffffu)); acc[i][j][3] = bf2f((bf16_t)(pk.y >> 16));
+                        if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
+                        else if (m < g.M && n < g.N) *reinterpret_cast<uint2*>(g.pre + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
+                    }
+                }
+                if (staged) {
+#pragma unroll
+                    for (int t = 0; t < 2 * MF; ++t) {
+                        const int row = t * 8 + rrow, m = mrow0 + row, n = nbase + rchunk * 8;
+                        const uint4 v = unstage_row16(stg, row, rchunk);
+                        if (m < g.M && n < g.N) *reinterpret_cast<uint4*>(g.pre + (int64_t)m * g.ldo2 + (n - g.Nq)) = v;
+                    }
+                }
+            }
+            const bool rounded = g.pre != nullptr;  // acc already holds bf16(acc + bias): no second bias add
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = nbase + i * 16 + fg * 4;
                 float bn[4];
                 load_bias4(g, n, bn);
+                if (rounded) { bn[0] = bn[1] = bn[2] = bn[3] = 0.f; }
 #pragma unroll
                 for (int j = 0; j < MF; ++j) {
                     const int m = mrow0 + j * 16 + fr;
                     uint2 pk;
+                    // (training: acc holds the rounded pre-activation and bn is 0 -> the bits of showo_gelu_bf16 on the saved tensor)
                     pk.x = pack_bf2(gelu_new_fast(acc[i][j][0] + bn[0]), gelu_new_fast(acc[i][j][1] + bn[1]));
                     pk.y = pack_bf2(gelu_new_fast(acc[i][j][2] + bn[2]), gelu_new_fast(acc[i][j][3] + bn[3]));
                     if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
@@ -233,6 +270,17 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
+                if (g.raw) {  // training forward: save bf16(qkv) for backward and continue from the rounded values
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint2 pk;
+                        pk.x = pack_bf2(x[i][0], x[i][1]);
+                        pk.y = pack_bf2(x[i][2], x[i][3]);
+                        x[i][0] = bf2f((bf16_t)(pk.x & 0xffffu)); x[i][1] = bf2f((bf16_t)(pk.x >> 16));
+                        x[i][2] = bf2f((bf16_t)(pk.y & 0xffffu)); x[i][3] = bf2f((bf16_t)(pk.y >> 16));
+                        if (valid) *reinterpret_cast<uint2*>(g.raw + (int64_t)m * g.ldraw + nbase + i * 16 + fg * 4) = pk;
+                    }
+                }
                 if (which == 2) {  // V^T[bh][d][pos]
                     if (stg_v) {  // staged transposed: [d][token] in the wave's LDS slice, stored below with the lanes along `pos`
 #pragma unroll

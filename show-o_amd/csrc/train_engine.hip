@@ -10,6 +10,7 @@
 //             (showo_transpose_bf16; the bias gradient = column sums of dY comes out of the same pass)
 // Saved per layer: x (fp32 block input), h = LN(x), raw qkv, Q, K, V^T, lse, attention output, fc1 pre-activation.
 #include "engine.h"
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -263,18 +264,32 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
         else SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, sizeof(int32_t), s));
         iv = e->iv; flag = e->flag;
     }
+    // SHOWO_TRAIN_FUSED_PROJ (default 1): the fused projection launch of the inference layer, in its save-for-backward form
+    static int fused_env = -1;
+    if (fused_env < 0) { const char* env = getenv("SHOWO_TRAIN_FUSED_PROJ"); fused_env = env ? (atoi(env) != 0) : 1; }
+    const bool fused_proj = fused_env && T >= 256 && e->cfg.rotary_dim == 32 && (3 * H) % 256 == 0 && (F % 8) == 0 &&
+                            (int64_t)T * F * 2 < ((int64_t)1 << 32);
     for (int i = 0; i < e->nL; ++i) {
         Layer& w = e->layers[i];
         LayerT& l = t->L[i];
         SHOWO_CHECK_HIP(hipMemcpyAsync(l.x, e->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
         TRY(showo_layernorm_f32_bf16(e->x, w.ln_w, w.ln_b, l.h, nullptr, T, H, e->cfg.ln_eps, s));
-        TRY(showo_gemm_bf16(l.h, H, w.wqkv, H, w.bqkv, 0, l.qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
-        TRY(showo_qk_prep(l.qkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt, B, L, nH, e->cfg.rotary_dim,
-                          e->cfg.ln_eps, 0, L, Lp, s));
-        TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
-        TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
-        TRY(showo_gemm_bf16(l.h, H, w.w1, H, w.b1, 0, l.f, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));
-        TRY(showo_gelu_bf16(l.f, e->ffn, (int64_t)T * F, s));
+        if (fused_proj) {
+            // q/k/v_proj + q/k LayerNorm + RoPE + relayout AND fc1 + gelu_new in one launch that also saves qkv and the fc1
+            // pre-activation for backward ([Wqkv ; W1] is one allocation, engine.hip); same bits as the four launches below
+            TRY(showo_gemm_qkv_fc1_save_bf16(l.h, H, w.wqkv, H, w.bqkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt,
+                                             l.qkv, 3 * H, l.f, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
+            TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
+            TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+        } else {
+            TRY(showo_gemm_bf16(l.h, H, w.wqkv, H, w.bqkv, 0, l.qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
+            TRY(showo_qk_prep(l.qkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt, B, L, nH, e->cfg.rotary_dim,
+                              e->cfg.ln_eps, 0, L, Lp, s));
+            TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
+            TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+            TRY(showo_gemm_bf16(l.h, H, w.w1, H, w.b1, 0, l.f, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));
+            TRY(showo_gelu_bf16(l.f, e->ffn, (int64_t)T * F, s));
+        }
         TRY(showo_gemm_bf16(e->ffn, F, w.w2, F, w.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
     }
     TRY(showo_layernorm_f32_bf16(e->x, e->fln_w, e->fln_b, e->hf, nullptr, T, H, e->cfg.ln_eps, s));

@@ -10,10 +10,10 @@ using namespace showo;
 
 namespace {
 
-__device__ __forceinline__ float gelu_new_f(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
-}
+// forward gelu_new of the training path = the GEMM epilogues' form (common.h: x * sigmoid(2u), within ~1e-6 relative of the tanh form,
+// far below the bf16 rounding of its result): showo_gelu_bf16, the gelu(f)^T recomputation of the dW2 operand and the
+// save-for-backward projection epilogue (showo_gemm_qkv_fc1_save_bf16) all produce the same bits
+__device__ __forceinline__ float gelu_new_f(float x) { return gelu_new_fast(x); }
 // d/dx [0.5 x (1 + tanh(u))],  u = c (x + 0.044715 x^3)
 __device__ __forceinline__ float gelu_new_grad(float x) {
     const float c = 0.7978845608028654f;

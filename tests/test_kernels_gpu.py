@@ -651,6 +651,49 @@ def test_fused_qkv_fc1_equals_separate_launches_bits(variant, B, Lq, nH, F):
     assert int(outs[1][3].ne(0).sum()) > 0.9 * M * F  # the fc1 tail was written
 
 
+@pytest.mark.parametrize("variant", [0, 256, 1160, 3192, 2224])
+def test_fused_qkv_fc1_save_matches_training_launches(variant):
+    """showo_gemm_qkv_fc1_save_bf16 (training forward): the saved qkv / fc1 pre-activation and gelu(fc1) carry the bits of the separate
+    launches (showo_gemm_bf16 x2 + showo_gelu_bf16), V^T is a pure relayout of the saved v, and Q / K (LayerNorm + RoPE of the ROUNDED
+    q / k, like showo_qk_prep) agree with showo_qk_prep on the saved qkv to bf16 rounding"""
+    torch.manual_seed(variant + 3)
+    B, Lq, nH, F = 2, 387, 4, 512
+    H, M = nH * 64, B * Lq
+    h = dev(to_bf16_bits(torch.randn(M, H)))
+    W = dev(to_bf16_bits(torch.randn(3 * H + F, H) * 0.05))
+    bias = dev(torch.randn(3 * H + F) * 0.1)
+    ln = [dev(t) for t in (torch.randn(64) * .1 + 1, torch.randn(64) * .05, torch.randn(64) * .1 + 1, torch.randn(64) * .05)]
+    cos, sin = (dev(t) for t in _rope_tables())
+    Lp = ((Lq + 63) // 64) * 64
+
+    def bufs():
+        return (torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda"), torch.zeros((B, nH, Lq, 64), dtype=torch.int16, device="cuda"),
+                torch.zeros((B, nH, 64, Lp), dtype=torch.int16, device="cuda"))
+    L().call("showo_gemm_tune", 8, variant << 8, None)
+    try:
+        Q1, K1, V1 = bufs()
+        raw1 = torch.zeros((M, 3 * H), dtype=torch.int16, device="cuda")
+        pre1 = torch.zeros((M, F), dtype=torch.int16, device="cuda")
+        ffn1 = torch.zeros((M, F), dtype=torch.int16, device="cuda")
+        L().call("showo_gemm_qkv_fc1_save_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos), L().ptr(sin),
+                 L().ptr(Q1), L().ptr(K1), L().ptr(V1), L().ptr(raw1), 3 * H, L().ptr(pre1), L().ptr(ffn1), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp, 0, S())
+        Q0, K0, V0 = bufs()
+        raw0 = torch.zeros_like(raw1); pre0 = torch.zeros_like(pre1); ffn0 = torch.zeros_like(ffn1)
+        L().call("showo_gemm_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), 0, L().ptr(raw0), 3 * H, None, 0, M, 3 * H, H, 0, S())
+        L().call("showo_qk_prep", L().ptr(raw0), *[L().ptr(t) for t in ln], L().ptr(cos), L().ptr(sin), L().ptr(Q0), L().ptr(K0), L().ptr(V0), B, Lq,
+                 nH, 32, 1e-5, 0, Lq, Lp, S())
+        L().call("showo_gemm_bf16", L().ptr(h), H, W.data_ptr() + 3 * H * H * 2, H, bias.data_ptr() + 3 * H * 4, 0, L().ptr(pre0), F, None, 0, M, F, H, 0, S())
+        L().call("showo_gelu_bf16", L().ptr(pre0), L().ptr(ffn0), M * F, S())
+        sync()
+    finally:
+        L().call("showo_gemm_tune", 8, 0, None)
+    assert torch.equal(raw1, raw0) and torch.equal(pre1, pre0) and torch.equal(ffn1, ffn0) and torch.equal(V1, V0)
+    for a, b in ((Q1, Q0), (K1, K0)):
+        fa, fb = from_bf16_bits(a).cpu(), from_bf16_bits(b).cpu()
+        assert float(fb.abs().max()) > 0.1
+        assert ((fa - fb).abs() <= 2 ** -7 * fb.abs() + 1e-6).all(), float((fa - fb).abs().max())
+
+
 SPLITK_OFF, SPLITK_ON = 64, 128  # showo_gemm_tune flag bits
 
 
