@@ -248,9 +248,9 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
     const int Lp = ((L + 63) / 64) * 64;
     if (ids) {
         SHOWO_CHECK_HIP(hipMemcpyAsync(t->ids, ids, (size_t)T * 8, hipMemcpyDeviceToDevice, s));
-        TRY(showo_embed_f32(ids, e->embed, e->x, T, H, V, s));
+        TRY(showo_embed_f32(ids, e->embed, t->L[0].x, T, H, V, s));  // layer 0's saved input IS the embedding output (no copy)
     } else {  // inputs_embeds path (modeling_showo.py:77-78, phi.py:1005-1006): the residual stream starts from the caller's rows
-        SHOWO_CHECK_HIP(hipMemcpyAsync(e->x, embeds, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SHOWO_CHECK_HIP(hipMemcpyAsync(t->L[0].x, embeds, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     t->from_embeds = ids == nullptr;
     const int32_t *iv = nullptr, *flag = nullptr;
@@ -272,25 +272,27 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
     for (int i = 0; i < e->nL; ++i) {
         Layer& w = e->layers[i];
         LayerT& l = t->L[i];
-        SHOWO_CHECK_HIP(hipMemcpyAsync(l.x, e->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-        TRY(showo_layernorm_f32_bf16(e->x, w.ln_w, w.ln_b, l.h, nullptr, T, H, e->cfg.ln_eps, s));
+        // The layer's input (saved for ln_bwd) lives in l.x already: the previous layer's fc2 epilogue wrote it there.  The residual
+        // stream ping-pongs l.x -> e->x (after dense) -> L[i + 1].x (after fc2; e->x for the last layer): no 92 MB copy per layer.
+        float* xnext = (i + 1 < e->nL) ? t->L[i + 1].x : e->x;
+        TRY(showo_layernorm_f32_bf16(l.x, w.ln_w, w.ln_b, l.h, nullptr, T, H, e->cfg.ln_eps, s));
         if (fused_proj) {
             // q/k/v_proj + q/k LayerNorm + RoPE + relayout AND fc1 + gelu_new in one launch that also saves qkv and the fc1
             // pre-activation for backward ([Wqkv ; W1] is one allocation, engine.hip); same bits as the four launches below
             TRY(showo_gemm_qkv_fc1_save_bf16(l.h, H, w.wqkv, H, w.bqkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt,
                                              l.qkv, 3 * H, l.f, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
             TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
-            TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+            TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, l.x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
         } else {
             TRY(showo_gemm_bf16(l.h, H, w.wqkv, H, w.bqkv, 0, l.qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
             TRY(showo_qk_prep(l.qkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt, B, L, nH, e->cfg.rotary_dim,
                               e->cfg.ln_eps, 0, L, Lp, s));
             TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
-            TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+            TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, l.x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
             TRY(showo_gemm_bf16(l.h, H, w.w1, H, w.b1, 0, l.f, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));
             TRY(showo_gelu_bf16(l.f, e->ffn, (int64_t)T * F, s));
         }
-        TRY(showo_gemm_bf16(e->ffn, F, w.w2, F, w.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+        TRY(showo_gemm_bf16(e->ffn, F, w.w2, F, w.b2, 0, xnext, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
     }
     TRY(showo_layernorm_f32_bf16(e->x, e->fln_w, e->fln_b, e->hf, nullptr, T, H, e->cfg.ln_eps, s));
     TRY(showo_gemm_bf16(e->hf, H, e->wlm, H, e->blm, 0, t->logits, V, nullptr, 0, T, V, H, SHOWO_EPI_F32, s));
