@@ -335,6 +335,11 @@ void showo_engine_destroy(showo_engine* e);
  * "showo.model.layers.3.self_attn.q_proj.weight"; src = device fp32, n = element count.  GEMM weights are
  * converted to bf16 and q/k/v are packed into one [3H,H] matrix.  cos/sin tables: keys "rope.cos"/"rope.sin". */
 int showo_engine_load(showo_engine* e, const char* key, const float* src, int64_t n, void* stream);
+/* Where showo_engine_load would put a tensor, without copying: exactly one of *dst_bf16 (weight image) / *dst_f32 (vector, embedding
+ * table) is set.  The trainer's fused optimizer launch writes the refreshed images through these pointers and then calls
+ * showo_engine_weights_touched (the bookkeeping showo_engine_load does: fused weight images / cached graphs are rebuilt). */
+int showo_engine_slot(showo_engine* e, const char* key, int64_t n, uint16_t** dst_bf16, float** dst_f32);
+int showo_engine_weights_touched(showo_engine* e);
 /* number of tensors still missing (0 = ready) */
 int showo_engine_missing(const showo_engine* e);
 /* number of times showo_engine_t2i_generate captured a denoise step into a hipGraph on this engine (the instantiated graph is

@@ -103,6 +103,8 @@ _PROTOS = {
     "showo_argmax_f32": [c_p, c_i, c_p, c_p],
     "showo_engine_create": [c_p, C.POINTER(c_p)],
     "showo_engine_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
+    "showo_engine_slot": [c_p, c_p, c_i64, c_p, c_p],
+    "showo_engine_weights_touched": [c_p],
     "showo_engine_missing": [c_p],
     "showo_engine_t2i_captures": [c_p],
     "showo_engine_set_collect": [c_p, c_p],

@@ -112,3 +112,11 @@ namespace showo {
 int set_error_hip(hipError_t e, const char* what, const char* file, int line);
 int set_error_msg(int code, const char* msg);
 }
+
+// multi-tensor AdamW (train_kernels.hip adamw_multi_kernel; table built by train_engine.hip)
+namespace showo {
+struct AdamSeg { float *p, *m, *v; const float* g; bf16_t* dst16; float* dst32; int64_t n; int decay; };
+constexpr int64_t ADAM_CHUNK = 65536;  // elements per block
+int adamw_multi_launch(const AdamSeg* segs, const int* seg_of, const int64_t* start_of, int nchunks, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, hipStream_t s);
+}  // namespace showo

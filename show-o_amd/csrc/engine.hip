@@ -225,6 +225,54 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     return rc;
 }
 
+// Destination of a state-dict tensor inside the engine, without copying: bf16 weight image OR fp32 vector (exactly one is set).
+// Used by the trainer's fused optimizer step, which writes the refreshed images itself (train_engine.hip).
+extern "C" int showo_engine_slot(showo_engine* e, const char* key, int64_t n, uint16_t** dst_bf16, float** dst_f32) {
+    if (!e || !key || !dst_bf16 || !dst_f32) return set_error_msg(1, "engine_slot: null argument");
+    const int64_t H = e->H, F = e->F, V = e->V;
+    *dst_bf16 = nullptr; *dst_f32 = nullptr;
+    std::string k(key);
+    int64_t expect = -1;
+    int li = -1;
+    char sub[128];
+    if (k == "showo.model.embed_tokens.weight") { *dst_f32 = e->embed; expect = V * H; }
+    else if (k == "showo.model.final_layernorm.weight") { *dst_f32 = e->fln_w; expect = H; }
+    else if (k == "showo.model.final_layernorm.bias") { *dst_f32 = e->fln_b; expect = H; }
+    else if (k == "showo.lm_head.weight") { *dst_bf16 = e->wlm; expect = V * H; }
+    else if (k == "showo.lm_head.bias") { *dst_f32 = e->blm; expect = V; }
+    else if (sscanf(key, "showo.model.layers.%d.%127s", &li, sub) == 2 && li >= 0 && li < e->nL) {
+        showo::Layer& l = e->layers[li];
+        std::string t(sub);
+        if (t == "self_attn.q_proj.weight") { *dst_bf16 = l.wqkv; expect = H * H; }
+        else if (t == "self_attn.k_proj.weight") { *dst_bf16 = l.wqkv + H * H; expect = H * H; }
+        else if (t == "self_attn.v_proj.weight") { *dst_bf16 = l.wqkv + 2 * H * H; expect = H * H; }
+        else if (t == "self_attn.q_proj.bias") { *dst_f32 = l.bqkv; expect = H; }
+        else if (t == "self_attn.k_proj.bias") { *dst_f32 = l.bqkv + H; expect = H; }
+        else if (t == "self_attn.v_proj.bias") { *dst_f32 = l.bqkv + 2 * H; expect = H; }
+        else if (t == "self_attn.dense.weight") { *dst_bf16 = l.wd; expect = H * H; }
+        else if (t == "self_attn.dense.bias") { *dst_f32 = l.bd; expect = H; }
+        else if (t == "self_attn.q_layernorm.weight") { *dst_f32 = l.qln_w; expect = 64; }
+        else if (t == "self_attn.q_layernorm.bias") { *dst_f32 = l.qln_b; expect = 64; }
+        else if (t == "self_attn.k_layernorm.weight") { *dst_f32 = l.kln_w; expect = 64; }
+        else if (t == "self_attn.k_layernorm.bias") { *dst_f32 = l.kln_b; expect = 64; }
+        else if (t == "mlp.fc1.weight") { *dst_bf16 = l.w1; expect = F * H; }
+        else if (t == "mlp.fc1.bias") { *dst_f32 = l.b1; expect = F; }
+        else if (t == "mlp.fc2.weight") { *dst_bf16 = l.w2; expect = H * F; }
+        else if (t == "mlp.fc2.bias") { *dst_f32 = l.b2; expect = H; }
+        else if (t == "input_layernorm.weight") { *dst_f32 = l.ln_w; expect = H; }
+        else if (t == "input_layernorm.bias") { *dst_f32 = l.ln_b; expect = H; }
+    }
+    if (expect < 0) return set_error_msg(3, "engine_slot: unknown state-dict key");
+    if (expect != n) return set_error_msg(2, "engine_slot: element count mismatch");
+    return 0;
+}
+// the caller rewrote weight images through showo_engine_slot pointers: same bookkeeping as showo_engine_load
+extern "C" int showo_engine_weights_touched(showo_engine* e) {
+    if (!e) return set_error_msg(1, "engine: null handle");
+    e->fused_valid = false;
+    return 0;
+}
+
 namespace {
 __global__ void add2_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

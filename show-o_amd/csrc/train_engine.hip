@@ -47,6 +47,11 @@ struct showo_trainer {
     bf16_t* wlmT = nullptr;
     std::map<std::string, Grad> grads;
     std::vector<Bound> bound;  // master weights + AdamW moments registered by the host (showo_train_bind_param)
+    showo::AdamSeg* adam_segs = nullptr;  // device tables of the multi-tensor optimizer launch (train_kernels.hip, adamw_multi_kernel)
+    int* adam_seg_of = nullptr;
+    int64_t* adam_start_of = nullptr;
+    int adam_chunks = 0;
+    bool adam_dirty = true;
     // head
     float *logits = nullptr, *gembed = nullptr, *gfln = nullptr, *gwlm = nullptr, *gblm = nullptr;
     bf16_t *dlogits = nullptr, *bigT = nullptr;  // bigT: [max(Vp, F), Tp] transposed image of the dY side
@@ -190,6 +195,7 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
 extern "C" void showo_train_destroy(showo_trainer* t) {
     if (!t) return;
     for (void* p : t->allocs) hipFree(p);
+    if (t->adam_segs) { hipFree(t->adam_segs); hipFree(t->adam_seg_of); hipFree(t->adam_start_of); }
     delete t;
 }
 
@@ -454,6 +460,7 @@ extern "C" int showo_train_bind_param(showo_trainer* t, const char* key, float* 
     const char* nd[4] = {"bias", "layer_norm.weight", "mlm_ln.weight", "embeddings.weight"};
     bool decay = true;
     for (const char* x : nd) decay = decay && k.find(x) == std::string::npos;
+    t->adam_dirty = true;  // the optimizer's segment table is rebuilt by the next step
     for (auto& b : t->bound)
         if (b.key == k) { b.p = param; b.m = exp_avg; b.v = exp_avg_sq; b.n = n; b.decay = decay; return 0; }
     t->bound.push_back(Bound{k, param, exp_avg, exp_avg_sq, n, decay});
@@ -466,6 +473,41 @@ extern "C" int showo_train_adamw_step(showo_trainer* t, float lr, float beta1, f
                                       void* stream) {
     if (!t) return set_error_msg(1, "train_adamw_step: null handle");
     if (t->bound.empty()) return set_error_msg(1, "train_adamw_step: no parameters bound");
+    // SHOWO_TRAIN_ADAMW_MULTI (default 1): one launch over a segment table instead of one adamw + one image refresh per tensor
+    static int multi = -1;
+    if (multi < 0) { const char* env = getenv("SHOWO_TRAIN_ADAMW_MULTI"); multi = env ? (atoi(env) != 0) : 1; }
+    if (multi) {
+        hipStream_t s = (hipStream_t)stream;
+        if (t->adam_dirty) {  // (re)build the table: segments = bound tensors with their engine destinations, chunks of ADAM_CHUNK elements
+            std::vector<showo::AdamSeg> segs;
+            std::vector<int> seg_of;
+            std::vector<int64_t> start_of;
+            for (auto& b : t->bound) {
+                showo::AdamSeg sg{b.p, b.m, b.v, t->grads[b.key].p, nullptr, nullptr, b.n, b.decay ? 1 : 0};
+                uint16_t* d16 = nullptr;
+                TRY(showo_engine_slot(t->e, b.key.c_str(), b.n, &d16, &sg.dst32));
+                sg.dst16 = d16;
+                for (int64_t st = 0; st < b.n; st += showo::ADAM_CHUNK) { seg_of.push_back((int)segs.size()); start_of.push_back(st); }
+                segs.push_back(sg);
+            }
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            hipStreamIsCapturing(s, &cs);
+            if (cs != hipStreamCaptureStatusNone) return set_error_msg(7, "train_adamw_step: the segment table must be built outside a stream capture");
+            if (t->adam_segs) { hipFree(t->adam_segs); hipFree(t->adam_seg_of); hipFree(t->adam_start_of); }
+            SHOWO_CHECK_HIP(hipMalloc(&t->adam_segs, segs.size() * sizeof(showo::AdamSeg)));
+            SHOWO_CHECK_HIP(hipMalloc(&t->adam_seg_of, seg_of.size() * sizeof(int)));
+            SHOWO_CHECK_HIP(hipMalloc(&t->adam_start_of, start_of.size() * sizeof(int64_t)));
+            SHOWO_CHECK_HIP(hipMemcpy(t->adam_segs, segs.data(), segs.size() * sizeof(showo::AdamSeg), hipMemcpyHostToDevice));
+            SHOWO_CHECK_HIP(hipMemcpy(t->adam_seg_of, seg_of.data(), seg_of.size() * sizeof(int), hipMemcpyHostToDevice));
+            SHOWO_CHECK_HIP(hipMemcpy(t->adam_start_of, start_of.data(), start_of.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            t->adam_chunks = (int)seg_of.size();
+            t->adam_dirty = false;
+        }
+        TRY(showo::adamw_multi_launch(t->adam_segs, t->adam_seg_of, t->adam_start_of, t->adam_chunks, lr, beta1, beta2, eps, weight_decay, step, s));
+        TRY(showo_engine_weights_touched(t->e));
+        t->weights_synced = false;
+        return 0;
+    }
     for (auto& b : t->bound) {
         const Grad& g = t->grads[b.key];
         TRY(showo_adamw(b.p, g.p, b.m, b.v, b.n, lr, beta1, beta2, eps, b.decay ? weight_decay : 0.f, step, stream));

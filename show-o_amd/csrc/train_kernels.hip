@@ -437,6 +437,33 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// Multi-tensor form: ONE launch updates every bound parameter and writes the engine's refreshed weight image (bf16 cast or fp32 copy)
+// from the register that holds the new master value -- 437 adamw launches + 181 casts + 256 copies per step become one kernel, and the
+// 5.8 GB of master weights are not read a second time by the cast.  Same expressions as adamw_kernel element by element (same bits).
+// chunk c = (segment seg_of[c], elements [start_of[c], start_of[c] + ADAM_CHUNK)).
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const showo::AdamSeg* __restrict__ segs, const int* __restrict__ seg_of,
+                                                          const int64_t* __restrict__ start_of, float lr, float beta1, float beta2, float eps,
+                                                          float wd_all, float bc1, float bc2) {
+    const showo::AdamSeg sg = segs[seg_of[blockIdx.x]];
+    const int64_t i0 = start_of[blockIdx.x];
+    const int64_t i1 = i0 + showo::ADAM_CHUNK < sg.n ? i0 + showo::ADAM_CHUNK : sg.n;
+    const float wd = sg.decay ? wd_all : 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float w = sg.p[i];
+        const float gr = sg.g[i];
+        w *= 1.0f - lr * wd;
+        const float mm = beta1 * sg.m[i] + (1.0f - beta1) * gr;
+        const float vv = beta2 * sg.v[i] + (1.0f - beta2) * gr * gr;
+        sg.m[i] = mm;
+        sg.v[i] = vv;
+        const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+        const float pn = w - (lr / bc1) * (mm / denom);
+        sg.p[i] = pn;
+        if (sg.dst16) sg.dst16[i] = f2bf(pn);
+        else if (sg.dst32) sg.dst32[i] = pn;
+    }
+}
+
 __global__ void scale_f32_kernel(float* __restrict__ x, int64_t n, float s) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -564,6 +591,19 @@ extern "C" int showo_adamw(float* p, const float* g, float* m, float* v, int64_t
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+namespace showo {
+int adamw_multi_launch(const AdamSeg* segs, const int* seg_of, const int64_t* start_of, int nchunks, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, hipStream_t s) {
+    if (nchunks <= 0) return 0;
+    if (step < 1) return set_error_msg(1, "adamw: step counts from 1");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_multi_kernel<<<dim3(nchunks), dim3(256), 0, s>>>(segs, seg_of, start_of, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error_hip(e, "adamw_multi launch", __FILE__, __LINE__);
+    return 0;
+}
+}  // namespace showo
 
 extern "C" int showo_scale_f32(float* x, int64_t n, float s, void* stream) {
     if (n <= 0) return 0;
