@@ -1,6 +1,6 @@
 #!/bin/bash
-# round-2 GPU pass 3I: confirmation of the last build (training forward through the fused projection): full GPU suite, smoke, headline line (with train_step and cpu_baseline), train line
-TAG=${1:-r3i}
+# round-2 GPU pass 3L: confirmation of the last build: full GPU suite, smoke, headline line (with train_step and cpu_baseline), train line
+TAG=${1:-r3l}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/tests_$TAG.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/tests_$TAG.log | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
