@@ -511,3 +511,47 @@ def test_bench_training_leg_child_launch(monkeypatch):
 
     monkeypatch.setattr(subprocess, "Popen", Hung)
     assert "timed out" in bench.train_leg(2, 0)["error"] and seen.get("killed")
+
+
+def test_measurement_tools_parse_their_inputs(tmp_path):
+    """tools/power_trace.py (sysfs / rocm-smi parsing, summary statistics) and tools/pmc_summary.py (per-kernel HBM traffic with the
+    gfx950 FETCH_SIZE correction, GEMM family grouped over gemm2p + gemm3w) on synthetic inputs"""
+    import csv
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(util.ROOT, "tools", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    pt = load("power_trace")
+    assert pt.dpm_current("0: 500Mhz\n1: 2381Mhz *\n2: 2400Mhz") == 2381 and pt.dpm_current("S: 117Mhz *\n0: 500Mhz") == 117
+    assert pt.dpm_current(None) is None and pt.dpm_current("0: 500Mhz") is None
+    st = pt.stats([float(i) for i in range(1, 101)])
+    assert st["n"] == 100 and st["min"] == 1.0 and st["max"] == 100.0 and st["median"] == 51.0 and abs(st["mean"] - 50.5) < 1e-9
+    out = tmp_path / "trace.json"
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "power_trace.py"), str(out), "--", sys.executable, "-c", "print(1)"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.load(open(out))["summary"]["rc"] == 0
+
+    fd, wd = tmp_path / "f", tmp_path / "w"
+    for d, counter, vals in ((fd, "FETCH_SIZE", (1000.0, 3000.0, 500.0)), (wd, "WRITE_SIZE", (100.0, 300.0, 50.0))):
+        os.makedirs(d)
+        with open(d / "x_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writerow(["void showo::(anonymous namespace)::gemm2p_kernel<3, 5, 4, true>(showo::GemmArgs)", counter, vals[0]])
+            w.writerow(["void showo::(anonymous namespace)::gemm3w_kernel<4, 6, 6, true, false>(showo::GemmArgs)", counter, vals[1]])
+            w.writerow(["void (anonymous namespace)::attn_fwd_lds_kernel<4, 4>((anonymous namespace)::AttnArgs)", counter, vals[2]])
+    res = tmp_path / "traffic.json"
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "pmc_summary.py"), "tag", str(fd), str(wd), str(res)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    t = json.load(open(res))
+    g = t["gemm2p_kernel"]  # both kernels of the family, launch-weighted; fetch = 2 x KiB x 1024, write = KiB x 1024
+    assert g["launches"] == 2 and abs(g["fetch_bytes_per_launch"] - 2 * 1024 * 2000.0) < 1e-6 and abs(g["write_bytes_per_launch"] - 1024 * 200.0) < 1e-6
+    assert abs(t["attn_fwd_lds_kernel"]["bytes_per_launch"] - (2 * 1024 * 500.0 + 1024 * 50.0)) < 1e-6
