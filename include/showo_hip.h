@@ -77,6 +77,11 @@ int showo_gemm_set_impl(int impl);
  * launches with few tiles off / on (default on: tiles x splits ~ 256 blocks, partials summed in split order by the last block). */
 int showo_gemm_tune(int gn, int flags, unsigned long long* dbg);
 
+/* Launch counters of the production GEMM family (gemm2p / gemm3w): out3[0] = launches, out3[1] = of those the fused [Wqkv ; W1]
+ * save-for-backward form (showo_gemm_qkv_fc1_save_bf16), out3[2] = launches that split K; reset != 0 zeroes them after reading.
+ * Parity tests use it to assert that a training batch ran the T >= 256 kernels that the benchmark times. */
+int showo_gemm_counters(int64_t* out3, int reset);
+
 /* Split-precision forms (VQGAN path): every operand is a (hi, lo) bf16 pair, x = hi + lo to ~2^-17; the MFMA
  * accumulates hi*hi + hi*lo + lo*hi in fp32.  fp32 output, optional residual.  Same layouts as the plain calls. */
 int showo_gemm_bf16x3(const uint16_t* A, const uint16_t* Alo, int lda, const uint16_t* W, const uint16_t* Wlo, int ldw,
@@ -118,7 +123,9 @@ int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ld
 /* showo_gemm_qkv_bf16 and fc1 + gelu_new in ONE launch: PhiDecoderLayer feeds the same LayerNorm output to q/k/v_proj and to
  * mlp.fc1 (models/phi.py:776-790, 208-212), so the weight is the row concatenation [Wqkv ; W1] bf16 [3*nH*64 + F, ldw] (bias
  * fp32 [3*nH*64 + F]); output columns below 3*nH*64 take the QKV epilogue above, the others
- * ffn_out bf16 [B*L, ldf] = gelu_new(A W1^T + b1).  Results are bit-identical to the two separate launches.
+ * ffn_out bf16 [B*L, ldf] = gelu_new(A W1^T + b1).  Results are bit-identical to the two separate launches whenever both sides
+ * use the same k-partition: always with SHOWO_GEMM_SPLITK=0, and otherwise unless the narrower separate launch is a split-K shape
+ * (few tiles, K >= 2048: the split count is a function of (M, N, K) only, never of the tile variant the tuner picks).
  * w_tiled = 1: Wqkv_fc1 is the tiled copy made by showo_gemm_tile_weight (ldw must equal K = nH*64). */
 int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
                             const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,

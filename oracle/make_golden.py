@@ -603,6 +603,72 @@ def make_magvit_256():
                         image_rms=float(img.pow(2).mean().sqrt()))
 
 
+def make_small_train():
+    """Production-path training fixture: the REFERENCE's losses and gradients on a mixed 6 t2i + 2 lm + 4 mmu batch
+    of 12 x 27 = 324 token rows on the SMALL geometry (hidden 256: 3 * hidden is a multiple of the 256-wide GEMM tile, every GEMM
+    dimension >= 256), i.e. a batch the HIP trainer runs through its T >= 256 branch: fused [Wqkv ; W1] save-for-backward launch,
+    gemm2p / gemm3w forward + dgrad + wgrad (K = token count), multi-block transposes.  -> tests/golden/showo_small_train.npz"""
+    print("[small showo, 324-row training batch]")
+    d = Wt.ShowoDims(**Wt.SMALL)
+    sd_np = Wt.make_showo_state(d, seed=13)
+    ref = ref_showo_from_state(d, sd_np)
+    P = R.load_reference().prompting
+    sd = O.to_torch(sd_np)
+    rs = np.random.RandomState(17)
+    N = d.num_vq_tokens
+    bt, bl, bm = 6, 2, 4
+    img_gt = rs.randint(0, d.codebook, size=(bt, N)) + d.image_offset
+    masked = rs.rand(bt, N) < rs.uniform(0.2, 0.95, size=(bt, 1))
+    masked[:, 0] = True  # at least one masked position per row (training/utils.py:101-102)
+    img_in = np.where(masked, d.mask_token_id, img_gt)
+    ids_t = t2i_ids(d, [6, 9, 3, 8, 5, 7], rs, image_tokens=img_in)
+    L = ids_t.shape[1]
+    lab_t = ids_t.clone()
+    lab_t[:, -(N + 1):-1] = torch.from_numpy(np.where(masked, img_gt, -100))
+    lab_t[lab_t == d.pad_id] = -100
+    ids_l = torch.from_numpy(rs.randint(0, d.llm_vocab - 20, size=(bl, L))).long()
+    ids_l[1, :5] = d.pad_id  # a left-padded lm row
+    lab_l = ids_l.clone()
+    lab_l[lab_l == d.pad_id] = -100
+    ids_u = mmu_ids(d, bm, L - N - 4, rs)
+    lab_u = ids_u.clone()
+    lab_u[:, : N + 3] = -100
+    ids_all = torch.cat([ids_t, ids_l, ids_u])
+    labels = torch.cat([lab_t, lab_l, lab_u])
+    assert ids_all.shape[0] * L >= 256
+    m_t = P.create_attention_mask_predict_next(ids_t, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id, rm_pad_in_image=True)
+    m_l = P.create_attention_mask_predict_next(ids_l, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id)
+    m_u = P.create_attention_mask_for_mmu(ids_u, eoi_id=d.eoi_id)
+    mask_all = torch.cat([m_t, m_l, m_u]).float()
+    ref.zero_grad()
+    lg, l1, l2, l3 = ref(ids_all, attention_mask=mask_all, labels=labels, batch_size_t2i=bt, batch_size_lm=bl, batch_size_mmu=bm,
+                         max_seq_length=d.max_text_len)
+    (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    o = O.showo_forward(sd, d, ids_all, attention_mask=mask_all, labels=labels, batch_size_t2i=bt, batch_size_lm=bl,
+                        batch_size_mmu=bm, max_seq_length=d.max_text_len)
+    assert report("logits", o[0], lg.detach()) < 2e-4
+    for n_, a, b in zip(("loss_t2i", "loss_lm", "loss_mmu"), o[1:], (l1, l2, l3)):
+        assert report(n_, a, b.detach()) < 1e-4
+    out = dict(ids=ids_all.numpy(), labels=labels.numpy(), mask=mask_all.numpy(), b=np.array([bt, bl, bm]),
+               logits_s=lg.detach()[:, ::3].contiguous().numpy(),  # every third position: keeps the file small
+               losses=np.array([l1.item(), l2.item(), l3.item()], dtype=np.float64))
+    big = ("showo.model.layers.0.self_attn.q_proj.weight", "showo.model.layers.1.self_attn.v_proj.weight",
+           "showo.model.layers.0.self_attn.dense.weight", "showo.model.layers.1.mlp.fc1.weight", "showo.model.layers.0.mlp.fc2.weight",
+           "showo.model.layers.1.self_attn.k_proj.weight")
+    for k, v in grads.items():
+        if k in big or (v.dim() == 1 and "embed" not in k):
+            out["grad::" + k] = v.numpy()
+    rows = torch.unique(ids_all.reshape(-1))[:24]
+    out["grad::embed_row_ids"] = rows.numpy()
+    out["grad::embed_rows"] = grads["showo.model.embed_tokens.weight"][rows].numpy()
+    hrows = torch.arange(0, d.vocab, 7)
+    out["grad::lm_head_row_ids"] = hrows.numpy()
+    out["grad::lm_head_rows"] = grads["showo.lm_head.weight"][hrows].numpy()
+    np.savez_compressed(os.path.join(GOLD, "showo_small_train.npz"), **out)
+    print("  rows", ids_all.shape[0] * L, "losses", out["losses"], "tensors", len(out))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
@@ -626,6 +692,8 @@ if __name__ == "__main__":
         make_tiny_inpaint()
     if a.only in ("", "magvit256"):
         make_magvit_256()
+    if a.only in ("", "small_train"):
+        make_small_train()
     if a.full or a.only == "full":
         make_full_showo()
     print("done")

@@ -64,6 +64,10 @@ class ShowoDims:
 FULL = dict()  # defaults of ShowoDims = full-size Show-o
 TINY = dict(hidden=128, layers=2, heads=2, ffn=256, vocab=439, llm_vocab=300, codebook=128,
             num_vq_tokens=16, max_text_len=8, max_pos=2048)
+# smallest geometry whose >= 256-row batches take the PRODUCTION kernels of the training step: 3 * hidden is a multiple of the 256-wide
+# GEMM tile (fused [Wqkv ; W1] save-for-backward launch) and every GEMM dimension is >= 256 (gemm2p / gemm3w forward, dgrad, wgrad)
+SMALL = dict(hidden=256, layers=2, heads=4, ffn=512, vocab=439, llm_vocab=300, codebook=128,
+             num_vq_tokens=16, max_text_len=8, max_pos=2048)
 
 
 def showo_state_spec(d: ShowoDims):

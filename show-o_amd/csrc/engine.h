@@ -91,16 +91,31 @@ struct showo_engine {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fc1 = nullptr;
     float* y2 = nullptr;  // forked decode layer: fc2 + b2 of the current layer
-    // hipGraph replay of the denoise step: the instantiated graph of one active-rows step is cached, keyed by everything baked
-    // into its launches (shapes, scalars, every pointer that is not engine-owned-and-fixed)
+    // hipGraph replay of the denoise step: instantiated graphs of one active-rows step are cached (small LRU), keyed by everything
+    // BAKED into their launches: shapes, scalars, and every pointer that is neither engine-owned-and-fixed nor refreshed per call.
+    // With prefix reuse the captured step reads its visibility intervals from the engine's own gathered copy (iv_act, rewritten by
+    // every call), so the caller's mask / interval pointers are NOT part of the key: a caller that builds a fresh, equal mask tensor
+    // per batch (reference inference_t2i.py:290-318) replays the same graph.  Without reuse the step reads the caller's intervals /
+    // dense mask directly and their pointers stay in the key.
     struct T2IGraphKey {
-        int nseq, L, N, prefix, steps, id_offset, codebook, reuse;
+        int B, nseq, L, N, prefix, steps, id_offset, codebook, reuse, cfg, has_iv;
         int64_t mask_id;
         float guidance;
         const void* p[11];
     };
-    T2IGraphKey t2i_key{};
-    hipGraphExec_t t2i_exec = nullptr;
+    struct T2IGraphEntry {
+        T2IGraphKey key;
+        hipGraphExec_t exec;
+        uint64_t last_use;
+    };
+    static constexpr int T2I_GRAPH_SLOTS = 6;  // full / ragged last batch x CFG on / off x reuse on / off never thrash
+    std::vector<T2IGraphEntry> t2i_graphs;
+    uint64_t t2i_tick = 0;
+    // deferred prefix check of t2i_generate: the device flag lands in pinned host memory behind an event; the host looks at it only
+    // after every step of the call is queued (no pipeline bubble), and repeats the call without prefix reuse in the (never yet seen)
+    // case that a text row can see an image column
+    int32_t* pfx_host = nullptr;
+    hipEvent_t ev_pfx = nullptr;
     float* collect = nullptr;  // parity hook (showo_engine_set_collect)
     int t2i_captures = 0;  // how often a denoise step was captured (tests: a second identical call must not capture again)
     int* step_dev = nullptr;

@@ -93,6 +93,13 @@ __global__ void decode_iv_kernel(const int32_t* __restrict__ last_iv, int L0, co
 __global__ void store_token_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ out, const int* __restrict__ pos, int base) {
     if (threadIdx.x == 0) out[*pos - base] = *tok;
 }
+// per-call constants of the graph-replayed denoise loop, passed BY VALUE as kernel arguments (no host staging buffer to keep alive,
+// no stream synchronisation): sched[0..n) = mask_len_f | temperature per step, hdr = step index | pad | seed lo | seed hi
+struct SchedArgs { float v[512]; int hdr[4]; int n; };
+__global__ void sched_upload_kernel(SchedArgs a, float* __restrict__ sched, int* __restrict__ hdr) {
+    for (int i = threadIdx.x; i < a.n; i += blockDim.x) sched[i] = a.v[i];
+    if (threadIdx.x < 4) hdr[threadIdx.x] = a.hdr[threadIdx.x];
+}
 __global__ void copy_i64_kernel(const int64_t* s, int64_t* d, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = s[i];
@@ -151,7 +158,10 @@ extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** 
 
 extern "C" void showo_engine_destroy(showo_engine* e) {
     if (!e) return;
-    if (e->t2i_exec) hipGraphExecDestroy(e->t2i_exec);
+    for (auto& ge : e->t2i_graphs)
+        if (ge.exec) hipGraphExecDestroy(ge.exec);
+    if (e->ev_pfx) hipEventDestroy(e->ev_pfx);
+    if (e->pfx_host) hipHostFree(e->pfx_host);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_fc1) hipEventDestroy(e->ev_fc1);
     if (e->side) hipStreamDestroy(e->side);
@@ -615,11 +625,6 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
         TRY(e->alloc(&e->row_logits, e->row_logits_cap));
     }
     const int thr = 256;
-    build_ids_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(ids_cond, cfg ? ids_uncond : nullptr, e->ids_all, B, L,
-                                                                       text_len + 1);
-    init_cur_kernel<<<dim3((B * N + thr - 1) / thr), dim3(thr), 0, s>>>(ids_cond, L, img_start, mask_id, id_offset, e->cur, N, B * N);
-    rows_index_kernel<<<dim3((nrows + thr - 1) / thr), dim3(thr), 0, s>>>(e->rows, nseq, L, img_start, N);
-    SHOWO_CHECK_HIP(hipGetLastError());
     const int32_t *iv = nullptr, *flag = nullptr;
     if (mask) {
         TRY(showo_mask_compress(mask, e->iv, e->flag, nseq, L, L, s));  // the mask is step-invariant: compress once
@@ -633,21 +638,37 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     // only the rows [prefix, L) (soi, image tokens, eoi: 258 of 387 at 256x256) against the cached text keys.  Exact up to the
     // grouping of rows into tiles (same arithmetic per row); checked on the device: interval masks only, no prefix row may see
     // a column >= prefix.  use_graph bit 1 disables it.
+    // The check is DEFERRED: its flag travels to pinned host memory behind an event and is read after every step of the call has
+    // been queued (the GPU never waits for the host); in the case that it fires the call is repeated without reuse -- ids_cond /
+    // sampled_out are only written at the very end, so nothing of the optimistic attempt is visible to the caller.
     const int prefix = text_len + 1;
     const int La = L - prefix;
-    bool reuse = !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
-    if (reuse && !e->pfx_flag) {
+    const int LpC = ((L + 63) / 64) * 64;
+    const bool reuse_ok = !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
+    hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cs0);
+    if (cs0 != hipStreamCaptureStatusNone) return set_error_msg(7, "t2i_generate: the call captures its own graph; do not call it inside a stream capture");
+    TRY(fused_sync(e, s));  // weight images of the fused launches: rebuilt here (never inside a capture), so cached graphs stay valid
+    if (reuse_ok && !e->pfx_flag) {
         TRY(e->alloc(&e->pfx_flag, 4));
+        SHOWO_CHECK_HIP(hipHostMalloc((void**)&e->pfx_host, 64, hipHostMallocDefault));
+        SHOWO_CHECK_HIP(hipEventCreateWithFlags(&e->ev_pfx, hipEventDisableTiming));
     }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool reuse = reuse_ok && attempt == 0;
+    bool check_pending = false;
+    build_ids_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(ids_cond, cfg ? ids_uncond : nullptr, e->ids_all, B, L,
+                                                                       text_len + 1);
+    init_cur_kernel<<<dim3((B * N + thr - 1) / thr), dim3(thr), 0, s>>>(ids_cond, L, img_start, mask_id, id_offset, e->cur, N, B * N);
+    rows_index_kernel<<<dim3((nrows + thr - 1) / thr), dim3(thr), 0, s>>>(e->rows, nseq, L, img_start, N);
+    SHOWO_CHECK_HIP(hipGetLastError());
     if (reuse && iv) {
-        int32_t hflag = 0;
         SHOWO_CHECK_HIP(hipMemsetAsync(e->pfx_flag, 0, sizeof(int32_t), s));
         prefix_check_kernel<<<dim3((nseq * prefix + thr - 1) / thr), dim3(thr), 0, s>>>(iv, flag, e->pfx_flag, nseq, L, prefix);
-        SHOWO_CHECK_HIP(hipMemcpyAsync(&hflag, e->pfx_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SHOWO_CHECK_HIP(hipStreamSynchronize(s));
-        if (hflag) reuse = false;
+        SHOWO_CHECK_HIP(hipMemcpyAsync(e->pfx_host, e->pfx_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SHOWO_CHECK_HIP(hipEventRecord(e->ev_pfx, s));
+        check_pending = true;
     }
-    const int LpC = ((L + 63) / 64) * 64;
     KVDest kvc = kv_workspace(e, L);
     if (reuse) {
         const int64_t kn = (int64_t)e->nL * nseq * e->nH * L * 64, vn = (int64_t)e->nL * nseq * e->nH * 64 * LpC;
@@ -685,31 +706,50 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
         return 0;
     };
     // hipGraph path (the default of Showo.t2i_generate): ONE denoise step -- every row from <soi> on, ~80 kernels -- is captured with
-    // everything that changes from step to step or call to call in device memory (step index, schedule constants, seed) and the
-    // instantiated graph is CACHED on the engine, keyed by every launch argument baked into it; later calls with the same key
-    // replay it without capturing again.  The eager steps before a capture (2 with prefix reuse: the full step 0 and one
-    // active-rows step) launch every kernel variant once (first-use attributes, GEMM tile tuning) outside the capture; step 0
-    // always runs eagerly.  Not combined with per-launch event timing.
+    // everything that changes from step to step or call to call in device memory (step index, schedule constants, seed, the gathered
+    // visibility intervals) and the instantiated graph is CACHED on the engine (LRU of T2I_GRAPH_SLOTS), keyed by every launch
+    // argument baked into it; later calls with the same key replay it without capturing again and without a host synchronisation.
+    // The eager steps before a capture (2 with prefix reuse: the full step 0 and one active-rows step) launch every kernel variant
+    // once (first-use attributes, GEMM tile tuning) outside the capture; step 0 always runs eagerly.  Not combined with per-launch
+    // event timing.
     const int n_eager = reuse ? 2 : 1;
     const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query();
     if (!graph) {
         for (int step = 0; step < steps; ++step) TRY(denoise_step(step, step == 0 || !reuse));
     } else {
         if (!e->step_dev) { TRY(e->alloc(&e->step_dev, 4)); }
-        if (e->sched_cap < 2 * steps) { TRY(e->alloc(&e->sched_dev, 2 * steps)); e->sched_cap = 2 * steps; }
-        std::vector<float> sched(2 * steps);
-        for (int i = 0; i < steps; ++i) { sched[i] = mask_len_host[i]; sched[steps + i] = temps_host[i]; }
-        const int hdr[4] = {0, 0, (int)(uint32_t)(seed & 0xffffffffu), (int)(uint32_t)(seed >> 32)};  // step index | pad | seed
-        SHOWO_CHECK_HIP(hipMemcpyAsync(e->sched_dev, sched.data(), sizeof(float) * 2 * steps, hipMemcpyHostToDevice, s));
-        SHOWO_CHECK_HIP(hipMemcpyAsync(e->step_dev, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
-        SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // `sched` / `hdr` are host temporaries
+        if (e->sched_cap < 2 * steps) {
+            // (re)allocation changes a pointer baked into cached graphs: they are keyed on it (p[8]) and simply miss afterwards
+            TRY(e->alloc(&e->sched_dev, 2 * (steps > 256 ? steps : 256))); e->sched_cap = 2 * (steps > 256 ? steps : 256);
+        }
+        if (2 * steps <= 512) {
+            SchedArgs a;
+            for (int i = 0; i < steps; ++i) { a.v[i] = mask_len_host[i]; a.v[steps + i] = temps_host[i]; }
+            a.hdr[0] = 0; a.hdr[1] = 0; a.hdr[2] = (int)(uint32_t)(seed & 0xffffffffu); a.hdr[3] = (int)(uint32_t)(seed >> 32);
+            a.n = 2 * steps;
+            sched_upload_kernel<<<1, 256, 0, s>>>(a, e->sched_dev, e->step_dev);
+            SHOWO_CHECK_HIP(hipGetLastError());
+        } else {
+            std::vector<float> sched(2 * steps);
+            for (int i = 0; i < steps; ++i) { sched[i] = mask_len_host[i]; sched[steps + i] = temps_host[i]; }
+            const int hdr[4] = {0, 0, (int)(uint32_t)(seed & 0xffffffffu), (int)(uint32_t)(seed >> 32)};  // step index | pad | seed
+            SHOWO_CHECK_HIP(hipMemcpyAsync(e->sched_dev, sched.data(), sizeof(float) * 2 * steps, hipMemcpyHostToDevice, s));
+            SHOWO_CHECK_HIP(hipMemcpyAsync(e->step_dev, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
+            SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // `sched` / `hdr` are host temporaries
+        }
         showo::sampler_set_device_step(e->step_dev, e->sched_dev, steps);
-        showo_engine::T2IGraphKey key{};
-        key.nseq = nseq; key.L = L; key.N = N; key.prefix = prefix; key.steps = steps; key.id_offset = id_offset; key.codebook = codebook;
-        key.reuse = reuse ? 1 : 0; key.mask_id = mask_id; key.guidance = guidance;
-        key.p[0] = iv; key.p[1] = flag; key.p[2] = mask; key.p[3] = exp_noise; key.p[4] = uniform; key.p[5] = e->row_logits;
-        key.p[6] = e->tk; key.p[7] = e->tvt; key.p[8] = e->sched_dev; key.p[9] = e->step_dev; key.p[10] = s;
-        const bool hit = e->t2i_exec && memcmp(&key, &e->t2i_key, sizeof(key)) == 0 && e->fused_valid;
+        showo_engine::T2IGraphKey key;
+        memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
+        key.B = B; key.nseq = nseq; key.L = L; key.N = N; key.prefix = prefix; key.steps = steps; key.id_offset = id_offset;
+        key.codebook = codebook; key.reuse = reuse ? 1 : 0; key.cfg = cfg ? 1 : 0; key.has_iv = iv ? 1 : 0;
+        key.mask_id = mask_id; key.guidance = guidance;
+        if (!reuse) { key.p[0] = iv; key.p[1] = flag; key.p[2] = mask; }  // with reuse the captured step reads e->iv_act only
+        key.p[3] = exp_noise; key.p[4] = uniform; key.p[5] = e->row_logits;
+        key.p[6] = reuse ? e->tk : nullptr; key.p[7] = reuse ? e->tvt : nullptr; key.p[8] = e->sched_dev; key.p[9] = e->step_dev; key.p[10] = s;
+        showo_engine::T2IGraphEntry* ent = nullptr;
+        for (auto& ge : e->t2i_graphs)
+            if (memcmp(&key, &ge.key, sizeof(key)) == 0) { ent = &ge; break; }
+        const bool hit = ent != nullptr;
         int rc = 0;
         const int first_replay = hit ? 1 : n_eager;
         for (int i = 0; i < first_replay && !rc; ++i) {
@@ -717,8 +757,8 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
             if (!rc) rc = showo::sampler_step_inc(e->step_dev, s);
         }
         if (!rc && !hit) {
-            if (e->t2i_exec) { hipGraphExecDestroy(e->t2i_exec); e->t2i_exec = nullptr; }
             hipGraph_t g = nullptr;
+            hipGraphExec_t exec = nullptr;
             hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
             if (he == hipSuccess) {
                 rc = denoise_step(-1, !reuse);
@@ -729,19 +769,39 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
                 rc = set_error_hip(he, "hipStreamBeginCapture", __FILE__, __LINE__);
             }
             if (!rc) {
-                hipError_t he3 = hipGraphInstantiate(&e->t2i_exec, g, nullptr, nullptr, 0);
-                if (he3 != hipSuccess) { e->t2i_exec = nullptr; rc = set_error_hip(he3, "hipGraphInstantiate", __FILE__, __LINE__); }
-                else { e->t2i_key = key; e->t2i_captures++; }
+                hipError_t he3 = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+                if (he3 != hipSuccess) { exec = nullptr; rc = set_error_hip(he3, "hipGraphInstantiate", __FILE__, __LINE__); }
             }
             if (g) hipGraphDestroy(g);
+            if (!rc) {
+                if ((int)e->t2i_graphs.size() >= showo_engine::T2I_GRAPH_SLOTS) {  // evict the least recently used graph
+                    size_t lru = 0;
+                    for (size_t i = 1; i < e->t2i_graphs.size(); ++i)
+                        if (e->t2i_graphs[i].last_use < e->t2i_graphs[lru].last_use) lru = i;
+                    // the evicted graph may still be executing a previous call's replays on another stream
+                    hipDeviceSynchronize();
+                    hipGraphExecDestroy(e->t2i_graphs[lru].exec);
+                    e->t2i_graphs.erase(e->t2i_graphs.begin() + lru);
+                }
+                e->t2i_graphs.push_back(showo_engine::T2IGraphEntry{key, exec, 0});
+                ent = &e->t2i_graphs.back();
+                e->t2i_captures++;
+            }
         }
+        if (!rc) ent->last_use = ++e->t2i_tick;
         for (int step = first_replay; !rc && step < steps; ++step) {
-            hipError_t he = hipGraphLaunch(e->t2i_exec, s);
+            hipError_t he = hipGraphLaunch(ent->exec, s);
             if (he != hipSuccess) rc = set_error_hip(he, "hipGraphLaunch", __FILE__, __LINE__);
         }
         showo::sampler_set_device_step(nullptr, nullptr, 0);
         if (rc) return rc;
     }
+    if (check_pending) {
+        SHOWO_CHECK_HIP(hipEventSynchronize(e->ev_pfx));  // recorded before the first step: long since complete
+        if (*(volatile int32_t*)e->pfx_host) continue;  // a text row sees an image column (or the mask is not an interval mask): repeat without reuse
+    }
+    break;
+    }  // attempt
     copy_i64_kernel<<<dim3((B * L + thr - 1) / thr), dim3(thr), 0, s>>>(e->ids_all, ids_cond, B * L);  // in-place update like the reference
     copy_i64_kernel<<<dim3((B * N + thr - 1) / thr), dim3(thr), 0, s>>>(e->sampled, sampled_out, B * N);
     SHOWO_CHECK_HIP(hipGetLastError());

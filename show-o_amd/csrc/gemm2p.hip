@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <tuple>
 
 namespace showo {
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
 // ---- split-K workspace: one per stream that asks for it (at most 4), allocated on first use outside a stream capture.
 // 96 MiB covers tiles x splits <= 256 blocks of the tallest tile (256 x 256 fp32 = 256 KiB per block).
 struct SplitWs { hipStream_t s; float4* ws; unsigned* tick; };
-SplitWs g_sws[4];
+SplitWs g_sws[8];
 int g_nsws = 0;
 constexpr size_t SPLITK_WS_BYTES = (size_t)96 << 20;
 constexpr int SPLITK_TICKS = 4096;
@@ -322,7 +323,7 @@ bool splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     if (need > SPLITK_WS_BYTES) return false;
     for (int i = 0; i < g_nsws; ++i)
         if (g_sws[i].s == s) { *ws = g_sws[i].ws; *tick = g_sws[i].tick; return true; }
-    if (g_nsws == 4) return false;
+    if (g_nsws == 8) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;  // never allocate inside a capture
     SplitWs w{s, nullptr, nullptr};
@@ -335,6 +336,32 @@ bool splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     g_sws[g_nsws++] = w;
     *ws = w.ws; *tick = w.tick;
     return true;
+}
+
+// ---- split-K policy.  Few tiles, long K: split until ~one block per CU, >= 16 k-tiles per split.  The exchange costs a tile-sized fp32
+// write per split, one L2 write-back + ticket per block and `splits` tile reads in the last block.  Measured
+// (profiles/r2_gemm_harness.txt, r3c / r3d): M = 631, K = 10 240 residual GEMM 168 -> 70 us; CLIP fc2 (K = 4 096) 65 -> 37-40 us; cfg4
+// prefill 6.3 -> 4.5 ms, CLIP tower 5.8 -> 4.9 ms, time to first token 12.1 -> 9.5 ms.  Splits of 8 k-tiles measured within noise of
+// none -> floor 16 (SHOWO_GEMM_SPLITK_MIN).
+// The count is derived from the PROBLEM (tile count of the tallest, 256-row, tile), never from the tile variant that runs it: the
+// k-partition -- and with it the fp32 summation order of every output element -- is then the same for every variant, so the
+// wall-clock race of the tuner cannot change results between processes, ranks or runs (with the count taken from the
+// variant's own tile count, M = 631 gave S = 10 at 256 rows and S = 6 at 144).  The ring variants (gemm3w) do not split; they are
+// kept out of the candidate list of split shapes (launch2p_bm) for the same reason.
+int64_t g_cnt_gemm2p = 0, g_cnt_qkv_save = 0, g_cnt_splitk = 0;
+int splitk_count(int M, int N, int K) {
+    if (g_gemm_splitk < 0) { const char* e = getenv("SHOWO_GEMM_SPLITK"); g_gemm_splitk = e ? atoi(e) : 1; }
+    static int min_kt = 0;  // k-tiles per split at least (SHOWO_GEMM_SPLITK_MIN, default 16)
+    if (!min_kt) { const char* e = getenv("SHOWO_GEMM_SPLITK_MIN"); min_kt = (e && atoi(e) >= 2) ? atoi(e) : 16; }
+    const int tiles = ((M + 255) / 256) * ((N + B2 - 1) / B2), nk = K / GEMM_BK;
+    if (!g_gemm_splitk || tiles * 2 > 256 || nk < 2 * min_kt) return 1;
+    int S = 256 / tiles;
+    if (S > nk / min_kt) S = nk / min_kt;
+    if (S > 16) S = 16;
+    if (S < 2) return 1;
+    const int per = (nk + S - 1) / S;
+    S = (nk + per - 1) / per;  // no empty split
+    return S >= 2 ? S : 1;
 }
 
 template <int EPI, int MF0, int MF1, bool NS>
@@ -350,25 +377,17 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
     constexpr int BMT = 16 * (MF0 + MF1);
     int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
     const int tiles = tilesM * tilesN, nk = g.K / GEMM_BK;
+    // split-K: the split count S (hence the k-partition and the fp32 summation order) is a function of (M, N, K) ALONE
+    // (splitk_count below): every split-capable tile variant produces the same bits, whichever one the tuner picks.
     g.splits = 1;
-    if (g_gemm_splitk < 0) { const char* e = getenv("SHOWO_GEMM_SPLITK"); g_gemm_splitk = e ? atoi(e) : 1; }
-    // few tiles, long K: split until ~one block per CU, >= 16 k-tiles per split.  The exchange costs a tile-sized fp32 write per
-    // split, one L2 write-back + ticket per block and `splits` tile reads in the last block.  Measured (profiles/r2_gemm_harness.txt,
-    // r3c / r3d): M = 631, K = 10 240 residual GEMM 168 -> 70 us (6 splits of a 128-row variant); CLIP fc2 (K = 4 096) 65 -> 37-40 us;
-    // cfg4 prefill 6.3 -> 4.5 ms, CLIP tower 5.8 -> 4.9 ms, time to first token 12.1 -> 9.5 ms.  Splits of 8 k-tiles (K = 1 024
-    // GEMMs) measured within noise of none -> floor 16.  Ring variants (gemm3w) do not split: the tuner compares both families.
-    static int min_kt = 0;  // k-tiles per split at least (SHOWO_GEMM_SPLITK_MIN, default 16)
-    if (!min_kt) { const char* e = getenv("SHOWO_GEMM_SPLITK_MIN"); min_kt = (e && atoi(e) >= 2) ? atoi(e) : 16; }
-    if (g_gemm_splitk && tiles * 2 <= 256 && nk >= 2 * min_kt) {
-        int S = 256 / tiles;
-        if (S > nk / min_kt) S = nk / min_kt;
-        if (S > 16) S = 16;
-        if (S >= 2) {
-            const int per = (nk + S - 1) / S;
-            S = (nk + per - 1) / per;  // no empty split
-            constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
-            if (S >= 2 && splitk_ws(s, (size_t)tiles * S * NFS * 512 * sizeof(float4), &g.ws, &g.tick)) g.splits = S;
-        }
+    const int S = splitk_count(g.M, g.N, g.K);
+    if (S >= 2) {
+        constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
+        if (tiles * S > SPLITK_TICKS || !splitk_ws(s, (size_t)tiles * S * NFS * 512 * sizeof(float4), &g.ws, &g.tick))
+            return set_error_msg(7, "gemm2p: split-K workspace unavailable (first use of a split shape inside a stream capture, or more than 8 "
+                                    "streams): run the shape once eagerly, or set SHOWO_GEMM_SPLITK=0");
+        g.splits = S;
+        g_cnt_splitk++;
     }
     kfn<<<dim3(tiles * g.splits), dim3(512), SMEM3_BYTES, s>>>(g);
     hipError_t e = hipGetLastError();
@@ -449,9 +468,13 @@ int pick_bm(int M, int N) {
 }
 
 // Tile variant per (M, N, K, epilogue).  The rounds model mispredicts by up to ~10 % (per-tile weight streaming, epilogue traffic,
-// DVFS), so the first launch of a shape times every variant (interleaved passes, HIP events) and the winner is cached.  Every
-// variant computes bit-identical results (same k order per element), so the choice never changes numerics.  Skipped while the
+// DVFS), so the first launch of a shape times every candidate (interleaved passes, HIP events) and the winner is cached.  Every
+// CANDIDATE of a shape computes bit-identical results: an output element is one fp32 chain over k in order, or -- for shapes that
+// split K -- `splitk_count(M, N, K)` chains over a k-partition that depends on the problem only, summed in split order; the ring
+// variants, which never split, are not candidates of a split shape.  So the timing race never changes numerics.  Skipped while the
 // stream is being captured (the model is used), and with SHOWO_GEMM_TUNE=0.  In-place residual launches are timed on a scratch output.
+// g_bm_cache / the split-K workspaces are process-wide: guarded by g_gemm_mu (autograd's backward thread launches GEMMs too).
+std::mutex g_gemm_mu;
 std::map<std::tuple<int, int, int, int>, int> g_bm_cache;  // (M, N, K, EPI) -> variant | tile-group width << 16
 int g_gemm_tune = -1;
 
@@ -461,6 +484,7 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     if (g_gemm_bm > 0) return launch2p_h<EPI>(g, g_gemm_bm, s);
     if (g_gemm_tune < 0) { const char* e = getenv("SHOWO_GEMM_TUNE"); g_gemm_tune = e ? atoi(e) : 1; }
     const auto key = std::make_tuple(g.M, g.N, g.K, EPI);
+    const bool split_shape = splitk_count(g.M, g.N, g.K) >= 2;  // ring variants never split: not candidates (bit-identity, see above)
     auto it = g_bm_cache.find(key);
     if (it != g_bm_cache.end()) {
         GemmArgs c = g;
@@ -489,7 +513,7 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     for (int pass = 0; pass < 2; ++pass) {
         for (int ci = 0; ci < N_VARIANTS; ++ci) {
             const int h = k_variants[ci];
-            if (h >= 2000 && !ring_ok) continue;
+            if (h >= 2000 && (!ring_ok || split_shape)) continue;
             int rc = launch2p_h<EPI>(t, h, s);  // warm-up (instruction cache, attribute set)
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, h, s);
@@ -541,6 +565,9 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
 }  // namespace
 
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_gemm_mu);
+    g_cnt_gemm2p++;
+    if (epilogue == EPI_QKV && g.raw && g.pre) g_cnt_qkv_save++;
     g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
     if (g_gemm_pf < 0) { const char* e = getenv("SHOWO_GEMM_PF"); g_gemm_pf = e ? (atoi(e) != 0) : 0; }
     if (g_gemm_stage < 0) { const char* e = getenv("SHOWO_GEMM_STAGE"); g_gemm_stage = e ? atoi(e) : 1; }
@@ -557,3 +584,13 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
 }
 
 }  // namespace showo
+
+// Launch counters of the production GEMM family (tests assert that a batch took the T >= 256 branch the bench times):
+// out[0] = launches through gemm2p_dispatch (gemm2p / gemm3w kernels), out[1] = of those, the fused [Wqkv ; W1] save-for-backward form
+// (showo_gemm_qkv_fc1_save_bf16), out[2] = launches that split K.  reset != 0 zeroes them after reading.
+extern "C" int showo_gemm_counters(int64_t* out3, int reset) {
+    std::lock_guard<std::mutex> lock(showo::g_gemm_mu);
+    if (out3) { out3[0] = showo::g_cnt_gemm2p; out3[1] = showo::g_cnt_qkv_save; out3[2] = showo::g_cnt_splitk; }
+    if (reset) showo::g_cnt_gemm2p = showo::g_cnt_qkv_save = showo::g_cnt_splitk = 0;
+    return 0;
+}

@@ -331,7 +331,10 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         rowloss[2 * r + 1] = (cr.bits & 6) ? (okB ? lse - z[cr.labB] : __builtin_nanf("")) : 0.f;
     }
     if (dz) {
-        const float w = wa + wb, inv = 1.0f / tot;
+        // same rule for the gradient: a row whose label is out of range gets a NaN gradient row, so the wrong batch cannot update the
+        // weights silently (the NaN reaches every parameter through the lm_head dgrad / wgrad; the reference aborts with a device assert)
+        const bool bad = ((cr.bits & 1) && (cr.labA < 0 || cr.labA >= V)) || ((cr.bits & 6) && (cr.labB < 0 || cr.labB >= V));
+        const float w = bad ? __builtin_nanf("") : wa + wb, inv = 1.0f / tot;
         for (int i0 = tid * 8; i0 < ldd; i0 += 256 * 8) {
             float v[8];
 #pragma unroll

@@ -108,21 +108,42 @@ class Trainer:
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
         self.params = [("showo." + n, p) for n, p in model.showo.named_parameters()]
-        dev = self.params[0][1].device
         self.m = {n: torch.zeros_like(p) for n, p in self.params}
         self.v = {n: torch.zeros_like(p) for n, p in self.params}
-        self.tr = model.trainer()
+        self._wire, self._force_exchange = wire, force_exchange
+        self._bound = None
+        self._bind()
+
+    def _binding_key(self, params=None):
+        params = self.params if params is None else params
+        return (self.tr.value if hasattr(self.tr, "value") else int(self.tr),) + tuple(p.data_ptr() for _, p in params)
+
+    def _bind(self):
+        """(Re)create everything that holds raw pointers into the native trainer or the parameters: the gradient-bucket views, the
+        exchange's staging buffers and the optimizer's parameter table.  Called by __init__ and by step() whenever the trainer
+        handle changed (configure_workspace / _drop_engine re-create it) or a parameter's storage moved (load_state_dict(assign=True),
+        .to(), ...): a stale handle would have no parameters bound and the native AdamW would write through dangling pointers."""
+        self.tr = self.model.trainer()
+        dev = self.params[0][1].device
+        for n, p in self.params:
+            if self.m[n].device != p.device or self.m[n].shape != p.shape:
+                self.m[n] = torch.zeros_like(p)
+                self.v[n] = torch.zeros_like(p)
         lib = _lib.load()
         self.buckets = []
         for b in range(lib.showo_train_num_buckets(self.tr)):
             ptr, n = C.c_void_p(), C.c_int64()
             _lib.check(lib.showo_train_bucket(self.tr, b, C.byref(ptr), C.byref(n)), "showo_train_bucket")
             self.buckets.append(device_view(ptr.value, n.value, dev))
-        for n, p in self.params:  # master weights + moments are registered once; the step is one C call
+        for n, p in self.params:  # master weights + moments are registered once per binding; the step is one C call
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise ValueError(f"{n}: the native optimizer updates contiguous fp32 master parameters in place")
             _lib.call("showo_train_bind_param", self.tr, n.encode(), p.data_ptr(), self.m[n].data_ptr(), self.v[n].data_ptr(), p.numel())
         import torch.distributed as dist
-        active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
-        self.exchange = GradientExchange(self.buckets, dist, group, wire=wire) if active else None
+        group = self.group
+        active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self._force_exchange)
+        self.exchange = GradientExchange(self.buckets, dist, group, wire=self._wire) if active else None
+        self._bound = self._binding_key()
 
     # ---- checkpoint / resume of the optimizer (reference: accelerator.save_state / load_state, training/train.py:851-889, 429-443)
     def state_dict(self):
@@ -168,6 +189,10 @@ class Trainer:
         # model.trainer() re-uploads parameters whose (data_ptr, version) changed since the last call (load_state_dict, resume,
         # manual edits); the native AdamW below updates them through raw pointers and refreshes the engine images itself
         self.tr = self.model.trainer()
+        cur = [("showo." + n, p) for n, p in self.model.showo.named_parameters()]  # assign=True loads replace the Parameter objects
+        if self._binding_key(cur) != self._bound:  # new native trainer, or a parameter's storage moved: rebuild every raw-pointer binding
+            self.params = cur
+            self._bind()
         m, tr, s = self.model, self.tr, _lib.stream
         B, L = input_ids.shape
         ids = input_ids.to(torch.int64).contiguous()

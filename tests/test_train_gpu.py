@@ -613,3 +613,153 @@ def test_cross_entropy_out_of_range_label_poisons_the_loss():
            None, 0, L.ptr(losses), L.stream())
     torch.cuda.synchronize()
     assert math.isnan(float(losses[0])) and math.isfinite(float(losses[1]))
+    # ... and the gradient row of that position is NaN too (a caller that never looks at the losses must not train on it), the other
+    # rows are finite
+    dl = torch.zeros((B * Lq, V), dtype=torch.int16, device="cuda")
+    L.call("showo_ce_loss", L.ptr(logits), V, L.ptr(labels), B, Lq, V, 1, 1, 0, 4, 1.0, 1.0, 1.0, L.ptr(rows), L.ptr(counts), L.ptr(rowloss),
+           L.ptr(dl), V, None, L.stream())
+    gd = from_bf16_bits(dl).cpu()
+    assert torch.isnan(gd[9]).all()
+    assert torch.isfinite(torch.cat([gd[:9], gd[10:]])).all()
+
+
+def _gemm_counters(reset=False):
+    import ctypes as C
+    out = (C.c_int64 * 3)()
+    L().call("showo_gemm_counters", C.cast(out, C.c_void_p), 1 if reset else 0)
+    return [int(v) for v in out]
+
+
+def test_small_training_step_production_path_vs_reference_golden():
+    """a 324-row mixed batch (6 t2i + 2 lm + 4 mmu x 27) on the SMALL geometry (hidden 256) goes through the
+    trainer's T >= 256 branch -- fused [Wqkv ; W1] save-for-backward launch, gemm2p / gemm3w forward / dgrad / wgrad with K = token
+    count, multi-block transposes -- and reproduces the losses and gradients of the REAL reference (tests/golden/showo_small_train.npz,
+    oracle/make_golden.py::make_small_train).  Asserts by launch counters that the production kernels ran."""
+    g = util.golden("showo_small_train.npz")
+    d = Wt.ShowoDims(**Wt.SMALL)
+    sd = Wt.make_showo_state(d, seed=13)
+    m = util.build_showo(d, sd, max_batch=12, max_seq=32).train()
+    ids, mask, labels = dev(g["ids"]), dev(g["mask"]), dev(g["labels"])
+    bt, bl, bm = (int(x) for x in g["b"])
+    assert ids.numel() >= 256
+    _gemm_counters(reset=True)
+    logits, l1, l2, l3 = m(ids, attention_mask=mask, labels=labels, batch_size_t2i=bt, batch_size_lm=bl, batch_size_mmu=bm,
+                           max_seq_length=d.max_text_len)
+    fwd = _gemm_counters()
+    # forward: per layer the fused save-form projection + dense + fc2, then lm_head -- all on the production family
+    assert fwd[1] == d.layers, fwd
+    assert fwd[0] >= 3 * d.layers + 1, fwd
+    want = g["losses"]
+    got = [float(l1), float(l2), float(l3)]
+    print(f"[parity] small (324-row) training losses {got} reference {want.tolist()}")
+    for a, b in zip(got, want):
+        assert abs(a - b) < 5e-3 * abs(b)
+    rmax, rrms = util.relerr(logits[:, ::3], torch.from_numpy(g["logits_s"]))
+    print(f"[parity] small training logits: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rrms < 1e-2
+    (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+    bwd = _gemm_counters()
+    # backward: lm_head dgrad + wgrad, per layer 4 wgrads + 4 dgrads
+    assert bwd[0] - fwd[0] >= 8 * d.layers + 2, (fwd, bwd)
+    named = dict(m.named_parameters())
+    n = 0
+    for k in g.files:
+        if not k.startswith("grad::showo"):
+            continue
+        name = k[len("grad::"):]
+        gr = named[name].grad
+        assert gr is not None, name
+        rmax, rrms = util.relerr(gr, torch.from_numpy(g[k]))
+        print(f"[parity] small grad {name}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+        assert rrms < 3e-2 and rmax < 8e-2, name
+        n += 1
+    assert n >= 30
+    for tab, key in (("showo.model.embed_tokens.weight", "embed"), ("showo.lm_head.weight", "lm_head")):
+        rows = torch.from_numpy(g[f"grad::{key}_row_ids"])
+        rmax, rrms = util.relerr(named[tab].grad[rows.cuda()], torch.from_numpy(g[f"grad::{key}_rows"]))
+        print(f"[parity] small grad {tab} rows: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+        assert rrms < 3e-2, tab
+    # and the native Trainer (phased backward + fused AdamW) takes the same batch
+    tr = util.pkg().Trainer(m, lr=1e-3)
+    first = tr.step(ids, mask, labels, bt, bl, bm, d.max_text_len)
+    assert torch.allclose(first.cpu(), torch.tensor(got), rtol=1e-4, atol=1e-5)
+    for _ in range(4):
+        last = tr.step(ids, mask, labels, bt, bl, bm, d.max_text_len)
+    assert float(last.sum()) < float(first.sum())
+
+
+def test_full_width_two_layer_stage1_batch_gradients_vs_oracle_autograd():
+    """the shapes the training bench times -- hidden 2048, ffn 8192, 32 heads, the stage-1 batch of
+    15 t2i + 4 lm + 10 mmu sequences x 387 = 11 223 token rows (configs/showo_pretraining_stage1.yaml:84-86, training/train.py:510-628)
+    built by the product's own build_training_batch -- on a 2-layer stack with a small vocabulary, against torch autograd through the
+    CPU oracle (pinned to the reference's backward by tests/test_oracle_vs_golden.py::test_small_train_fixture_...).
+    M = 11 223 forward / dgrad GEMMs, K = 11 264 wgrad GEMMs, L = 387 attention backward, the fused save-form projection."""
+    from stub_tokenizer import StubTokenizer
+    P = util.pkg()
+    d = Wt.ShowoDims(hidden=2048, layers=2, heads=32, ffn=8192, vocab=1000 + 10 + 512 + 1, llm_vocab=1000, codebook=512,
+                     num_vq_tokens=256, max_text_len=128)
+    sd_np = Wt.make_showo_state(d, seed=19)
+    bt, bl, bm = 15, 4, 10
+    m = util.build_showo(d, sd_np, max_batch=bt + bl + bm, max_seq=387).train()
+    up = P.UniversalPrompting(StubTokenizer(vocab=d.llm_vocab, bos=d.llm_vocab - 10, eos=d.llm_vocab - 10), max_text_len=d.max_text_len,
+                              cond_dropout_prob=0.1)
+    sp = {k: int(v) for k, v in up.sptids_dict.items()}
+    assert sp["<|pad|>"] == d.pad_id and sp["<|soi|>"] == d.soi_id and sp["<|eoi|>"] == d.eoi_id
+    rs = np.random.RandomState(23)
+    words = [f"w{i}" for i in range(400)]
+
+    def text(n):
+        return " ".join(words[j] for j in rs.randint(0, len(words), size=n))
+
+    N = d.num_vq_tokens
+    torch.manual_seed(5)
+    import random
+    random.seed(5)
+    img_t2i = torch.randint(0, d.codebook, (bt, N), device="cuda") + d.image_offset
+    img_mmu = torch.randint(0, d.codebook, (bm, N), device="cuda") + d.image_offset
+    texts_t2i = [text(int(k)) for k in rs.randint(3, 60, size=bt)]
+    texts_lm = [text(int(k)) for k in rs.randint(100, 500, size=bl)]
+    texts_mmu = [text(int(k)) for k in rs.randint(5, 110, size=bm)]
+    cfg = type("Cfg", (), {"training": type("S", (dict,), {"__getattr__": dict.__getitem__})(min_masking_rate=0.0)})
+    ids, labels, imask, _, (b1, b2, b3) = P.training_utils.build_training_batch(
+        up, cfg, d.mask_token_id, P.cosine_schedule, img_t2i, texts_t2i, texts_lm, img_mmu, texts_mmu)
+    assert (b1, b2, b3) == (bt, bl, bm) and tuple(ids.shape) == (29, 387)
+    kw = dict(labels=labels, batch_size_t2i=bt, batch_size_lm=bl, batch_size_mmu=bm, max_seq_length=d.max_text_len)
+    _gemm_counters(reset=True)
+    logits, l1, l2, l3 = m(ids, attention_mask=imask, **kw)
+    cnt = _gemm_counters()
+    assert cnt[1] == d.layers and cnt[0] >= 3 * d.layers + 1, cnt
+    (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+    torch.cuda.synchronize()
+    # ---- oracle: the reference's dense masks for the same rows, fp32 autograd on the CPU
+    c = ids.cpu()
+    dense = torch.cat([O.mask_t2i(c[:bt], d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=True),
+                       O.mask_t2i(c[bt:bt + bl], d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False),
+                       O.mask_mmu(c[bt + bl:], d.eoi_id)], dim=0)
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch(sd_np).items()}
+    import time
+    t0 = time.time()
+    lg, o1, o2, o3 = O.showo_forward(sd, d, c, attention_mask=dense, labels=labels.cpu(), batch_size_t2i=bt, batch_size_lm=bl,
+                                     batch_size_mmu=bm, max_seq_length=d.max_text_len)
+    (1.0 * o1 + 0.1 * o2 + 1.0 * o3).backward()
+    print(f"[parity] full-width oracle fwd+bwd on the host: {time.time() - t0:.1f} s")
+    got, want = [float(l1), float(l2), float(l3)], [float(o1), float(o2), float(o3)]
+    print(f"[parity] full-width 2-layer losses {got} oracle {want}")
+    for a, b in zip(got, want):
+        assert abs(a - b) < 5e-3 * abs(b)
+    rmax, rrms = util.relerr(logits, lg.detach())
+    print(f"[parity] full-width 2-layer logits: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rrms < 1e-2
+    worst = (0.0, "")
+    for name, p in m.named_parameters():
+        if name == "showo.model.embed_tokens.weight":
+            rows = torch.unique(c.reshape(-1))
+            a, b = p.grad[rows.cuda()], sd[name].grad[rows]
+        else:
+            a, b = p.grad, sd[name].grad
+        assert a is not None and b is not None, name
+        rmax, rrms = util.relerr(a, b)
+        print(f"[parity] full-width grad {name}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+        worst = max(worst, (rrms, name))
+        assert rrms < 3e-2 and rmax < 1e-1, name
+    print(f"[parity] full-width worst gradient rel_rms {worst[0]:.3e} ({worst[1]})")
