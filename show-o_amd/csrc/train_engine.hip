@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 
 using namespace showo;
@@ -170,9 +171,11 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     }
     rc |= t->alloc(&t->logits, T * V);
     rc |= t->alloc(&t->dlogits, T * Vp);
-    const int64_t bigrows = Vp > F ? Vp : F;
+    // bigT holds the transposed dY side of every wgrad GEMM: dlogits^T [Vp, Tp], df^T [F, Tp], dqkv^T [3H, Tp] -- the tallest wins
+    // (round 3: sizing it by max(Vp, F) alone overflowed for geometries with 3H > max(Vp, F), found by the SMALL training fixture)
+    const int64_t bigrows = std::max<int64_t>(std::max<int64_t>(Vp, F), 3 * H);
     rc |= t->alloc(&t->bigT, bigrows * Tp);
-    rc |= t->alloc(&t->xT, F * Tp);
+    rc |= t->alloc(&t->xT, std::max<int64_t>(F, H) * Tp);
     rc |= t->alloc(&t->dy, T * H); rc |= t->alloc(&t->dh, T * H); rc |= t->alloc(&t->dy16, T * H); rc |= t->alloc(&t->d_o, T * H);
     rc |= t->alloc(&t->dff, T * F); rc |= t->alloc(&t->dqk, T * 2 * H); rc |= t->alloc(&t->dqkv, T * 3 * H);
     rc |= t->alloc(&t->QT, (int64_t)max_batch * H * t->Lp); rc |= t->alloc(&t->KT, (int64_t)max_batch * H * t->Lp);
