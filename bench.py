@@ -93,6 +93,16 @@ def cpu_baseline(budget_s=30.0):
                       f"scaled x18/{n}; decode_code omitted (<1% of FLOPs)"}
 
 
+def gemm_src_sha1():
+    """identity of the kernels a PMC traffic figure belongs to: sha1 over the sources of the production GEMM family"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("gemm_common.h", "gemm2p.hip", "gemm3w.hip"):
+        with open(os.path.join(ROOT, "show-o_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def self_launch(gpus, script):
     """`python bench.py --gpus N` without a launcher: re-exec as N ranks (one process per GPU) under torch.distributed.run, as
     the reference is started by `accelerate launch` (training/train.py:91-110; accelerate_configs/8_gpus_deepspeed_zero2.yaml).
@@ -175,11 +185,11 @@ def main():
         if wl == "train":
             import bench_train
             return bench_train.main(sys.argv[1:])
-        if wl in ("t2i512", "mmu"):  # BASELINE configs[2] / configs[3] as their own JSON lines
+        if wl in ("t2i512", "mmu", "vq"):  # BASELINE configs[2] / configs[3] and the VQ path's HBM-bound kernels as their own JSON lines
             import bench_configs
             return bench_configs.main(sys.argv[1:])
         if wl != "t2i":
-            raise SystemExit(f"bench: unknown --workload {wl} (t2i | train | t2i512 | mmu)")
+            raise SystemExit(f"bench: unknown --workload {wl} (t2i | train | t2i512 | mmu | vq)")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -290,11 +300,17 @@ def main():
         peak = 2500.0  # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
         # HBM bytes per GEMM launch: PMC counters cannot be read from inside this process; they come from the separate
         # rocprofv3 --pmc passes over this same command (scripts/gpu_pmc.sh -> profiles/pmc/bench_traffic.json)
+        # The committed figure carries the hash of the GEMM sources it was measured on (tools/pmc_agg.py writes `kernel_src_sha1`):
+        # when the kernels have changed since, the line says null + why instead of quoting a stale number.
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc", "bench_traffic.json")))
-            traffic = tj["gemm2p_kernel"]["bytes_per_launch"]
-            traffic_src = f"profiles/pmc/bench_traffic.json ({tj['tag']}: {tj['corrections']})"
+            if tj.get("kernel_src_sha1") == gemm_src_sha1():
+                traffic = tj["gemm2p_kernel"]["bytes_per_launch"]
+                traffic_src = f"profiles/pmc/bench_traffic.json ({tj['tag']}: {tj['corrections']}; GEMM sources {tj['kernel_src_sha1'][:12]} = this build)"
+            else:
+                traffic_src = (f"profiles/pmc/bench_traffic.json ({tj.get('tag')}) was measured on GEMM sources {str(tj.get('kernel_src_sha1'))[:12]}, this "
+                               f"build is {gemm_src_sha1()[:12]}: stale, not quoted (re-run scripts/gpu_pmc3.sh)")
         except (OSError, KeyError, TypeError, ValueError):
             pass
         # ceilings measured on an MI355X by tools/ceiling.py (hipBLASLt through torch.matmul and a float4 copy kernel, random / zero
@@ -309,8 +325,8 @@ def main():
             "metric": "t2i images/sec @256x256 (18 denoise steps)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2: configs/showo_demo.yaml t2i 256x256, batch 8 prompts, CFG 5.0 (forward on [16,387]), "
-                                   "18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M",
+            "config": {"workload": (f"BASELINE cfg{2 if B == 8 else 1}{'' if B in (1, 8) else ' shape'}: configs/showo_demo.yaml t2i 256x256, batch {B} prompt{'s' if B > 1 else ''}, "
+                                    f"CFG 5.0 (forward on [{2 * B},387]), 18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M"),
                        "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
                        "launch_mode": "hipGraph replay of the denoise steps (cached on the engine)" if a.graph else "eager",
                        "algorithmic_tflop_per_image": 38.4, "end_to_end_algorithmic_tflops": value * 38.4,
@@ -324,6 +340,11 @@ def main():
                          "avg_launch_ms": ms_gemm.value / max(1, n_gemm.value),
                          "measured_in": f"{n_evt} extra eager steps with HIP events after the timed region ({dt_evt / n_evt * 1e3:.1f} ms per step)" if n_evt else None,
                          "time_share_of_step": (fl_all.value / max(1e-9, ach * 1e12)) / dt_evt if (ach > 0 and n_evt) else None,
+                         # at small batches the forward approaches the weight-streaming roof (2.90 GB of bf16 weights per
+                         # forward, 18 forwards per image batch): printed so that a --batch 1 line (BASELINE cfg1 shape) can be read
+                         "weight_stream": {"bytes_per_forward": 2.896e9, "forwards_per_step": 18,
+                                           "TBps_if_weights_streamed_once_per_forward": 18 * 2.896e9 / (dt / a.steps) / 1e12,
+                                           "frac_of_8TBps": 18 * 2.896e9 / (dt / a.steps) / 8e12, "token_rows_per_forward": 2 * B * 387},
                          "attention": {"achieved": fl_attn.value / max(1e-9, ms_attn.value * 1e-3) / 1e12},
                          "vq_conv": {"achieved": fl_conv.value / max(1e-9, ms_conv.value * 1e-3) / 1e12}},
         }
@@ -340,6 +361,13 @@ def main():
         out["train_step"] = train_step
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            if isinstance(train_step, dict) and "error" not in train_step:
+                # the CPU side of the second half of the metric, same run, same host cores (bounded sample: 3-sequence fwd + bwd)
+                import bench_train
+                try:
+                    train_step["cpu_baseline"] = bench_train.cpu_baseline(29, budget_s=25.0)
+                except Exception as ex:  # the headline line must survive a host that cannot hold the fp32 model twice
+                    train_step["cpu_baseline"] = {"error": repr(ex)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

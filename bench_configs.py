@@ -9,6 +9,11 @@
       (modeling_showo.py:204,229).  HBM-bound: every decoded token streams the 2.66 GB of bf16 weights once
       (24 x 100.7 MB + 240 MB lm_head), so roofline.achieved = 2.66 GB x tokens / decode time.
 
+  vq: the HBM-bound kernels of the MAGVIT-v2 path as bandwidth lines (BASELINE.json north_star: "rocprof showing achieved HBM GB/s on
+      the VQ/argmin path"): LFQ pack (sign test + bit pack, models/modeling_magvitv2.py:201-206) / unpack (:208-221) at >= 64 MB and
+      the GroupNorm(32) + swish passes (models/common_modules.py:16-24) at the decoder's largest activation ([8, 256x256, 128] fp32).
+      achieved = algorithmic bytes (each tensor once) / launch time from HIP events on the launch stream; peak 8 TB/s.
+
 Synthetic data, random-init weights of the true architectures (no checkpoints offline).  Nothing here touches oracle/."""
 import argparse
 import ctypes as C
@@ -169,6 +174,76 @@ def mmu(a):
             "cpu_baseline": None}
 
 
+def vq(a):
+    """HBM GB/s of the VQ path's bandwidth-bound kernels at sizes where bandwidth, not launch latency, decides"""
+    import showo_amd
+    L = showo_amd._lib
+    s = L.stream
+    torch.manual_seed(0)
+    reps = max(3, a.steps)
+
+    def timed(fn):
+        for _ in range(max(1, a.warmup)):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # torch's current stream IS the launch stream
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    rows = {}
+    # ---- LFQ: 16 x 131 072 tokens x 13 channels fp32 = 109 MB in, 16.8 MB of int64 ids out (60 B per token, SURVEY 8d)
+    B, Cz, hw = 16, 13, 131072
+    z = torch.randn(B, Cz, hw, device="cuda")
+    ids = torch.empty(B, hw, dtype=torch.int64, device="cuda")
+    t = timed(lambda: L.call("showo_lfq_pack_nchw", L.ptr(z), L.ptr(ids), B, Cz, hw, s()))
+    by = B * hw * (Cz * 4 + 8)
+    rows["lfq_pack_nchw"] = {"bytes": by, "us": t * 1e6, "GBps": by / t / 1e9}
+    zq = torch.empty_like(z)
+    t = timed(lambda: L.call("showo_lfq_unpack_nchw", L.ptr(ids), L.ptr(zq), B, Cz, hw, s()))
+    rows["lfq_unpack_nchw"] = {"bytes": by, "us": t * 1e6, "GBps": by / t / 1e9}
+    assert torch.equal(zq > 0, z > 0)  # pack -> unpack round trip keeps every sign (size-independent property)
+    zl = torch.randn(B, hw, 16, device="cuda")
+    t = timed(lambda: L.call("showo_lfq_pack_nhwc", L.ptr(zl), L.ptr(ids), B, Cz, hw, 16, s()))
+    by2 = B * hw * (16 * 4 + 8)
+    rows["lfq_pack_nhwc"] = {"bytes": by2, "us": t * 1e6, "GBps": by2 / t / 1e9}
+    del z, zq, zl, ids
+    # ---- GroupNorm(32, eps 1e-6) + swish on the decoder's largest activation: [8, 65 536, 128] fp32 NHWC = 268 MB
+    Bn, HW, Cc = 8, 65536, 128
+    x = torch.randn(Bn, HW, Cc, device="cuda")
+    nd = L.load().showo_gn_stats_doubles(Bn, HW)
+    stats = torch.empty(nd, dtype=torch.float64, device="cuda")
+    gam, bet = torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda")
+    y = torch.empty(Bn, HW, Cc, dtype=torch.int16, device="cuda")
+    ylo = torch.empty_like(y)
+    t = timed(lambda: L.call("showo_gn_stats", L.ptr(x), L.ptr(stats), Bn, HW, Cc, s()))
+    rows["gn_stats"] = {"bytes": x.numel() * 4, "us": t * 1e6, "GBps": x.numel() * 4 / t / 1e9}
+    t = timed(lambda: L.call("showo_gn_apply", L.ptr(x), L.ptr(stats), L.ptr(gam), L.ptr(bet), L.ptr(y), None, Bn, HW, Cc, 1e-6, 1, s()))
+    rows["gn_apply_swish_bf16"] = {"bytes": x.numel() * 6, "us": t * 1e6, "GBps": x.numel() * 6 / t / 1e9}
+    t = timed(lambda: L.call("showo_gn_apply", L.ptr(x), L.ptr(stats), L.ptr(gam), L.ptr(bet), L.ptr(y), L.ptr(ylo), Bn, HW, Cc, 1e-6, 1, s()))
+    rows["gn_apply_swish_split"] = {"bytes": x.numel() * 8, "us": t * 1e6, "GBps": x.numel() * 8 / t / 1e9}
+    # the copy ceiling of this box, same process
+    src, dst = torch.empty(1 << 28, dtype=torch.uint8, device="cuda"), torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    t = timed(lambda: L.call("showo_copy_b128", L.ptr(src), L.ptr(dst), src.numel(), s()))
+    copy = 2 * src.numel() / t / 1e9
+    dom = rows["gn_apply_swish_split"]  # the pass the default (split-precision) MAGVIT-v2 runs 42 times per image
+    tot_b = sum(r["bytes"] for r in rows.values())
+    tot_t = sum(r["us"] for r in rows.values()) * 1e-6
+    return {"metric": "MAGVIT-v2 VQ path, HBM-bound kernels: achieved GB/s (LFQ pack / unpack, GroupNorm + swish)", "value": tot_b / tot_t / 1e9,
+            "unit": "GB/s", "n_gpus": 1, "steps": reps, "warmup": a.warmup, "ms_per_step": tot_t * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 -> i64 / bf16", "data": "synthetic",
+            "config": {"workload": "LFQ pack / unpack on 16 x 131 072 tokens (109 MB of latents), GroupNorm(32)+swish on [8, 65 536, 128] fp32 "
+                                   "(268 MB: the decoder's 128-channel 256x256 stage); value = sum of algorithmic bytes / sum of kernel times",
+                       "kernels": rows, "copy_kernel_GBps_same_process": copy},
+            "roofline": {"bound": "hbm", "kernel": "gn_apply_kernel (GroupNorm + swish -> (hi, lo) bf16)", "achieved": dom["GBps"], "peak": 8000.0,
+                         "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": None,
+                         "frac_of_copy_ceiling": dom["GBps"] / copy},
+            "cpu_baseline": None}
+
+
 def main(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", required=True)
@@ -179,9 +254,9 @@ def main(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a, _ = ap.parse_known_args(argv)
     if a.gpus != 1:
-        raise SystemExit("bench: the t2i512 / mmu workloads are single-GPU lines (replicas scale like the headline)")
+        raise SystemExit("bench: the t2i512 / mmu / vq workloads are single-GPU lines (replicas scale like the headline)")
     torch.cuda.set_device(0)
-    out = t2i512(a) if a.workload == "t2i512" else mmu(a)
+    out = {"t2i512": t2i512, "mmu": mmu, "vq": vq}[a.workload](a)
     print(json.dumps(out))
 
 

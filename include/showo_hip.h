@@ -356,6 +356,15 @@ int showo_engine_t2i_captures(const showo_engine* e);
  * embedded input, slot i = output of transformer block i - 1), so that a test can check each block against the oracle evaluated on
  * the block's own input as the GPU computed it (no error amplification across blocks). */
 int showo_engine_set_collect(showo_engine* e, float* buf);
+/* Accuracy mode.  precision 0 (default, the timed path): bf16 GEMM / attention operands, fp32 accumulation.  precision 1: the
+ * reference's fp32 inference (inference_t2i.py:67 keeps the model in fp32; models/phi.py:1182-1183 returns fp32 logits) to ~1e-4 end
+ * to end -- every GEMM on the split-bf16 MFMA kernel (hi + lo operand pairs, see showo_gemm_bf16x3), LayerNorm / q,k-LayerNorm /
+ * RoPE / attention / gelu_new in fp32 on the vector ALU.  Covers showo_engine_forward, _forward_rows and _t2i_generate (eager steps,
+ * no prefix cache); the KV-cached decode entry points refuse.  The weights must be uploaded (showo_engine_load) AFTER switching to
+ * precision 1 -- the loader then also keeps their low halves; showo_engine_precise_ready tells whether they are current. */
+int showo_engine_set_precision(showo_engine* e, int precision);
+int showo_engine_get_precision(const showo_engine* e);
+int showo_engine_precise_ready(const showo_engine* e);
 /* Showo.forward without labels (modeling_showo.py:76-79 -> phi.py:953-1183):
  * ids int64 [B,L] or embeds fp32 [B,L,H] (exactly one non-NULL); mask fp32 [B,1,L,L] or NULL (causal);
  * logits fp32 [B,L,vocab]. */

@@ -109,6 +109,9 @@ _PROTOS = {
     "showo_engine_missing": [c_p],
     "showo_engine_t2i_captures": [c_p],
     "showo_engine_set_collect": [c_p, c_p],
+    "showo_engine_set_precision": [c_p, c_i],
+    "showo_engine_get_precision": [c_p],
+    "showo_engine_precise_ready": [c_p],
     "showo_engine_use_intervals": [c_p, c_p, c_p],
     "showo_engine_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "showo_engine_forward_rows": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p],

@@ -17,6 +17,9 @@ struct Layer {
     float* bd2 = nullptr;
     bf16_t* wq1t = nullptr;  // tiled copy of [Wqkv ; W1] (showo_gemm_tile_weight), allocated on first use
     float *ln_w = nullptr, *ln_b = nullptr, *qln_w = nullptr, *qln_b = nullptr, *kln_w = nullptr, *kln_b = nullptr;
+    // accuracy mode (showo_engine_set_precision 1): low halves of the weights, w = hi + lo to 2^-17 (same layouts as the hi images;
+    // wqkv_lo and w1_lo are one allocation like wqkv / w1)
+    bf16_t *wqkv_lo = nullptr, *wd_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;
 };
 }  // namespace showo
 
@@ -39,6 +42,14 @@ int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const
 int greedy_token_seam(const float* logits, int n, int64_t* tok, int64_t* out_tokens, int* pos, int base, const float* table, float* x, int H,
                       int V, const int32_t* last_iv, int L0, int32_t* iv, hipStream_t s);
 int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t s);
+// accuracy-mode kernels (precise.hip)
+int precise_ln_split(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* hi, bf16_t* lo, int rows, int H,
+                     float eps, hipStream_t s);
+int precise_qk_prep(const float* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
+                    const float* sinT, float* Q, float* K, float* V, int B, int L, int nH, float eps, int pos0, int Lcap, hipStream_t s);
+int precise_attention(const float* Q, const float* K, const float* V, const int32_t* iv, const int32_t* flag, const float* dense, float* O,
+                      int B, int nH, int Lq, int Lk, int Lcap, int ldo, hipStream_t s);
+int precise_gelu_split(const float* f, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t s);
 extern int g_decode_impl;  // 0 = fused decode layer (default), 1 = the seven-launch path (showo_decode_set_impl)
 extern bool g_prof_on_query();
 }  // namespace showo
@@ -116,6 +127,13 @@ struct showo_engine {
     // case that a text row can see an image column
     int32_t* pfx_host = nullptr;
     hipEvent_t ev_pfx = nullptr;
+    // accuracy mode (showo_engine_set_precision): 0 = bf16 operands (default, the timed path), 1 = split-bf16 GEMMs + fp32 attention.
+    // lo_loaded: GEMM weights whose low halves are current (cleared when somebody rewrites the hi images behind the loader's back).
+    int precision = 0;
+    std::set<std::string> lo_loaded;
+    bf16_t* wlm_lo = nullptr;
+    bf16_t *p_hlo = nullptr, *p_actlo = nullptr;                            // low halves of h / hf and of attn | gelu(fc1)
+    float *p_qkv = nullptr, *p_f = nullptr, *p_Q = nullptr, *p_K = nullptr, *p_V = nullptr, *p_a = nullptr;  // fp32 intermediates
     float* collect = nullptr;  // parity hook (showo_engine_set_collect)
     int t2i_captures = 0;  // how often a denoise step was captured (tests: a second identical call must not capture again)
     int* step_dev = nullptr;

@@ -187,8 +187,14 @@ static int copy_f32(float* dst, const float* src, int64_t n, int64_t expect, hip
     if (e != hipSuccess) return set_error_hip(e, "hipMemcpyAsync", __FILE__, __LINE__);
     return 0;
 }
-static int cast_w(bf16_t* dst, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+// GEMM weight: bf16 image; in accuracy mode also the low half (hi + lo = w to 2^-17; hi is the same RNE rounding either way)
+static int cast_w(showo_engine* e, const std::string& key, bf16_t* dst, bf16_t* dst_lo, const float* src, int64_t n, int64_t expect, hipStream_t s) {
     if (n != expect) return set_error_msg(2, "engine_load: element count mismatch");
+    if (e->precision == 1 && dst_lo) {
+        int rc = showo_split_f32_bf16(src, dst, dst_lo, n, s);
+        if (!rc) e->lo_loaded.insert(key);
+        return rc;
+    }
     return showo_cast_f32_bf16(src, dst, n, s);
 }
 
@@ -203,28 +209,28 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     if (k == "showo.model.embed_tokens.weight") rc = copy_f32(e->embed, src, n, V * H, s);
     else if (k == "showo.model.final_layernorm.weight") rc = copy_f32(e->fln_w, src, n, H, s);
     else if (k == "showo.model.final_layernorm.bias") rc = copy_f32(e->fln_b, src, n, H, s);
-    else if (k == "showo.lm_head.weight") rc = cast_w(e->wlm, src, n, V * H, s);
+    else if (k == "showo.lm_head.weight") rc = cast_w(e, k, e->wlm, e->wlm_lo, src, n, V * H, s);
     else if (k == "showo.lm_head.bias") rc = copy_f32(e->blm, src, n, V, s);
     else if (k == "rope.cos") rc = copy_f32(e->cosT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
     else if (k == "rope.sin") rc = copy_f32(e->sinT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
     else if (sscanf(key, "showo.model.layers.%d.%127s", &li, sub) == 2 && li >= 0 && li < e->nL) {
         showo::Layer& l = e->layers[li];
         std::string t(sub);
-        if (t == "self_attn.q_proj.weight") rc = cast_w(l.wqkv, src, n, H * H, s);
-        else if (t == "self_attn.k_proj.weight") rc = cast_w(l.wqkv + H * H, src, n, H * H, s);
-        else if (t == "self_attn.v_proj.weight") rc = cast_w(l.wqkv + 2 * H * H, src, n, H * H, s);
+        if (t == "self_attn.q_proj.weight") rc = cast_w(e, k, l.wqkv, l.wqkv_lo, src, n, H * H, s);
+        else if (t == "self_attn.k_proj.weight") rc = cast_w(e, k, l.wqkv + H * H, l.wqkv_lo ? l.wqkv_lo + H * H : nullptr, src, n, H * H, s);
+        else if (t == "self_attn.v_proj.weight") rc = cast_w(e, k, l.wqkv + 2 * H * H, l.wqkv_lo ? l.wqkv_lo + 2 * H * H : nullptr, src, n, H * H, s);
         else if (t == "self_attn.q_proj.bias") rc = copy_f32(l.bqkv, src, n, H, s);
         else if (t == "self_attn.k_proj.bias") rc = copy_f32(l.bqkv + H, src, n, H, s);
         else if (t == "self_attn.v_proj.bias") rc = copy_f32(l.bqkv + 2 * H, src, n, H, s);
-        else if (t == "self_attn.dense.weight") rc = cast_w(l.wd, src, n, H * H, s);
+        else if (t == "self_attn.dense.weight") rc = cast_w(e, k, l.wd, l.wd_lo, src, n, H * H, s);
         else if (t == "self_attn.dense.bias") rc = copy_f32(l.bd, src, n, H, s);
         else if (t == "self_attn.q_layernorm.weight") rc = copy_f32(l.qln_w, src, n, 64, s);
         else if (t == "self_attn.q_layernorm.bias") rc = copy_f32(l.qln_b, src, n, 64, s);
         else if (t == "self_attn.k_layernorm.weight") rc = copy_f32(l.kln_w, src, n, 64, s);
         else if (t == "self_attn.k_layernorm.bias") rc = copy_f32(l.kln_b, src, n, 64, s);
-        else if (t == "mlp.fc1.weight") rc = cast_w(l.w1, src, n, F * H, s);
+        else if (t == "mlp.fc1.weight") rc = cast_w(e, k, l.w1, l.w1_lo, src, n, F * H, s);
         else if (t == "mlp.fc1.bias") rc = copy_f32(l.b1, src, n, F, s);
-        else if (t == "mlp.fc2.weight") rc = cast_w(l.w2, src, n, H * F, s);
+        else if (t == "mlp.fc2.weight") rc = cast_w(e, k, l.w2, l.w2_lo, src, n, H * F, s);
         else if (t == "mlp.fc2.bias") rc = copy_f32(l.b2, src, n, H, s);
         else if (t == "input_layernorm.weight") rc = copy_f32(l.ln_w, src, n, H, s);
         else if (t == "input_layernorm.bias") rc = copy_f32(l.ln_b, src, n, H, s);
@@ -280,6 +286,7 @@ extern "C" int showo_engine_slot(showo_engine* e, const char* key, int64_t n, ui
 extern "C" int showo_engine_weights_touched(showo_engine* e) {
     if (!e) return set_error_msg(1, "engine: null handle");
     e->fused_valid = false;
+    e->lo_loaded.clear();  // the hi images were rewritten without their low halves: accuracy mode needs a re-upload
     return 0;
 }
 
@@ -372,10 +379,79 @@ static int collect_x(showo_engine* e, int slot, int T, hipStream_t s) {
     return 0;
 }
 
+// ---- accuracy mode (precise.hip): split-bf16 GEMMs, everything between them in fp32 ---------------------------------------------
+extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
+    if (!e) return set_error_msg(1, "engine: null handle");
+    if (precision != 0 && precision != 1) return set_error_msg(1, "engine_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class)");
+    if (precision == 1 && !e->wlm_lo) {  // low halves of every GEMM weight + fp32 workspaces, allocated on first use
+        const int64_t H = e->H, F = e->F, V = e->V, T = e->maxT;
+        int rc = 0;
+        for (auto& l : e->layers) {
+            rc |= e->alloc(&l.wqkv_lo, (3 * H + F) * H);
+            if (!rc) l.w1_lo = l.wqkv_lo + 3 * H * H;
+            rc |= e->alloc(&l.wd_lo, H * H);
+            rc |= e->alloc(&l.w2_lo, H * F);
+        }
+        rc |= e->alloc(&e->p_hlo, T * H); rc |= e->alloc(&e->p_actlo, T * F);
+        rc |= e->alloc(&e->p_qkv, T * 3 * H); rc |= e->alloc(&e->p_f, T * F);
+        rc |= e->alloc(&e->p_Q, T * H); rc |= e->alloc(&e->p_K, T * H); rc |= e->alloc(&e->p_V, T * H); rc |= e->alloc(&e->p_a, T * H);
+        rc |= e->alloc(&e->wlm_lo, V * H);
+        if (rc) return rc;
+    }
+    e->precision = precision;
+    return 0;
+}
+// 1 when every GEMM weight has a current low half (q, k, v, dense, fc1, fc2 per layer + lm_head), i.e. precision 1 can run
+extern "C" int showo_engine_precise_ready(const showo_engine* e) {
+    return e && e->wlm_lo && (int)e->lo_loaded.size() == e->nL * 6 + 1;
+}
+extern "C" int showo_engine_get_precision(const showo_engine* e) { return e ? e->precision : -1; }
+
+static int precise_check(showo_engine* e) {
+    if (!showo_engine_precise_ready(e))
+        return set_error_msg(4, "engine (precision 1): the low halves of the weights are missing or stale (weights were loaded before "
+                                "showo_engine_set_precision(e, 1), or rewritten by the trainer): upload the weights again");
+    return 0;
+}
+
+// One pass over the layer stack in accuracy mode.  Same operation order as models/phi.py:774-790; the two residual adds land as
+// (x + dense(attn)) + fc2(gelu(fc1(h))) (fp32 either way).  K / V of the call live in the fp32 workspace: no KV cache in this mode.
+static int run_layers_precise(showo_engine* e, int B, int L, const int32_t* iv, const int32_t* flag, const float* dense, hipStream_t s) {
+    const int H = e->H, F = e->F, nH = e->nH, T = B * L;
+    TRY(precise_check(e));
+    if (e->cfg.rotary_dim != 32) return set_error_msg(1, "engine (precision 1): rotary_dim 32 only");
+    TRY(collect_x(e, 0, T, s));
+    for (int li = 0; li < e->nL; ++li) {
+        showo::Layer& l = e->layers[li];
+        TRY(showo::precise_ln_split(e->x, l.ln_w, l.ln_b, nullptr, e->h, e->p_hlo, T, H, e->cfg.ln_eps, s));
+        TRY(showo_gemm_bf16x3(e->h, e->p_hlo, H, l.wqkv, l.wqkv_lo, H, l.bqkv, 0, e->p_qkv, 3 * H, nullptr, 0, T, 3 * H, H, s));
+        TRY(showo::precise_qk_prep(e->p_qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->p_Q, e->p_K, e->p_V, B, L, nH,
+                                   e->cfg.ln_eps, 0, L, s));
+        TRY(showo::precise_attention(e->p_Q, e->p_K, e->p_V, iv, flag, dense, e->p_a, B, nH, L, L, L, H, s));
+        TRY(showo_split_f32_bf16(e->p_a, e->attn, e->p_actlo, (int64_t)T * H, s));
+        TRY(showo_gemm_bf16x3(e->attn, e->p_actlo, H, l.wd, l.wd_lo, H, l.bd, 0, e->x, H, e->x, H, T, H, H, s));
+        TRY(showo_gemm_bf16x3(e->h, e->p_hlo, H, l.w1, l.w1_lo, H, l.b1, 0, e->p_f, F, nullptr, 0, T, F, H, s));
+        TRY(showo::precise_gelu_split(e->p_f, e->ffn, e->p_actlo, (int64_t)T * F, s));
+        TRY(showo_gemm_bf16x3(e->ffn, e->p_actlo, F, l.w2, l.w2_lo, F, l.b2, 0, e->x, H, e->x, H, T, H, F, s));
+        TRY(collect_x(e, li + 1, T, s));
+    }
+    return 0;
+}
+static int head_rows_precise(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
+    TRY(precise_check(e));
+    TRY(showo::precise_ln_split(e->x, e->fln_w, e->fln_b, rows, e->hf, e->p_hlo, nrows, e->H, e->cfg.ln_eps, s));
+    return showo_gemm_bf16x3(e->hf, e->p_hlo, e->H, e->wlm + (int64_t)col0 * e->H, e->wlm_lo + (int64_t)col0 * e->H, e->H, e->blm + col0, 0,
+                             logits, ncols, nullptr, 0, nrows, ncols, e->H, s);
+}
+
 static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
                       const float* dense, hipStream_t s) {
     const int H = e->H, F = e->F, nH = e->nH;
     const int T = B * L;
+    if (e->precision == 1) {
+        if (pos0 != 0 || kv.k != e->K) return set_error_msg(1, "engine (precision 1): KV-cached calls are not available in accuracy mode");
+        return run_layers_precise(e, B, L, iv, flag, dense, s);
+    }
     TRY(collect_x(e, 0, T, s));
     const int Lk = pos0 + L;
     const int Lcap = kv.Lcap, Lp = kv.Lp;
@@ -582,6 +658,7 @@ static int hidden(showo_engine* e, const int64_t* ids, const float* embeds, cons
 
 static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
     if (col0 < 0 || ncols <= 0 || col0 + ncols > e->V) return set_error_msg(1, "engine: bad vocabulary slice");
+    if (e->precision == 1) return head_rows_precise(e, rows, nrows, col0, ncols, logits, s);
     if (nrows == 1 && !rows && showo::g_decode_impl == 0 && showo::decode_fused_shapes_ok(e->H, e->F))  // decode step: LN + lm_head in one launch
         return showo::decode_ln_gemv2(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, e->H, e->wlm + (int64_t)col0 * e->H, e->blm + col0,
                                       nullptr, logits, ncols, nullptr, nullptr, nullptr, 0, s);
@@ -644,7 +721,7 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     const int prefix = text_len + 1;
     const int La = L - prefix;
     const int LpC = ((L + 63) / 64) * 64;
-    const bool reuse_ok = !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
+    const bool reuse_ok = e->precision == 0 && !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
     hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cs0);
     if (cs0 != hipStreamCaptureStatusNone) return set_error_msg(7, "t2i_generate: the call captures its own graph; do not call it inside a stream capture");
@@ -713,7 +790,7 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     // once (first-use attributes, GEMM tile tuning) outside the capture; step 0 always runs eagerly.  Not combined with per-launch
     // event timing.
     const int n_eager = reuse ? 2 : 1;
-    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query();
+    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query() && e->precision == 0;
     if (!graph) {
         for (int step = 0; step < steps; ++step) TRY(denoise_step(step, step == 0 || !reuse));
     } else {
@@ -830,6 +907,7 @@ extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const f
                                     float* logits_last, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     TRY(check_ready(e, 1, L));
+    if (e->precision == 1) return set_error_msg(1, "prefill: the KV-cached decode runs with bf16 operands only (showo_engine_set_precision(e, 0))");
     TRY(ensure_cache(e, L + 1));
     TRY(embed_in(e, ids, embeds, L, s));
     const int32_t *iv = nullptr, *flag = nullptr;

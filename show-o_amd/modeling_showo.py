@@ -202,6 +202,16 @@ class _MMProjector(nn.Sequential):
         self._dims = (din, dout)
         self._proj, self._rows, self._versions = None, 0, None
 
+    def set_precision(self, precision):
+        """0 (default): bf16 GEMM / attention operands with fp32 accumulation -- the timed path.  1: accuracy mode, the reference's
+        fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
+        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels and t2i_generate();
+        mmu_generate() and training keep bf16 operands (mmu_generate raises in mode 1).  Costs a second bf16 image of the weights."""
+        if int(precision) not in (0, 1):
+            raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
+        self._precision = int(precision)
+        return self
+
     def mark_weights_dirty(self):
         """re-upload the projector's parameters at the next call (updates through `.data` do not bump tensor versions)"""
         if getattr(self, "_proj", None) is not None:
@@ -287,6 +297,7 @@ class Showo(PretrainedMixin, nn.Module):
         self._weights_changed = True
         self.max_batch = int(kwargs.get("max_batch", 32))
         self.max_seq = int(kwargs.get("max_seq", 1280))
+        self._precision = 0
 
     def _init_from_phi_checkpoint(self, llm_model_path):
         """`load_from_showo=False`: start from a Hugging Face Phi checkpoint in the local directory `llm_model_path`
@@ -357,6 +368,16 @@ class Showo(PretrainedMixin, nn.Module):
         missing = [k for k in want if k not in seen and k not in allowed_missing]
         if missing:
             raise KeyError(f"Phi checkpoint {d} lacks {len(missing)} tensors, e.g. {missing[:5]}")
+
+    def set_precision(self, precision):
+        """0 (default): bf16 GEMM / attention operands with fp32 accumulation -- the timed path.  1: accuracy mode, the reference's
+        fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
+        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels and t2i_generate();
+        mmu_generate() and training keep bf16 operands (mmu_generate raises in mode 1).  Costs a second bf16 image of the weights."""
+        if int(precision) not in (0, 1):
+            raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
+        self._precision = int(precision)
+        return self
 
     def mark_weights_dirty(self):
         """Re-upload every parameter to the HIP engine at the next call.  The engine notices parameter changes by
@@ -456,6 +477,11 @@ class Showo(PretrainedMixin, nn.Module):
             _lib.call("showo_engine_load", self._engine, b"rope.cos", _lib.ptr(cos), cos.numel(), _lib.stream())
             _lib.call("showo_engine_load", self._engine, b"rope.sin", _lib.ptr(sin), sin.numel(), _lib.stream())
             torch.cuda.current_stream().synchronize()
+        want = int(getattr(self, "_precision", 0))
+        if lib.showo_engine_get_precision(self._engine) != want:
+            _lib.call("showo_engine_set_precision", self._engine, want)
+        if want == 1 and not lib.showo_engine_precise_ready(self._engine):
+            self._engine_versions = {}  # the low halves of the weights are made by the loader: upload everything again
         for k, v in self._engine_params():
             ver = (v.data_ptr(), v._version)
             if self._engine_versions.get(k) != ver:

@@ -32,6 +32,9 @@ pytestmark = pytest.mark.gpu
 
 REL_RMS, REL_MAX = 1e-2, 3e-2
 BF16_POINTS_TOL = 1e-3
+# accuracy mode (Showo.set_precision(1): split-bf16 GEMMs, fp32 attention): north_star's "logits within 1e-3", end to end, vs the
+# fp32 reference: max|d| / max|ref| <= 1e-3 (and the rms ratio likewise)
+PRECISE_TOL = 1e-3
 
 
 def _check_logits(got, ref, what):
@@ -57,6 +60,63 @@ def test_tiny_forward_matches_reference_golden():
     assert torch.equal(lg, lg) and (lg2 - m(dev(g["mmu_ids"]), attention_mask=dev(g["mmu_mask"]))).abs().max() == 0
     with pytest.raises(ValueError):
         m(dev(g["mmu_ids"]), attention_mask=dev(g["t2i_mask"]))
+
+
+def _check_precise(got, ref, what):
+    rmax, rrms = util.relerr(got, ref)
+    print(f"[parity] accuracy mode, {what}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rmax <= PRECISE_TOL and rrms <= PRECISE_TOL, (what, rmax, rrms)
+    return rmax
+
+
+def test_tiny_accuracy_mode_logits_within_1e3_of_the_fp32_reference_end_to_end():
+    """precision 1 (split-bf16 MFMA GEMMs + fp32 LayerNorm / RoPE / attention / gelu) against the REFERENCE's fp32 logits
+    (tests/golden/showo_tiny_forward.npz, showo_tiny_t2i.npz): every mask family, the inputs_embeds path, the row / column sliced head,
+    the 6-step trajectory with the reference's noise, and switching back to bf16 operands on the same engine."""
+    g = util.golden("showo_tiny_forward.npz")
+    d, sd = util.tiny_state()
+    m = util.build_showo(d, sd).set_precision(1)
+    for key in ("t2i", "mmu", "train"):
+        lg = m(dev(g[f"{key}_ids"]), attention_mask=dev(g[f"{key}_mask"]))
+        assert lg.dtype == torch.float32
+        _check_precise(lg, torch.from_numpy(g[f"{key}_logits"]), f"tiny {key} logits vs the fp32 reference")
+    emb = m.showo.model.embed_tokens.weight[dev(g["mmu_ids"])]
+    lg2 = m(None, input_embeddings=emb, attention_mask=dev(g["mmu_mask"]))
+    _check_precise(lg2, torch.from_numpy(g["mmu_logits"]), "tiny mmu logits from input_embeddings")
+    # interval masks built on the device give the same bits as the dense reference masks
+    P = util.pkg().prompting_utils
+    ids = dev(g["t2i_ids"])
+    iv = P.intervals_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id, rm_pad_in_image=True)
+    assert torch.equal(m(ids, attention_mask=iv), m(ids, attention_mask=dev(g["t2i_mask"])))
+    # t2i_generate in accuracy mode: the reference's trajectory under its own noise, and its per-step logits
+    g2 = util.golden("showo_tiny_t2i.npz")
+    steps, B = int(g2["steps"]), g2["ids_cond"].shape[0]
+    N, V = d.num_vq_tokens, d.codebook
+    ids_c = dev(g2["ids_cond"]).clone()
+    out = m.t2i_generate(input_ids=ids_c, uncond_input_ids=dev(g2["ids_uncond"]), attention_mask=dev(g2["mask"]), timesteps=steps,
+                         guidance_scale=float(g2["guidance"]), config=util.gen_config(d),
+                         _exp_noise=dev(g2["exp_noise"].reshape(steps, B * N, V)), _uniform=dev(g2["uniform"].reshape(steps, B, N)))
+    assert torch.equal(out.cpu(), torch.from_numpy(g2["result"])) and torch.equal(ids_c.cpu(), torch.from_numpy(g2["final_input_ids"]))
+    worst = 0.0
+    for s in range(steps):
+        worst = max(worst, _check_precise(m(dev(g2["fwd_in"][s]), attention_mask=dev(g2["mask"])), torch.from_numpy(g2["fwd_logits"][s]),
+                                          f"teacher-forced step {s}"))
+    # KV-cached decode keeps bf16 operands: accuracy mode refuses instead of silently answering with another arithmetic
+    with pytest.raises(RuntimeError):
+        m.mmu_generate(dev(g["mmu_ids"])[:1], attention_mask=dev(g["mmu_mask"])[:1], max_new_tokens=2, top_k=1)
+    # back to bf16 operands on the same engine: the default path's numbers
+    m.set_precision(0)
+    lg0 = m(dev(g["t2i_ids"]), attention_mask=dev(g["t2i_mask"]))
+    ref0 = util.build_showo(d, sd)(dev(g["t2i_ids"]), attention_mask=dev(g["t2i_mask"]))
+    assert torch.equal(lg0, ref0)
+    # a training step rewrites the bf16 images through the optimizer: the next accuracy-mode call re-uploads (hi, lo) by itself
+    m.train()
+    tr = util.pkg().Trainer(m, lr=1e-3)
+    tr.step(dev(g["train_ids"]), dev(g["train_mask"]), dev(g["train_labels"]), 2, 1, 2, d.max_text_len)
+    m.eval().set_precision(1)
+    sd_now = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = O.showo_logits(sd_now, d, torch.from_numpy(g["t2i_ids"]), attention_mask=torch.from_numpy(g["t2i_mask"]))
+    _check_precise(m(dev(g["t2i_ids"]), attention_mask=dev(g["t2i_mask"])), want, "tiny t2i logits after one optimizer step vs the oracle on the updated weights")
 
 
 def _blockwise_bf16_points(m, d, sdt, ids, mask, what, qkv_round, blocks=None):
@@ -337,6 +397,17 @@ def test_full_size_logits_vs_reference_subset():
     print(f"[parity] full-size logits vs reference subset: rel_max={rmax:.3e} rel_rms={rrms:.3e} "
           f"(abs max err {float((sub.cpu() - ref).abs().max()):.3e}, logit absmax {float(g['logit_absmax']):.3f}, std {float(g['logit_std']):.3f})")
     assert rrms <= REL_RMS and rmax <= REL_MAX
+    # accuracy mode at full size, END TO END against the fp32 reference: north_star's "logits within 1e-3"
+    m.set_precision(1)
+    lgp = m(ids, attention_mask=mask)
+    subp = lgp[:, torch.from_numpy(g["rows"]).cuda()][:, :, torch.from_numpy(g["cols"]).cuda()]
+    pmax, prms = util.relerr(subp, ref)
+    print(f"[parity] full-size logits, accuracy mode (split-bf16 GEMMs, fp32 attention) vs the fp32 reference subset: rel_max={pmax:.3e} "
+          f"rel_rms={prms:.3e} (bf16 operands: rel_max={rmax:.3e} rel_rms={rrms:.3e})")
+    assert pmax <= PRECISE_TOL and prms <= PRECISE_TOL
+    del lgp, subp
+    m.set_precision(0)
+    assert torch.equal(m(ids, attention_mask=mask), lg)  # back on the bf16 path: the same bits as before
     # north_star's 1e-3, block by block at full size (blocks 0, 1, 11, 23 and the head: each on the GPU's own block input), and the
     # end-to-end comparison with the rounding-point oracle for the record
     sdt = O.to_torch(Wt.make_showo_state(d, seed=int(g["seed"])))

@@ -46,7 +46,13 @@ def main():
         f = sum(v["launches"] * (v["fetch_bytes_per_launch"] or 0) for k, v in kernels.items() if k.startswith(prefix)) / n
         w = sum(v["launches"] * (v["write_bytes_per_launch"] or 0) for k, v in kernels.items() if k.startswith(prefix)) / n
         return {"launches": n, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "bytes_per_launch": f + w}
-    res = {"tag": tag, "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-events (one --pmc pass per counter)",
+    import hashlib
+    h = hashlib.sha1()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("gemm_common.h", "gemm2p.hip", "gemm3w.hip"):  # same definition as bench.py::gemm_src_sha1
+        with open(os.path.join(root, "show-o_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    res = {"tag": tag, "kernel_src_sha1": h.hexdigest(), "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-events (one --pmc pass per counter)",
            "corrections": "fetch = 2 x FETCH_SIZE KiB (gfx950 wide-read halving), write = WRITE_SIZE KiB (uncalibrated)",
            "gemm2p_kernel": group(("gemm2p_kernel", "gemm3w_kernel")),  # the bf16 GEMM family (gemm2p.hip + its weight-ring form gemm3w.hip)
             "attn_fwd_lds_kernel": group("attn_fwd_lds_kernel"),
