@@ -103,6 +103,33 @@ def gemm_src_sha1():
     return h.hexdigest()
 
 
+def dry_run():
+    """SHOWO_BENCH_DRYRUN=1: exercise ONLY the launch plumbing of the multi-GPU lines -- self-launch under torch.distributed.run,
+    rank environment, the MAX-time / SUM-units aggregation, the training leg's child ranks with their own rendezvous -- with gloo
+    and no GPU work (tests/test_dist_cpu.py runs it with two real processes; the first N > 1 run on hardware is then not a cold start)."""
+    return os.environ.get("SHOWO_BENCH_DRYRUN", "0") == "1"
+
+
+def dry_main(a):
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    dt, units = aggregate(0.01 * (rank + 1), a.batch * a.steps, dist, "cpu")
+    train_step = None if a.no_train_leg else train_leg(world, rank, steps=1, warmup=0, timeout_s=180)
+    if rank == 0:
+        print(json.dumps({"metric": "t2i images/sec @256x256 (18 denoise steps)", "value": units / dt, "unit": "images/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "dry-run: launch plumbing only, no GPU work (SHOWO_BENCH_DRYRUN=1)",
+                          "config": {"workload": "dry-run"}, "dryrun": {"ranks": world, "units": units, "max_dt": dt,
+                                                                          "master_port": os.environ.get("MASTER_PORT")},
+                          "train_step": train_step, "cpu_baseline": None}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_launch(gpus, script):
     """`python bench.py --gpus N` without a launcher: re-exec as N ranks (one process per GPU) under torch.distributed.run, as
     the reference is started by `accelerate launch` (training/train.py:91-110; accelerate_configs/8_gpus_deepspeed_zero2.yaml).
@@ -115,7 +142,7 @@ def self_launch(gpus, script):
     if gpus <= 1:
         return
     have = torch.cuda.device_count()
-    if have < gpus:
+    if have < gpus and not dry_run():
         raise SystemExit(f"bench: --gpus {gpus} requested but {have} GPU(s) are visible")
     import socket
     import subprocess
@@ -164,6 +191,8 @@ def train_leg(world, rank, steps=4, warmup=2, timeout_s=420):
             "global_batch": d["config"].get("global_batch"), "tokens_per_s": d["config"].get("tokens_per_s"),
             "gradient_wire": d["config"].get("gradient_wire"), "gemm_tflops": d["roofline"].get("achieved"),
             "gemm_frac_of_mfma_peak": d["roofline"].get("frac"),
+            "exchange_exposed_ms": d["config"].get("exchange_exposed_ms"), "wire_bytes_per_rank": d["config"].get("wire_bytes_per_rank"),
+            "dryrun": d.get("dryrun"),
             "source": "bench_train.py run by this command as child ranks (one process per GPU, RCCL all-reduce of the gradient buckets overlapped with backward)"}
 
 
@@ -206,6 +235,8 @@ def main():
                     "t2i512 | mmu (bench_configs.py: BASELINE configs[2] / configs[3])")
     a = ap.parse_args()
     self_launch(a.gpus, __file__)
+    if dry_run():
+        return dry_main(a)
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # shows where a stuck run is
 

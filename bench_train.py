@@ -91,6 +91,22 @@ def main(argv=None):
     import bench
     bench.self_launch(a.gpus, sys.argv[0])  # `--gpus N` without a launcher: re-exec as N ranks under torch.distributed.run
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if bench.dry_run():  # launch plumbing only (bench.dry_run): rendezvous of the ranks over gloo, one all-reduce, the line's shape
+        x = torch.tensor([rank + 1.0])
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            dist.all_reduce(x)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "train step-time (dry-run)", "value": 1.0, "unit": "ms/step", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": 1.0, "higher_is_better": False, "scaling": "weak", "data": "dry-run",
+                              "config": {"global_batch": 29 * world, "tokens_per_s": None, "gradient_wire": a.wire if world > 1 else None},
+                              "roofline": {"achieved": None, "frac": None},
+                              "dryrun": {"world": world, "master_port": os.environ.get("MASTER_PORT"), "allreduce_sum": float(x),
+                                         "agent_store_env": "TORCHELASTIC_USE_AGENT_STORE" in os.environ}}))
+        return
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -139,6 +155,8 @@ def main(argv=None):
     L.call("showo_prof_reset")
     L.call("showo_prof_set_stride", a.event_stride)  # per-launch events on a systematic sample of the launches
     L.call("showo_prof_enable", 0 if a.no_events else 1)
+    if trainer.exchange is not None:
+        trainer.exchange.measure(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -158,6 +176,8 @@ def main(argv=None):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    exposed_ms = trainer.exchange.exposed_ms() if trainer.exchange is not None else None
+    wire_bytes = trainer.exchange.wire_bytes() if trainer.exchange is not None else None
     if rank == 0:
         T = (bt + bl + bm) * 387
         ms = dt / a.steps * 1e3
@@ -187,6 +207,9 @@ def main(argv=None):
                        "parallelism": f"dp{world}", "tokens_per_s": T * world / (ms * 1e-3),
                        "algorithmic_tflops_per_gpu": flop / (ms * 1e-3) / 1e12,
                        "gradient_wire": a.wire if world > 1 else None,
+                       # GPU time the compute stream spends in GradientExchange.finish() (waiting for the collectives that did not
+                       # hide behind backward + widening the wire) and the bytes every rank hands to RCCL per step
+                       "exchange_exposed_ms": exposed_ms, "wire_bytes_per_rank": wire_bytes,
                        "losses_last_step": losses_host},
             "roofline": roofline, "cpu_baseline": cpu,
         }))

@@ -61,6 +61,19 @@ class GradientExchange:
         self.world = dist.get_world_size(group)
         self.stage = [torch.empty(b.numel(), dtype=torch.bfloat16, device=b.device) for b in buckets] if wire == "bf16" else None
         self.works = []
+        self._measure, self._spans = False, []
+
+    def measure(self, on=True):
+        """record the GPU time of every finish() (device events on the compute stream) from now on; exposed_ms() reads the mean"""
+        self._measure, self._spans = bool(on), []
+
+    def exposed_ms(self):
+        """mean GPU time per step that the compute stream spent in finish(): waiting for collectives that did not hide behind the
+        backward, plus widening / scaling the wire.  None when nothing was measured (CPU buckets, measure() off)."""
+        if not self._spans:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._spans) / len(self._spans)
 
     def wire_bytes(self):
         """bytes every rank hands to the collective per step"""
@@ -75,6 +88,16 @@ class GradientExchange:
         self.works.append((self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), b))
 
     def finish(self):
+        span = None
+        if self._measure and self.buckets and self.buckets[0].is_cuda:
+            span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            span[0].record()
+        self._finish()
+        if span is not None:
+            span[1].record()
+            self._spans.append(span)
+
+    def _finish(self):
         for w, b in self.works:
             if w is not None:
                 w.wait()

@@ -84,7 +84,8 @@ def test_clip_vit_l_14_336_full_size_vs_transformers_subset():
     # These synthetic weights amplify rounding (sharp soft-max: q/k projections at twice the usual scale, 23 blocks): rounding only
     # the GEMM operands of the fp32 oracle to bf16 on the CPU already gives rel_rms 2.9e-2 / rel_max 2.9e-2 against the fp32
     # reference; the HIP path also rounds Q, K, V, P and the MLP activations (measured 4.1e-2 / 2.5e-2).
-    assert rel_rms < 6e-2 and rel_max < 5e-2
+    # gate = measured + 25 %
+    assert rel_rms < 5.2e-2 and rel_max < 3.2e-2
 
 
 def test_mm_projector_hip_forward_vs_torch_module_golden():

@@ -90,3 +90,38 @@ def test_no_decay_rule_is_the_reference_rule():
     assert any(x in "showo.model.layers.0.mlp.fc1.bias" for x in nd)
     assert not any(x in "showo.model.layers.0.input_layernorm.weight" for x in nd)
     assert not any(x in "showo.model.embed_tokens.weight" for x in nd)
+
+
+def test_bench_gpus_2_launch_plumbing_with_two_real_processes():
+    """`python bench.py --gpus 2` end to end with REAL processes (no monkeypatching): bench.self_launch re-execs the
+    command as 2 ranks under torch.distributed.run, the ranks rendezvous (gloo here, RCCL on the GPU box), aggregate MAX time / SUM
+    units, and every rank starts bench_train.py as a child whose ranks rendezvous among themselves on MASTER_PORT + 101 without the
+    launcher's agent store.  SHOWO_BENCH_DRYRUN=1 removes the GPU work only; launch code, environment handling and aggregation are the
+    product's."""
+    import json
+    import subprocess
+    env = dict(os.environ, SHOWO_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-800:]  # only rank 0 prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dryrun"]["ranks"] == 2
+    assert d["dryrun"]["units"] == 2 * 8 * 3                      # SUM of the units of both ranks
+    assert abs(d["dryrun"]["max_dt"] - 0.02) < 1e-9               # MAX over ranks (rank 1 reported 0.02)
+    ts = d["train_step"]
+    assert ts is not None and "error" not in ts, ts
+    assert ts["n_gpus"] == 2 and ts["global_batch"] == 58 and ts["gradient_wire"] == "bf16"
+    child = ts["dryrun"]
+    assert child["world"] == 2 and child["allreduce_sum"] == 3.0  # the two CHILD ranks found each other: 1 + 2
+    assert int(child["master_port"]) == int(d["dryrun"]["master_port"]) + 101
+    assert child["agent_store_env"] is False
+    # the training line on its own, launched the same way
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][0])
+    assert d2["n_gpus"] == 2 and d2["dryrun"]["allreduce_sum"] == 3.0
