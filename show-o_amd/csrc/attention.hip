@@ -162,7 +162,31 @@ struct AttnArgs {
     int B, nH, Lq, Lk, Lcap, Lp, ldo;
     float* lse;  // optional (training): log-sum-exp of every score row, fp32 [B, nH, Lq]
     const int* pos_dev;  // graph replay of a decode step (Lq = 1): Lk = *pos_dev + 1 read on the device
+    int nqb = 0;  // LDS-tiled form launched as a 1-D grid of nqb * nH * B blocks in the XCD-aware order below (0: 3-D grid (qb, head, b))
 };
+
+// XCD-aware block order of the LDS-tiled forward.  Hardware places block `id` on XCD `id % 8`, each XCD has its own 4 MiB L2.  With
+// the natural (qb, head, b) grid the q-blocks of one (batch, head) -- which all stream the SAME K / V^T tiles -- have consecutive ids
+// and land on different XCDs: every tile crosses the fabric once per q-block (PMC r2: 158 MB fetched per launch against 68 MB of
+// Q / K / V^T at Lq = 258, where a (batch, head) has 3 q-blocks).  Here 8 (batch, head) pairs form a group of 8 * nqb blocks in which
+// pair j owns the ids j, j + 8, j + 16, ...: same XCD, dispatched back to back, so the second and third q-block find the tiles in
+// that XCD's L2.  Pairs beyond the last full group of 8 keep the natural order.
+__device__ __forceinline__ void attn_block_coords(const AttnArgs& a, int& qb, int& head, int& b) {
+    if (a.nqb == 0) { qb = blockIdx.x; head = blockIdx.y; b = blockIdx.z; return; }
+    const int lin = blockIdx.x, nbh = a.nH * a.B, per = 8 * a.nqb, full = nbh & ~7;
+    int bh;
+    if (lin < (full >> 3) * per) {
+        const int grp = lin / per, rem = lin - grp * per;
+        qb = rem >> 3;
+        bh = grp * 8 + (rem & 7);
+    } else {
+        const int t = lin - (full >> 3) * per, tail = nbh - full;
+        qb = t / tail;
+        bh = full + (t - qb * tail);
+    }
+    b = bh / a.nH;
+    head = bh - b * a.nH;
+}
 
 __device__ inline bf16x8 pack8(const float* p) {
     uint4 u;
@@ -312,9 +336,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 template <bool DENSE, int WPB>
 __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int* s_hull) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qblk = blockIdx.x * WPB + wave;
+    int qb_, head, b;
+    attn_block_coords(a, qb_, head, b);
+    const int qblk = qb_ * WPB + wave;
     const bool wactive = qblk * 32 < a.Lq;
-    const int head = blockIdx.y, b = blockIdx.z;
     const int qi = lane & 31, hh = lane >> 5;
     const int qrow_raw = qblk * 32 + qi;
     const int qrow = qrow_raw < a.Lq ? qrow_raw : a.Lq - 1;
@@ -756,10 +781,19 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
             return 0;
         }
     }
-    if (tiled && forced == 3) attn_fwd_lds_kernel<3><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
-    else if (tiled && (qblocks + 4) / 5 < (qblocks + 3) / 4 && g_attn_wpb5)  // five query tiles per block save a block per (b, head)
-        attn_fwd_lds_kernel<3, 5><<<dim3((qblocks + 4) / 5, nH, B), dim3(320), 0, (hipStream_t)stream>>>(a);
-    else if (tiled) attn_fwd_lds_kernel<4><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    // SHOWO_ATTN_XCD (default 1): XCD-aware 1-D block order (attn_block_coords); 0 = the natural 3-D grid (A/B runs).
+    // SHOWO_ATTN_WPB9=1: all (up to 9) query tiles of a (batch, head) in ONE 576-thread block -- every K / V^T tile is staged once per
+    // (batch, head) -- for 129 <= Lq <= 288 (the 258 active rows of the t2i loop).
+    static int xcd = -1, wpb9 = -1;
+    if (xcd < 0) { const char* e = getenv("SHOWO_ATTN_XCD"); xcd = e ? (atoi(e) != 0) : 1; }
+    if (wpb9 < 0) { const char* e = getenv("SHOWO_ATTN_WPB9"); wpb9 = e ? (atoi(e) != 0) : 0; }
+    auto grid = [&](int nqb) { if (xcd) { a.nqb = nqb; return dim3((unsigned)nqb * nH * B); } a.nqb = 0; return dim3(nqb, nH, B); };
+    if (tiled && forced == 3) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<3><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
+    else if (tiled && wpb9 && qblocks > 4 && qblocks <= 9) { const dim3 g = grid(1); attn_fwd_lds_kernel<2, 9><<<g, dim3(576), 0, (hipStream_t)stream>>>(a); }
+    else if (tiled && (qblocks + 4) / 5 < (qblocks + 3) / 4 && g_attn_wpb5) {  // five query tiles per block save a block per (b, head)
+        const dim3 g = grid((qblocks + 4) / 5);
+        attn_fwd_lds_kernel<3, 5><<<g, dim3(320), 0, (hipStream_t)stream>>>(a);
+    } else if (tiled) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<4><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
     else attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;

@@ -202,7 +202,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 //        part[blk][4][64] = per-block partials of (dqln_w, dqln_b, dkln_w, dkln_b).
 //   One wave per (token, head) row, lane = head dim.
 // ------------------------------------------------------------------------------------------------
-constexpr int QKB_ROWS = 8;  // rows (token, head pairs) per wave per block (short: occupancy hides the shuffle latency)
+// Round 3 layout: a (token, head) row of 64 dims is held by 8 lanes x 8 consecutive dims (one 16-B load per operand), so a wave
+// handles 8 rows -- the 8 consecutive heads of a token = 1 KiB contiguous per load instruction -- and every 64-dim reduction is 3
+// DPP steps over the 8 lanes of a row instead of 6 over a whole wave (round 2's one-lane-per-dim form ran at 5 x its byte floor:
+// 2-byte loads and 8 wave-wide reductions per row).  The rotate_half partner d <-> d + 16 is lane ^ 2.
+// Algorithmic bytes per token: dq, dk, q, k in (4 x 2H) + dq', dk' out (2 x 2H) = 12 H B = 276 MB at T = 11 223, H = 2048.
+constexpr int QKB_ROWS = 64;  // rows per wave (8 iterations of 8 rows); a 4-wave block covers 256 rows
+__device__ __forceinline__ float row8_sum(float v) {  // sum over the 8 lanes that share a row (lane bits 0..2)
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
+    f[0] = bf2f((bf16_t)(u.x & 0xffffu)); f[1] = bf2f((bf16_t)(u.x >> 16));
+    f[2] = bf2f((bf16_t)(u.y & 0xffffu)); f[3] = bf2f((bf16_t)(u.y >> 16));
+    f[4] = bf2f((bf16_t)(u.z & 0xffffu)); f[5] = bf2f((bf16_t)(u.z >> 16));
+    f[6] = bf2f((bf16_t)(u.w & 0xffffu)); f[7] = bf2f((bf16_t)(u.w >> 16));
+}
 __global__ __launch_bounds__(256) void qkln_rope_bwd_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, int ldg,
                                                             const bf16_t* __restrict__ qkv, const float* __restrict__ qw,
                                                             const float* __restrict__ kw, const float* __restrict__ cosT,
@@ -210,39 +227,87 @@ __global__ __launch_bounds__(256) void qkln_rope_bwd_kernel(const bf16_t* __rest
                                                             float* __restrict__ part, int T, int L, int nH, float eps) {
     __shared__ float red[4][4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = lane & 7, slot = lane >> 3;  // dims 8 sub .. 8 sub + 7 of row `slot` of the iteration
     const int H = nH * 64;
     const int64_t rows = (int64_t)T * nH;
-    float awq = 0.f, abq = 0.f, awk = 0.f, abk = 0.f;
-    const float wq = qw[lane], wk = kw[lane];
+    float acc[4][8];  // per-lane partials of (dq_ln_w, dq_ln_b, dk_ln_w, dk_ln_b) for the lane's 8 dims
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
+    float wq[8], wk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wq[j] = qw[8 * sub + j]; wk[j] = kw[8 * sub + j]; }
     const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * QKB_ROWS;
-    for (int i = 0; i < QKB_ROWS; ++i) {
-        const int64_t row = base + i;
-        if (row >= rows) break;
-        const int tok = (int)(row / nH), head = (int)(row - (int64_t)tok * nH);
+    for (int it = 0; it < QKB_ROWS / 8; ++it) {
+        const int64_t row = base + it * 8 + slot;
+        const bool live = row < rows;
+        const int64_t rr = live ? row : rows - 1;  // clamped rows compute on valid memory; they neither store nor accumulate
+        const int tok = (int)(rr / nH), head = (int)(rr - (int64_t)tok * nH);
         const int pos = tok % L;  // training sequences start at position 0 (phi.py:998-1003)
-        const float c = lane < 32 ? cosT[(int64_t)pos * 32 + lane] : 1.f;
-        const float sn = lane < 32 ? sinT[(int64_t)pos * 32 + lane] : 0.f;
+        float c[8], sn[8];
+        if (sub < 4) {
+            const float4 c0 = *reinterpret_cast<const float4*>(cosT + (int64_t)pos * 32 + 8 * sub), c1 = *reinterpret_cast<const float4*>(cosT + (int64_t)pos * 32 + 8 * sub + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(sinT + (int64_t)pos * 32 + 8 * sub), s1 = *reinterpret_cast<const float4*>(sinT + (int64_t)pos * 32 + 8 * sub + 4);
+            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+            sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { c[j] = 1.f; sn[j] = 0.f; }
+        }
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
-            const float g = bf2f((which ? dk : dq)[(int64_t)tok * ldg + head * 64 + lane]) * (which ? 1.0f : 0.125f);
-            // rope^T: y'[d] = y[d] c[d] + rot(y)[d] s[d], rot(y)[d] = -y[d+16] (d<16), +y[d-16] (16<=d<32)
-            //   => dy[d] = g[d] c[d] + (d < 16 ? g[d+16] s[d+16] : -g[d-16] s[d-16])
-            const float gs = g * sn;
-            const float other = __shfl_xor(gs, 16, 64);
-            float dy = g * c;
-            if (lane < 16) dy += other; else if (lane < 32) dy -= other;
-            const float x = bf2f(qkv[(int64_t)tok * 3 * H + which * H + head * 64 + lane]);
-            const float mean = wave_sum(x) * (1.0f / 64.0f);
-            const float xc = x - mean;
-            const float rstd = 1.0f / sqrtf(wave_sum(xc * xc) * (1.0f / 64.0f) + eps);
-            const float xh = xc * rstd;
-            if (which) { awk += dy * xh; abk += dy; } else { awq += dy * xh; abq += dy; }
-            const float gg = dy * (which ? wk : wq);
-            const float m1 = wave_sum(gg) * (1.0f / 64.0f), m2 = wave_sum(gg * xh) * (1.0f / 64.0f);
-            dqkv[(int64_t)tok * 3 * H + which * H + head * 64 + lane] = f2bf(rstd * (gg - m1 - xh * m2));
+            float g[8], x[8];
+            unpack8(*reinterpret_cast<const uint4*>((which ? dk : dq) + (int64_t)tok * ldg + head * 64 + 8 * sub), g);
+            unpack8(*reinterpret_cast<const uint4*>(qkv + (int64_t)tok * 3 * H + which * H + head * 64 + 8 * sub), x);
+            const float sc = which ? 1.0f : 0.125f;
+            float dy[8];
+            float sx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                g[j] *= sc;
+                // rope^T: y'[d] = y[d] c[d] + rot(y)[d] s[d], rot(y)[d] = -y[d+16] (d<16), +y[d-16] (16<=d<32)
+                //   => dy[d] = g[d] c[d] + (d < 16 ? g[d+16] s[d+16] : -g[d-16] s[d-16])
+                const float other = __shfl_xor(g[j] * sn[j], 2, 64);  // dims d +- 16 live two lanes away
+                dy[j] = g[j] * c[j];
+                if (sub < 2) dy[j] += other; else if (sub < 4) dy[j] -= other;
+                sx += x[j];
+            }
+            const float mean = row8_sum(sx) * (1.0f / 64.0f);
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x[j] -= mean; sq += x[j] * x[j]; }
+            const float rstd = 1.0f / sqrtf(row8_sum(sq) * (1.0f / 64.0f) + eps);
+            float s1 = 0.f, s2 = 0.f;
+            float gg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[j] *= rstd;  // xhat
+                if (live) { acc[2 * which][j] += dy[j] * x[j]; acc[2 * which + 1][j] += dy[j]; }
+                gg[j] = dy[j] * (which ? wk[j] : wq[j]);
+                s1 += gg[j];
+                s2 += gg[j] * x[j];
+            }
+            const float m1 = row8_sum(s1) * (1.0f / 64.0f), m2 = row8_sum(s2) * (1.0f / 64.0f);
+            uint4 o;
+            o.x = pack_bf2(rstd * (gg[0] - m1 - x[0] * m2), rstd * (gg[1] - m1 - x[1] * m2));
+            o.y = pack_bf2(rstd * (gg[2] - m1 - x[2] * m2), rstd * (gg[3] - m1 - x[3] * m2));
+            o.z = pack_bf2(rstd * (gg[4] - m1 - x[4] * m2), rstd * (gg[5] - m1 - x[5] * m2));
+            o.w = pack_bf2(rstd * (gg[6] - m1 - x[6] * m2), rstd * (gg[7] - m1 - x[7] * m2));
+            if (live) *reinterpret_cast<uint4*>(dqkv + (int64_t)tok * 3 * H + which * H + head * 64 + 8 * sub) = o;
         }
     }
-    red[wave][0][lane] = awq; red[wave][1][lane] = abq; red[wave][2][lane] = awk; red[wave][3][lane] = abk;
+    // fixed-order reductions: over the 8 row slots of the wave (lane bits 3..5), then over the 4 waves through LDS
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[p][j];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (slot == 0) red[wave][p][8 * sub + j] = v;
+        }
     __syncthreads();
     {
         const int which = threadIdx.x >> 6;
@@ -544,6 +609,8 @@ extern "C" int showo_qkln_rope_bwd(const uint16_t* dq, const uint16_t* dk, int l
                                    float* dparams, int T, int L, int nH, int rot, float eps, void* stream) {
     if (T <= 0) return 0;
     if (rot != 32) return set_error_msg(1, "qkln_rope_bwd: rotary_dim 32 only");
+    if ((ldg % 8) || (((uintptr_t)dq) & 15) || (((uintptr_t)dk) & 15) || (((uintptr_t)qkv) & 15) || (((uintptr_t)dqkv) & 15))
+        return set_error_msg(1, "qkln_rope_bwd: dq / dk / qkv / dqkv must be 16-byte aligned with ldg a multiple of 8 (16-byte row loads)");
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = (int64_t)T * nH;
     const int nblk = (int)((rows + 4 * QKB_ROWS - 1) / (4 * QKB_ROWS));
