@@ -19,18 +19,29 @@ __host__ __device__ inline float bf2f(bf16_t v) {
     return c.f;
 }
 
-// round-to-nearest-even, NaN preserved as quiet NaN
+// round-to-nearest-even.  Device code uses the gfx950 conversion instruction (v_cvt_pk_bf16_f32: one instruction per PAIR instead of
+// ~7 VALU instructions per value for the integer form; bit-identical on every finite value and on infinities, NaN stays NaN with
+// the hardware's quiet pattern) -- the integer form was 25-45 % of the VALU work of every bf16-producing GEMM epilogue
+// (profiles/r2_gemm_harness.txt, r3e).  The host keeps the integer form (NaN preserved as quiet NaN).
 __host__ __device__ inline bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(f));
+    return (bf16_t)(r & 0xffffu);
+#else
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#endif
 }
 
 __device__ inline uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 __device__ inline float wave_sum(float v) {
