@@ -205,8 +205,9 @@ class _MMProjector(nn.Sequential):
     def set_precision(self, precision):
         """0 (default): bf16 GEMM / attention operands with fp32 accumulation -- the timed path.  1: accuracy mode, the reference's
         fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
-        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels and t2i_generate();
-        mmu_generate() and training keep bf16 operands (mmu_generate raises in mode 1).  Costs a second bf16 image of the weights."""
+        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels, t2i_generate() and
+        mmu_generate() (which then runs the reference's own no-cache algorithm: the whole sequence per token); training keeps bf16
+        operands.  Costs a second bf16 image of the weights."""
         if int(precision) not in (0, 1):
             raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
         self._precision = int(precision)
@@ -372,8 +373,9 @@ class Showo(PretrainedMixin, nn.Module):
     def set_precision(self, precision):
         """0 (default): bf16 GEMM / attention operands with fp32 accumulation -- the timed path.  1: accuracy mode, the reference's
         fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
-        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels and t2i_generate();
-        mmu_generate() and training keep bf16 operands (mmu_generate raises in mode 1).  Costs a second bf16 image of the weights."""
+        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels, t2i_generate() and
+        mmu_generate() (which then runs the reference's own no-cache algorithm: the whole sequence per token); training keeps bf16
+        operands.  Costs a second bf16 image of the weights."""
         if int(precision) not in (0, 1):
             raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
         self._precision = int(precision)
@@ -613,6 +615,9 @@ class Showo(PretrainedMixin, nn.Module):
             if noise is not None and tuple(noise.shape) != (max_new_tokens, self.vocab_size):
                 raise ValueError("_exp_noise must be [max_new_tokens, vocab_size]")
         dev = idx.device if idx is not None else input_embeddings.device
+        if int(getattr(self, "_precision", 0)) == 1:
+            return self._mmu_generate_recompute(idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token,
+                                                greedy, None if greedy else (k, seed, noise))
         if input_embeddings is not None:
             if input_embeddings.shape[0] != 1:
                 raise ValueError("mmu_generate has batch-1 semantics (reference modeling_showo.py:204,229)")
@@ -673,6 +678,68 @@ class Showo(PretrainedMixin, nn.Module):
                     return result
             remaining -= n
         return result
+
+
+def _dense_mask_of(attention_mask, L, device):
+    """[1,1,L,L] additive fp32 mask from whatever mmu_generate accepts (dense tensor, IntervalMask, None = causal)"""
+    from .prompting_utils import IntervalMask
+    neg = float(torch.iinfo(torch.int64).min)
+    if attention_mask is None:
+        m = torch.zeros((L, L), dtype=torch.float32, device=device)
+        m.masked_fill_(torch.ones((L, L), dtype=torch.bool, device=device).triu(1), neg)
+        return m.reshape(1, 1, L, L)
+    if isinstance(attention_mask, IntervalMask):
+        iv = attention_mask.check().iv.reshape(-1, L, 4)[:1].to(torch.int64)
+        col = torch.arange(L, device=iv.device)[None, None, :]
+        vis = ((col >= iv[..., 0:1]) & (col < iv[..., 1:2])) | ((col >= iv[..., 2:3]) & (col < iv[..., 3:4]))
+        return torch.where(vis, 0.0, neg).to(torch.float32).reshape(1, 1, L, L).to(device)
+    return attention_mask.detach().float().reshape(1, 1, L, L).to(device)
+
+
+def _mmu_generate_recompute(self, idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token, greedy, sampling):
+    """Accuracy mode (`set_precision(1)`): the reference's OWN algorithm (models/modeling_showo.py:190-240) -- no KV cache, the whole
+    sequence is run again for every token on the grown mask (new column hidden from the old rows, new row = last row + itself,
+    :203-217) -- on the fp32-class engine path.  O(tokens x forward): a parity mode, not a serving mode."""
+    eng = self.engine()
+    dev = idx.device if idx is not None else input_embeddings.device
+    if (input_embeddings if input_embeddings is not None else idx).shape[0] != 1:
+        raise ValueError("mmu_generate has batch-1 semantics (reference modeling_showo.py:204,229)")
+    if input_embeddings is not None:
+        emb = input_embeddings.detach().float().contiguous()
+    else:
+        emb = self.showo.model.embed_tokens.weight.detach().float()[idx.to(torch.int64)].contiguous()
+    L = emb.shape[1]
+    mask = _dense_mask_of(attention_mask, L, dev)
+    neg = float(torch.finfo(torch.float32).min)  # the reference pads the new column with finfo(dtype).min (:206-209)
+    row = torch.empty((1,), dtype=torch.int32, device=dev)
+    logits = torch.empty((self.vocab_size,), dtype=torch.float32, device=dev)
+    tok = torch.empty((1,), dtype=torch.int64, device=dev)
+    result = []
+    for step in range(max_new_tokens):
+        row.fill_(L - 1)
+        _lib.call("showo_engine_forward_rows", eng, None, _lib.ptr(emb), _lib.ptr(mask), 1, L, _lib.ptr(row), 1, 0, self.vocab_size,
+                  _lib.ptr(logits), _lib.stream())
+        if greedy:
+            _lib.call("showo_argmax_f32", _lib.ptr(logits), self.vocab_size, _lib.ptr(tok), _lib.stream())
+        else:
+            k, seed, noise = sampling
+            _lib.call("showo_sample_topk", _lib.ptr(logits), self.vocab_size, k, float(temperature), _lib.ptr(noise), seed, step, _lib.ptr(tok),
+                      _lib.stream())
+        t = int(tok.item())
+        result.append(torch.tensor(t, device=dev))
+        if eot_token is not None and t == eot_token:
+            break
+        grown = torch.full((1, 1, L + 1, L + 1), neg, dtype=torch.float32, device=dev)
+        grown[0, 0, :L, :L] = mask[0, 0]
+        grown[0, 0, L, :L] = mask[0, 0, L - 1]
+        grown[0, 0, L, L] = 0.0
+        mask = grown
+        emb = torch.cat([emb, self.showo.model.embed_tokens.weight.detach().float()[tok].reshape(1, 1, -1)], dim=1).contiguous()
+        L += 1
+    return result
+
+
+Showo._mmu_generate_recompute = _mmu_generate_recompute
 
 
 def gen_config(llm_vocab_size=50295, num_new_special_tokens=10, num_vq_tokens=256, max_seq_length=128):

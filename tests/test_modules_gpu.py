@@ -101,9 +101,20 @@ def test_tiny_accuracy_mode_logits_within_1e3_of_the_fp32_reference_end_to_end()
     for s in range(steps):
         worst = max(worst, _check_precise(m(dev(g2["fwd_in"][s]), attention_mask=dev(g2["mask"])), torch.from_numpy(g2["fwd_logits"][s]),
                                           f"teacher-forced step {s}"))
-    # KV-cached decode keeps bf16 operands: accuracy mode refuses instead of silently answering with another arithmetic
+    # mmu_generate in accuracy mode = the reference's own no-cache algorithm on the fp32-class path: its tokens, greedy and with
+    # its recorded multinomial draws (top_k = 5 / T = 0.7 and top_k = None / T = 1.3); the KV-cached C entry points refuse
+    g3 = util.golden("showo_tiny_mmu.npz")
+    toks = m.mmu_generate(dev(g3["ids"]), attention_mask=dev(g3["mask"]), max_new_tokens=len(g3["tokens"]), top_k=1)
+    assert [int(t) for t in toks] == g3["tokens"].tolist()
+    ivm = util.pkg().prompting_utils.intervals_for_mmu(dev(g3["ids"]), eoi_id=d.eoi_id)
+    assert [int(t) for t in m.mmu_generate(dev(g3["ids"]), attention_mask=ivm, max_new_tokens=len(g3["tokens"]), top_k=1)] == g3["tokens"].tolist()
+    for tag, kw in (("topk5", dict(top_k=5, temperature=0.7)), ("full", dict(top_k=None, temperature=1.3))):
+        toks = m.mmu_generate(dev(g3["ids"]), attention_mask=dev(g3["mask"]), max_new_tokens=8, _exp_noise=dev(g3[f"exp_noise_{tag}"]), **kw)
+        assert [int(t) for t in toks] == g3[f"tokens_{tag}"].tolist(), tag
+    logits1 = torch.empty(d.vocab, device="cuda")
     with pytest.raises(RuntimeError):
-        m.mmu_generate(dev(g["mmu_ids"])[:1], attention_mask=dev(g["mmu_mask"])[:1], max_new_tokens=2, top_k=1)
+        util.lib().call("showo_engine_prefill", m.engine(), util.lib().ptr(dev(g3["ids"])), None, None, g3["ids"].shape[1], util.lib().ptr(logits1),
+                        util.lib().stream())
     # back to bf16 operands on the same engine: the default path's numbers
     m.set_precision(0)
     lg0 = m(dev(g["t2i_ids"]), attention_mask=dev(g["t2i_mask"]))
@@ -770,3 +781,12 @@ def test_tiny_inpainting_trajectory_cfg3_shape():
         assert agree >= 0.75  # one flipped near-tie re-routes the rest of that sample's 16 tokens
         outs.append((out, ids))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])  # graph replay == eager launches
+    # accuracy mode (fp32-class arithmetic): the FREE-RUNNING trajectory is the reference's, token for token -- no near-tie
+    # allowance needed -- and so is the id tensor it leaves behind (the 0.75 gate above is a bf16 artefact)
+    m.set_precision(1)
+    ids = dev(g["ids_cond"]).clone()
+    out = m.t2i_generate(input_ids=ids, uncond_input_ids=dev(g["ids_uncond"]), attention_mask=mask, temperature=1.0, timesteps=steps,
+                         guidance_scale=w, config=util.gen_config(d), _exp_noise=en, _uniform=un)
+    agree = float((out.cpu() == want).float().mean())
+    print(f"[parity] tiny inpainting trajectory, free-running, accuracy mode: agreement {agree:.4f}")
+    assert agree == 1.0 and torch.equal(ids.cpu(), torch.from_numpy(g["final_input_ids"]))
