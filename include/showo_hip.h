@@ -360,7 +360,8 @@ int showo_engine_set_collect(showo_engine* e, float* buf);
  * reference's fp32 inference (inference_t2i.py:67 keeps the model in fp32; models/phi.py:1182-1183 returns fp32 logits) to ~1e-4 end
  * to end -- every GEMM on the split-bf16 MFMA kernel (hi + lo operand pairs, see showo_gemm_bf16x3), LayerNorm / q,k-LayerNorm /
  * RoPE / attention / gelu_new in fp32 on the vector ALU.  Covers showo_engine_forward, _forward_rows and _t2i_generate (eager steps,
- * no prefix cache); the KV-cached decode entry points refuse.  The weights must be uploaded (showo_engine_load) AFTER switching to
+ * no prefix cache); the KV-cached decode entry points refuse (the Python mmu_generate runs the reference's no-cache algorithm
+ * through _forward_rows instead).  The weights must be uploaded (showo_engine_load) AFTER switching to
  * precision 1 -- the loader then also keeps their low halves; showo_engine_precise_ready tells whether they are current. */
 int showo_engine_set_precision(showo_engine* e, int precision);
 int showo_engine_get_precision(const showo_engine* e);
