@@ -89,6 +89,14 @@ int showo_gemm_bf16x3(const uint16_t* A, const uint16_t* Alo, int lda, const uin
                       int K, void* stream);
 int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
                          const float* resid, float* out, int B, int Hin, int Win, int Cin, int Cout, int mode, void* stream);
+/* The same convolution plus the GroupNorm(32) statistics of its OUTPUT -- what showo_gn_stats(out, stats, B, Hout*Wout, Cout)
+ * returns, equal to the last bits of the double sums.  In a VQGAN block every 3x3 conv is followed by GroupNorm of its
+ * result (common_modules.py:337-357); the conv epilogue produces the per-tile (sum, sumsq) partials (deterministic, no
+ * atomics) whenever a 256-pixel tile cannot straddle two images (Hout*Wout % 256 == 0, B*Hout*Wout >= 2048), which saves
+ * the read-back of the tensor; otherwise the separate reduction runs.  Cout % 128 == 0; stats: showo_gn_stats_doubles(). */
+int showo_conv3x3_bf16x3_gn(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
+                            const float* resid, float* out, double* stats, int B, int Hin, int Win, int Cin, int Cout, int mode,
+                            void* stream);
 /* fp32 -> (hi, lo) bf16 pair */
 int showo_split_f32_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
 
@@ -137,7 +145,9 @@ int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1
  * also saves what backward reads -- raw_qkv bf16 [B*L, ldraw] = A Wqkv^T + b (pre-LayerNorm q, k and v: the input of
  * showo_qkln_rope_bwd / showo_attn_bwd) and ffn_pre bf16 [B*L, ldf] = A W1^T + b1 (the input of showo_dgelu_bf16) -- and derives
  * Q / K / V^T and ffn_out = gelu_new(ffn_pre) from those ROUNDED values: one launch instead of showo_gemm_bf16 + showo_qk_prep +
- * showo_gemm_bf16 + showo_gelu_bf16, with the forward and the recomputation in backward seeing the same numbers. */
+ * showo_gemm_bf16 + showo_gelu_bf16, with the forward and the recomputation in backward seeing the same numbers.
+ * Q = K = Vt = NULL selects the raw-only form: raw_qkv / ffn_pre / ffn_out are written and the caller runs showo_qk_prep on
+ * raw_qkv (same Q / K / V^T bits; A/B switch of the trainer: SHOWO_TRAIN_QKPREP=1). */
 int showo_gemm_qkv_fc1_save_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
                                  const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
                                  const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
@@ -301,6 +311,8 @@ int showo_mask_by_topk(const float* sel_prob, const int64_t* sampled, int64_t* c
  * ([B,32,2] result followed by per-block partials). */
 int showo_gn_stats_doubles(int B, int HW);
 int showo_gn_stats(const float* x, double* stats, int B, int HW, int C, void* stream);
+/* second pass alone: stats[b][g][2] = sum_k part[b][k][g][2] over nblk per-block partials, in k order */
+int showo_gn_finalize(const double* part, double* stats, int B, int nblk, void* stream);
 /* y bf16 NHWC = act((x - mean) * rstd * gamma + beta); act = swish if do_swish (common_modules.py:16-24).
  * ylo (optional): low half for split precision, ylo = bf16(value - float(y)). */
 int showo_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, uint16_t* y, uint16_t* ylo,
@@ -472,6 +484,11 @@ int showo_train_backward_head(showo_trainer* t, const int64_t* labels, int b_t2i
                               float g_t2i, float g_lm, float g_mmu, void* stream);
 int showo_train_backward_layer(showo_trainer* t, int layer, void* stream);
 int showo_train_backward_embed(showo_trainer* t, void* stream);
+/* Announce the loss weights (training/train.py:600: loss = w_t2i*loss_t2i + w_lm*loss_lm + w_mmu*loss_mmu) BEFORE the forward:
+ * its cross-entropy pass then also writes d(loss)/d(logits), and a showo_train_backward[_head] call with the same labels
+ * pointer (contents unchanged), batch split and weights skips its own pass over the [B*L, V] fp32 logits.  Any mismatch falls
+ * back to the two-pass behaviour; enable = 0 turns the announcement off. */
+int showo_train_set_loss_weights(showo_trainer* t, float w_t2i, float w_lm, float w_mmu, int enable);
 /* all gradients live in one flat fp32 buffer; bucket 0 = embedding, 1 + i = block i, nL + 1 = head */
 int showo_train_num_buckets(showo_trainer* t);
 int showo_train_bucket(showo_trainer* t, int bucket, float** ptr, int64_t* n);

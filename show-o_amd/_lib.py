@@ -63,6 +63,7 @@ _PROTOS = {
     "showo_train_backward_head": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p],
     "showo_train_backward_layer": [c_p, c_i, c_p],
     "showo_train_backward_embed": [c_p, c_p],
+    "showo_train_set_loss_weights": [c_p, c_f, c_f, c_f, c_i],
     "showo_train_num_buckets": [c_p],
     "showo_train_bucket": [c_p, c_i, c_p, c_p],
     "showo_train_grad": [c_p, C.c_char_p, c_p, c_p],
@@ -76,6 +77,7 @@ _PROTOS = {
                        c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_bf16x3": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "showo_conv3x3_bf16x3": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_conv3x3_bf16x3_gn": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "showo_cast_f32_bf16": [c_p, c_p, c_i64, c_p],
     "showo_copy_b128": [c_p, c_p, c_i64, c_p],
@@ -94,6 +96,7 @@ _PROTOS = {
     "showo_mask_by_topk": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_f, c_f, c_p, c_u64, c_u32, c_p, c_i, c_i, c_p],
     "showo_gn_stats": [c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_gn_stats_doubles": [c_i, c_i],
+    "showo_gn_finalize": [c_p, c_p, c_i, c_i, c_p],
     "showo_gn_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
     "showo_conv3x3_bf16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_conv_small_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

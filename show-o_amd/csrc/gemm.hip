@@ -29,6 +29,10 @@ struct ConvArgs {
     const bf16_t* X;   // NHWC bf16 input
     const bf16_t* Xlo; // split-precision mode: low halves (same layout)
     int B, Hin, Win, Cin, Hout, Wout, mode;
+    // conv2p_split only: GroupNorm(32) statistics of the OUTPUT fused into the epilogue.  gn_part = per-tile (sum, sumsq) partials,
+    // double [M / 256][32][2] (requires Hout * Wout % 256 == 0: a 256-pixel tile never straddles two images), gn_cpg = Cout / 32
+    double* gn_part = nullptr;
+    int gn_cpg = 0;
 };
 
 // ---- activation-operand loaders: setup(i, m) once per staged row, load(i, k) per k-tile -> 16-B chunk
@@ -984,6 +988,7 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
     const int N = Nq + (ffn_out ? F : 0);
     if (M <= 0) return 0;
     if (rot != 32) return set_error_msg(1, "gemm_qkv: the fused epilogue implements rotary_dim 32 (use showo_gemm_bf16 + showo_qk_prep)");
+    if (Q ? (!K || !Vt) : !raw_qkv) return set_error_msg(1, "gemm_qkv: Q, K, Vt required (only the save form may omit all three)");
     if ((Lp % 64) || Lp < pos0 + L || Lcap < pos0 + L) return set_error_msg(1, "gemm_qkv: bad Lp/Lcap");
     if ((lda % 8) || (ldw % 8) || (((uintptr_t)A) & 15) || (((uintptr_t)Wqkv) & 15))
         return set_error_msg(1, "gemm_qkv: A/W must be 16B aligned with lda,ldw multiples of 8");
@@ -1039,6 +1044,7 @@ extern "C" int showo_gemm_qkv_fc1_save_bf16(const uint16_t* A, int lda, const ui
                                             uint16_t* raw_qkv, int ldraw, uint16_t* ffn_pre, uint16_t* ffn_out, int ldf, int F, int B, int L,
                                             int nH, int rot, float eps, int pos0, int Lcap, int Lp, int w_tiled, void* stream) {
     if (!ffn_out || !ffn_pre || !raw_qkv) return set_error_msg(1, "gemm_qkv_fc1_save: raw_qkv, ffn_pre and ffn_out required");
+    if (!Q && (K || Vt)) return set_error_msg(1, "gemm_qkv_fc1_save: Q, K and Vt are given together or not at all (raw-only form)");
     return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
                          pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream, raw_qkv, ldraw, ffn_pre);
 }
@@ -1113,6 +1119,21 @@ extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const fl
 //   ph0: read W (8 b128) + A frags m0,m1 (4); DMA W + A-lo rows of tile t+1 (4 pieces); vmcnt(4); 24 MFMAs
 //   ph1: read A frags m2,m3 (4);              DMA A-hi rows of tile t+1 (2 pieces);     vmcnt(2); 24 MFMAs
 // =====================================================================================================
+// store_frag for the fp32 epilogues of a full-width, 16-byte aligned output (vec_out, N % 4 == 0) that also returns what it stored
+template <int EPI>
+static __device__ inline bool store_frag_vals(const GemmArgs& g, const f32x4& acc, int m, int n, const float (&bn)[4], float (&v)[4]) {
+    static_assert(EPI == SHOWO_EPI_F32 || EPI == SHOWO_EPI_RESID_F32, "fp32 epilogues only");
+    if (m >= g.M || n >= g.N) return false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] + bn[r] + 0.f;  // store_frag's expression with bias_per_row = 0
+    if (EPI == SHOWO_EPI_RESID_F32) {
+        const float4 rv = *reinterpret_cast<const float4*>(g.resid + (int64_t)m * g.ldr + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    }
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    return true;
+}
+
 constexpr int CS_WROWS = 128, CS_AROWS = 256, CS_BK = 32;
 constexpr int CS_BUF = (2 * CS_WROWS + 2 * CS_AROWS) * CS_BK;  // elements per buffer (48 KiB)
 constexpr int CS_SMEM = 2 * CS_BUF * 2;                        // 96 KiB
@@ -1293,13 +1314,66 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
     if (t < nk) CS_TILE(0, t);
     if (grp == 0) bar_raw_fn();
 
+    if (c.gn_part == nullptr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + fg * 4;
-        float bn[4];
-        load_bias4(g, n, bn);
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn);
+            for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn);
+        }
+    } else {
+        // Same stores, plus the GroupNorm statistics of what was stored (the next op of the VQGAN block is GroupNorm(32) of this
+        // tensor: showo_gn_stats would read it back from HBM).  A lane's 4 columns belong to ONE group (Cout / 32 is a multiple of 4);
+        // sums are carried in double and combined in a fixed order (lane butterfly -> wave slots in LDS -> quads -> groups): the
+        // partial of a tile has the same bits on every run, like gn_partial_kernel's.
+        double gs[4], gq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
+            gs[i] = 0.0; gq[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+                if (store_frag_vals<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn, v)) {
+                    gs[i] += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+                    gq[i] += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {  // the 16 lanes fr = 0..15 hold the tile rows of the same 4 columns
+                gs[i] += __shfl_xor(gs[i], o, 64);
+                gq[i] += __shfl_xor(gq[i], o, 64);
+            }
+        double* sred = reinterpret_cast<double*>(smem_raw);  // [8 waves][16 quads][2]; every LDS read of the main loop has retired
+        __syncthreads();
+        if (fr == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sred[(wave * 16 + i * 4 + fg) * 2 + 0] = gs[i];
+                sred[(wave * 16 + i * 4 + fg) * 2 + 1] = gq[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int q = tid >> 1, which = tid & 1;  // q: column quad of the block (columns n0 + 4 q ..)
+            const int wq = q >> 4, ql = q & 15;
+            double a = 0.0;
+#pragma unroll
+            for (int pw = 0; pw < 4; ++pw) a += sred[((((pw >> 1) * 4 + (pw & 1) * 2 + wq) * 16) + ql) * 2 + which];
+            const int qpg = c.gn_cpg >> 2;  // quads per group: 1, 2, 4 or 8
+            if (qpg >= 2) a += __shfl_down(a, 2, 64);
+            if (qpg >= 4) a += __shfl_down(a, 4, 64);
+            if (qpg >= 8) a += __shfl_down(a, 8, 64);
+            const int ncol = n0 + 4 * q;
+            if ((q % qpg) == 0 && ncol < g.N) c.gn_part[((int64_t)tm * 32 + ncol / c.gn_cpg) * 2 + which] = a;
+        }
     }
 #undef CS_TILE
 #undef CS_TAP
@@ -1348,9 +1422,8 @@ extern "C" int showo_gemm_bf16x3(const uint16_t* A, const uint16_t* Alo, int lda
     return dispatch_split(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
 }
 
-extern "C" int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
-                                    const float* resid, float* out, int B, int Hin, int Win, int Cin, int Cout, int mode,
-                                    void* stream) {
+static int conv3x3_x3_impl(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
+                           const float* resid, float* out, double* stats, int B, int Hin, int Win, int Cin, int Cout, int mode, void* stream) {
     if (B <= 0) return 0;
     if (Cin % 64) return set_error_msg(1, "conv3x3 x3: Cin % 64 == 0 required");
     if (mode < 0 || mode > 2) return set_error_msg(1, "conv3x3 x3: bad mode");
@@ -1367,12 +1440,45 @@ extern "C" int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, cons
     g.vec_out = ((Cout % 4) == 0) && ((((uintptr_t)out) & 15) == 0) && (!resid || (((uintptr_t)resid) & 15) == 0);
     ConvLoader ld;
     ld.c = c; ld.M = g.M;
-    ProfScope prof(PROF_CONV, 2.0 * g.M * Cout * 9.0 * Cin, (hipStream_t)stream);
-    if (g_conv_split_impl < 0) { const char* e = getenv("SHOWO_CONV_SPLIT_IMPL"); g_conv_split_impl = e ? atoi(e) : 0; }
-    const bool phase_split = g_conv_split_impl == 2 || (g_conv_split_impl != 1 && g.M >= 2048);
-    if (phase_split && (int64_t)Cout * g.ldw * 2 < ((int64_t)1 << 32)) {
-        if (resid) return launch_conv2p_split<SHOWO_EPI_RESID_F32>(g, c, (hipStream_t)stream);
-        return launch_conv2p_split<SHOWO_EPI_F32>(g, c, (hipStream_t)stream);
+    const int HW = c.Hout * c.Wout;
+    int rc;
+    bool fused = false;
+    {
+        ProfScope prof(PROF_CONV, 2.0 * g.M * Cout * 9.0 * Cin, (hipStream_t)stream);
+        if (g_conv_split_impl < 0) { const char* e = getenv("SHOWO_CONV_SPLIT_IMPL"); g_conv_split_impl = e ? atoi(e) : 0; }
+        static int gn_fuse = -1;  // SHOWO_CONV_GN_FUSE=0: statistics by the separate two-pass reduction (A/B)
+        if (gn_fuse < 0) { const char* e = getenv("SHOWO_CONV_GN_FUSE"); gn_fuse = e ? atoi(e) : 1; }
+        const bool phase_split = g_conv_split_impl == 2 || (g_conv_split_impl != 1 && g.M >= 2048);
+        if (phase_split && (int64_t)Cout * g.ldw * 2 < ((int64_t)1 << 32)) {
+            if (stats && gn_fuse && (HW % CS_AROWS) == 0 && (Cout % 128) == 0 && Cout <= 1024 && g.vec_out) {
+                c.gn_part = stats + (int64_t)B * 64;  // partials behind the [B, 32, 2] result, like showo_gn_stats
+                c.gn_cpg = Cout / 32;
+                fused = true;
+            }
+            rc = resid ? launch_conv2p_split<SHOWO_EPI_RESID_F32>(g, c, (hipStream_t)stream)
+                       : launch_conv2p_split<SHOWO_EPI_F32>(g, c, (hipStream_t)stream);
+        } else {
+            rc = dispatch_split(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
+        }
     }
-    return dispatch_split(g, ld, resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, (hipStream_t)stream);
+    if (rc || !stats) return rc;
+    if (fused) return showo_gn_finalize(stats + (int64_t)B * 64, stats, B, HW / CS_AROWS, stream);
+    return showo_gn_stats(out, stats, B, HW, Cout, stream);
+}
+
+extern "C" int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
+                                    const float* resid, float* out, int B, int Hin, int Win, int Cin, int Cout, int mode,
+                                    void* stream) {
+    return conv3x3_x3_impl(x, xlo, w, wlo, bias, resid, out, nullptr, B, Hin, Win, Cin, Cout, mode, stream);
+}
+
+// The same convolution plus the GroupNorm(32) statistics of its output (what showo_gn_stats(out, stats, B, Hout * Wout, Cout) would
+// return, to the last bits of the double sums): produced by the conv epilogue when a 256-pixel tile never straddles two images,
+// by the separate reduction otherwise.  stats: showo_gn_stats_doubles(B, Hout * Wout) doubles.
+extern "C" int showo_conv3x3_bf16x3_gn(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
+                                       const float* resid, float* out, double* stats, int B, int Hin, int Win, int Cin, int Cout,
+                                       int mode, void* stream) {
+    if (!stats) return set_error_msg(1, "conv3x3 x3 gn: stats buffer required");
+    if (Cout % 128) return set_error_msg(1, "conv3x3 x3 gn: Cout must be a multiple of 128 (GroupNorm(32) over channel quads)");
+    return conv3x3_x3_impl(x, xlo, w, wlo, bias, resid, out, stats, B, Hin, Win, Cin, Cout, mode, stream);
 }

@@ -243,6 +243,33 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     if (m < g.M && n < g.N) *reinterpret_cast<uint4*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = v;
                 }
             }
+        } else if (nbase < g.N && g.Q == nullptr) {
+            // raw-only save form (training forward, SHOWO_TRAIN_QKPREP): the q / k / v columns are stored as bf16(acc + bias) rows of
+            // raw[m][n] and nothing else -- LayerNorm / RoPE / relayout run as showo_qk_prep on that tensor, which the backward keeps anyway
+            const bool staged = stg != nullptr && (g.ldraw % 8) == 0 && ((((uintptr_t)g.raw) & 15) == 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nbase + i * 16 + fg * 4;
+                float bn[4];
+                load_bias4(g, n, bn);
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = mrow0 + j * 16 + fr;
+                    uint2 pk;
+                    pk.x = pack_bf2(acc[i][j][0] + bn[0], acc[i][j][1] + bn[1]);
+                    pk.y = pack_bf2(acc[i][j][2] + bn[2], acc[i][j][3] + bn[3]);
+                    if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
+                    else if (m < g.M) *reinterpret_cast<uint2*>(g.raw + (int64_t)m * g.ldraw + n) = pk;
+                }
+            }
+            if (staged) {
+#pragma unroll
+                for (int t = 0; t < 2 * MF; ++t) {
+                    const int row = t * 8 + rrow, m = mrow0 + row;
+                    const uint4 v = unstage_row16(stg, row, rchunk);
+                    if (m < g.M) *reinterpret_cast<uint4*>(g.raw + (int64_t)m * g.ldraw + nbase + rchunk * 8) = v;
+                }
+            }
         } else if (nbase < g.N) {
             const int Hq = g.nH * 64;
             const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)

@@ -70,6 +70,14 @@ struct showo_trainer {
     bool has_mask = false;
     bool from_embeds = false;  // last forward started from caller-provided embeddings: d(loss)/d(embeddings) = dy
     bool weights_synced = false;
+    // loss weights announced before the forward (showo_train_set_loss_weights): the forward's cross-entropy pass then writes the
+    // logit gradients as well, and a backward with the same labels / split / weights skips its own pass over the 2.6 GB of logits
+    bool lw_set = false;
+    float lw[3] = {0.f, 0.f, 0.f};
+    bool dl_valid = false;
+    float dl_g[3] = {0.f, 0.f, 0.f};
+    const int64_t* dl_labels = nullptr;
+    int dl_split[4] = {0, 0, 0, 0};
 
     template <class T>
     int alloc(T** p, int64_t n) {
@@ -276,6 +284,9 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
     // SHOWO_TRAIN_FUSED_PROJ (default 1): the fused projection launch of the inference layer, in its save-for-backward form
     static int fused_env = -1;
     if (fused_env < 0) { const char* env = getenv("SHOWO_TRAIN_FUSED_PROJ"); fused_env = env ? (atoi(env) != 0) : 1; }
+    // SHOWO_TRAIN_QKPREP (default 0): 1 = raw-only projection launch + showo_qk_prep (A/B of the epilogue's LayerNorm / RoPE cost)
+    static int qkprep_env = -1;
+    if (qkprep_env < 0) { const char* env = getenv("SHOWO_TRAIN_QKPREP"); qkprep_env = env ? (atoi(env) != 0) : 0; }
     const bool fused_proj = fused_env && T >= 256 && e->cfg.rotary_dim == 32 && (3 * H) % 256 == 0 && (F % 8) == 0 &&
                             (int64_t)T * F * 2 < ((int64_t)1 << 32);
     for (int i = 0; i < e->nL; ++i) {
@@ -288,6 +299,14 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
         if (fused_proj) {
             // q/k/v_proj + q/k LayerNorm + RoPE + relayout AND fc1 + gelu_new in one launch that also saves qkv and the fc1
             // pre-activation for backward ([Wqkv ; W1] is one allocation, engine.hip); same bits as the four launches below
+            if (qkprep_env) {
+                // raw-only form: the launch stores qkv / the fc1 pre-activation / gelu and the q/k LayerNorm + RoPE + relayout run as
+                // showo_qk_prep on the saved qkv (same bits: both start from the rounded values)
+                TRY(showo_gemm_qkv_fc1_save_bf16(l.h, H, w.wqkv, H, w.bqkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, nullptr, nullptr,
+                                                 nullptr, l.qkv, 3 * H, l.f, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
+                TRY(showo_qk_prep(l.qkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt, B, L, nH, e->cfg.rotary_dim,
+                                  e->cfg.ln_eps, 0, L, Lp, s));
+            } else
             TRY(showo_gemm_qkv_fc1_save_bf16(l.h, H, w.wqkv, H, w.bqkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt,
                                              l.qkv, 3 * H, l.f, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
             TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
@@ -309,7 +328,16 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
     t->B = B; t->Lq = L;
     t->have_fwd = true;
     t->has_mask = iv != nullptr;
+    t->dl_valid = false;
     if (labels) {
+        if (t->lw_set) {  // one pass: losses and d(sum_g w_g loss_g)/d(logits)
+            TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, t->lw[0], t->lw[1], t->lw[2], t->ce_rows,
+                              t->counts, t->rowloss, t->dlogits, t->Vp, t->losses, s));
+            t->dl_valid = true;
+            t->dl_labels = labels;
+            for (int k = 0; k < 3; ++k) t->dl_g[k] = t->lw[k];
+            t->dl_split[0] = b_t2i; t->dl_split[1] = b_lm; t->dl_split[2] = b_mmu; t->dl_split[3] = max_seq_len;
+        } else
         TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, 0.f, 0.f, 0.f, t->ce_rows, t->counts,
                           t->rowloss, nullptr, 0, t->losses, s));
         // the backward works on the interval form only: a mask with more than two visibility runs in a row (never produced by
@@ -354,8 +382,12 @@ extern "C" int showo_train_backward_head(showo_trainer* t, const int64_t* labels
     BW_PROLOGUE
     if (!labels) return set_error_msg(1, "train_backward: labels required");
     // ---- loss + head
-    TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, g_t2i, g_lm, g_mmu, t->ce_rows, t->counts,
-                      t->rowloss, t->dlogits, Vp, nullptr, s));
+    const bool have_dl = t->dl_valid && t->dl_labels == labels && t->dl_g[0] == g_t2i && t->dl_g[1] == g_lm && t->dl_g[2] == g_mmu &&
+                         t->dl_split[0] == b_t2i && t->dl_split[1] == b_lm && t->dl_split[2] == b_mmu && t->dl_split[3] == max_seq_len;
+    t->dl_valid = false;  // dlogits^T below reuses nothing of it, but a second backward must not trust a consumed flag blindly
+    if (!have_dl)
+        TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, g_t2i, g_lm, g_mmu, t->ce_rows, t->counts,
+                          t->rowloss, t->dlogits, Vp, nullptr, s));
     TRY(showo_transpose_bf16(t->dlogits, Vp, t->bigT, T, Vp, Tp, 0, t->colpart, t->gblm, 0, s));  // dlogits^T + lm_head bias grad
     TRY(showo_transpose_bf16(e->hf, H, t->xT, T, H, Tp, 0, nullptr, nullptr, 0, s));
     TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, t->gwlm, H, nullptr, 0, V, H, Tp, SHOWO_EPI_F32, s));      // dWlm [V,H]
@@ -399,6 +431,17 @@ extern "C" int showo_train_backward_layer(showo_trainer* t, int i, void* stream)
         // LayerNorm + residual
         TRY(showo_ln_bwd(l.x, w.ln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, l.gln, T, H, e->cfg.ln_eps, s));
         }
+    return 0;
+}
+
+// Announce the weights of the three losses (training/train.py:600: loss = w_t2i loss_t2i + w_lm loss_lm + w_mmu loss_mmu) BEFORE the
+// forward: its cross-entropy pass then also writes d(loss)/d(logits), and showo_train_backward[_head] called with the same labels
+// pointer, batch split and weights does not read the logits a second time.  enable = 0 restores the two-pass behaviour.
+extern "C" int showo_train_set_loss_weights(showo_trainer* t, float w_t2i, float w_lm, float w_mmu, int enable) {
+    if (!t) return set_error_msg(1, "train_set_loss_weights: null handle");
+    t->lw_set = enable != 0;
+    t->lw[0] = w_t2i; t->lw[1] = w_lm; t->lw[2] = w_mmu;
+    t->dl_valid = false;
     return 0;
 }
 

@@ -125,14 +125,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         if (r >= T) break;
         const float* xr = x + (int64_t)r * H;
         const float* gr = dh + (int64_t)r * H;
-        float4 xv[8], gv[8];
-        float s = 0.f;
+        // the three rows this iteration reads (x, dh, dy: 24 KB) are requested up front: one HBM round trip per row instead of three
+        float4 xv[8], gv[8], ov[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (i < nv && (i * 64 + lane) * 4 < H) {
-                xv[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
-                s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+                const int c = (i * 64 + lane) * 4;
+                xv[i] = *reinterpret_cast<const float4*>(xr + c);
+                gv[i] = *reinterpret_cast<const float4*>(gr + c);
+                ov[i] = *reinterpret_cast<const float4*>(dy + (int64_t)r * H + c);
             }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nv && (i * 64 + lane) * 4 < H) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
         const float mean = wave_sum(s) / (float)H;
         float q = 0.f;
 #pragma unroll
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         for (int i = 0; i < 8; ++i)
             if (i < nv && (i * 64 + lane) * 4 < H) {
                 const int c = (i * 64 + lane) * 4;
-                const float4 d = *reinterpret_cast<const float4*>(gr + c);
+                const float4 d = gv[i];
                 const float4 w = *reinterpret_cast<const float4*>(gamma + c);
                 xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;  // xhat
                 ag[i][0] += d.x * xv[i].x; ag[i][1] += d.y * xv[i].y; ag[i][2] += d.z * xv[i].z; ag[i][3] += d.w * xv[i].w;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         for (int i = 0; i < 8; ++i)
             if (i < nv && (i * 64 + lane) * 4 < H) {
                 const int c = (i * 64 + lane) * 4;
-                float4 o = *reinterpret_cast<const float4*>(dy + (int64_t)r * H + c);
+                float4 o = ov[i];
                 o.x += rstd * (gv[i].x - m1 - xv[i].x * m2);
                 o.y += rstd * (gv[i].y - m1 - xv[i].y * m2);
                 o.z += rstd * (gv[i].z - m1 - xv[i].z * m2);
@@ -368,8 +374,15 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         if (tid == 0) { rowloss[2 * r] = 0.f; rowloss[2 * r + 1] = 0.f; }
         return;
     }
+    // rows are read as 8-byte pairs (ldl even, base 8-byte aligned: every row then starts on a pair boundary), four pairs in flight per
+    // thread: the three passes are latency-bound on a 234 KB row otherwise.  V2 = number of whole pairs read that way.
+    const bool pairs = ((ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 7) == 0);
+    const int V2 = pairs ? (V >> 1) : 0;
+    const float2* z2 = reinterpret_cast<const float2*>(z);
     float mx = -INFINITY;
-    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, z[i]);
+#pragma unroll 4
+    for (int i = tid; i < V2; i += 256) { const float2 p = z2[i]; mx = fmaxf(mx, fmaxf(p.x, p.y)); }
+    for (int i = 2 * V2 + tid; i < V; i += 256) mx = fmaxf(mx, z[i]);
     mx = wave_max(mx);
     if (lane == 0) sred[wave] = mx;
     __syncthreads();
@@ -377,7 +390,9 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     __syncthreads();
     mx = sbc;
     float s = 0.f;
-    for (int i = tid; i < V; i += 256) s += expf(z[i] - mx);
+#pragma unroll 4
+    for (int i = tid; i < V2; i += 256) { const float2 p = z2[i]; s += expf(p.x - mx) + expf(p.y - mx); }
+    for (int i = 2 * V2 + tid; i < V; i += 256) s += expf(z[i] - mx);
     s = wave_sum(s);
     __syncthreads();
     if (lane == 0) sred[wave] = s;
@@ -401,13 +416,21 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         const bool bad = ((cr.bits & 1) && (cr.labA < 0 || cr.labA >= V)) || ((cr.bits & 6) && (cr.labB < 0 || cr.labB >= V));
         const float w = bad ? __builtin_nanf("") : wa + wb, inv = 1.0f / tot;
         for (int i0 = tid * 8; i0 < ldd; i0 += 256 * 8) {
+            float zz[8];
+            if (i0 + 8 <= 2 * V2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float2 p = z2[(i0 >> 1) + j]; zz[2 * j] = p.x; zz[2 * j + 1] = p.y; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zz[j] = i0 + j < V ? z[i0 + j] : 0.f;
+            }
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = i0 + j;
                 float g = 0.f;
                 if (i < V) {
-                    g = w * expf(z[i] - mx) * inv;
+                    g = w * expf(zz[j] - mx) * inv;
                     if (i == cr.labA) g -= wa;
                     if (i == cr.labB) g -= wb;
                 }
@@ -445,19 +468,30 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
 // Embedding backward, deterministic: tokens are ranked by (id, position) with a counting pass, then every run of equal
 // ids is summed in position order by one block (4 waves x 512 columns at H = 2048).
 // ------------------------------------------------------------------------------------------------
-__global__ void embed_rank_kernel(const int64_t* __restrict__ ids, int* __restrict__ order, int* __restrict__ runstart, int T) {
-    // O(T^2 / threads) ranking; T <= ~16k tokens per step, ids small: cheap next to one GEMM
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    const int64_t id = ids[t];
-    int rank = 0, first = 1;
-    for (int u = 0; u < T; ++u) {
+__global__ __launch_bounds__(256) void embed_rank_kernel(const int64_t* __restrict__ ids, int* __restrict__ order, int* __restrict__ runstart, int T) {
+    // O(T^2) counting rank, T <= ~16k tokens per step.  A block ranks 64 tokens (lane = token); its four waves each scan a quarter of
+    // the positions (the scanned id is wave-uniform: scalar loads) and the four partial counts are added through LDS.
+    __shared__ int srank[4][64], searlier[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const int64_t id = t < T ? ids[t] : 0;
+    const int per = (T + 3) / 4, u0 = part * per, u1 = min(T, u0 + per);
+    int rank = 0, earlier = 0;
+    for (int u = u0; u < u1; ++u) {
         const int64_t o = ids[u];
-        rank += (o < id) || (o == id && u < t);
-        if (o == id && u < t) first = 0;
+        const int eq_before = (o == id) & (u < t);
+        rank += (o < id) | eq_before;
+        earlier |= eq_before;
     }
-    order[rank] = t;
-    runstart[rank] = first;
+    srank[part][lane] = rank;
+    searlier[part][lane] = earlier;
+    __syncthreads();
+    if (part == 0 && t < T) {
+        rank = (srank[0][lane] + srank[1][lane]) + (srank[2][lane] + srank[3][lane]);
+        earlier = searlier[0][lane] | searlier[1][lane] | searlier[2][lane] | searlier[3][lane];
+        order[rank] = t;
+        runstart[rank] = earlier ? 0 : 1;
+    }
 }
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const int* __restrict__ order,
                                                         const int* __restrict__ runstart, const float* __restrict__ dx,
@@ -644,7 +678,7 @@ extern "C" int showo_embed_bwd(const int64_t* ids, const float* dx, float* dE, i
     hipStream_t s = (hipStream_t)stream;
     int* order = order_ws;
     int* runstart = order_ws + T;
-    embed_rank_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ids, order, runstart, T);
+    embed_rank_kernel<<<dim3((T + 63) / 64), dim3(256), 0, s>>>(ids, order, runstart, T);
     embed_bwd_kernel<<<dim3(T), dim3(256), 0, s>>>(ids, order, runstart, dx, dE, T, H);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;

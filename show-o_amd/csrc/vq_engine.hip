@@ -267,6 +267,10 @@ struct Ctx {
     hipStream_t s;
     int B;
     float *cur, *t1, *t2;  // fp32 activation buffers (cur holds the running activation)
+    // v->stats holds the GroupNorm statistics of this fp32 tensor (written by the conv that produced it): the next gn() of it
+    // skips the statistics pass.  Cleared when the statistics are consumed or the tensor is rewritten by anything else.
+    const float* stats_of = nullptr;
+    int stats_hw = 0, stats_c = 0;
 };
 
 // fp32 -> MFMA operand image: bf16, or the (hi, lo) pair in split precision
@@ -276,7 +280,9 @@ int to_operand(Ctx& c, const float* src, bf16_t* hi, bf16_t* lo, int64_t n) {
 }
 
 int gn(Ctx& c, const float* x, const std::string& name, bf16_t* y, bf16_t* ylo, int HW, int C, int swish) {
-    TRY(showo_gn_stats(x, c.v->stats, c.B, HW, C, c.s));
+    const bool have = c.stats_of == x && c.stats_hw == HW && c.stats_c == C;
+    c.stats_of = nullptr;
+    if (!have) TRY(showo_gn_stats(x, c.v->stats, c.B, HW, C, c.s));
     return showo_gn_apply(x, c.v->stats, c.v->Wf(name), c.v->Bv(name), y, c.v->split ? ylo : nullptr, c.B, HW, C, 1e-6f, swish,
                           c.s);
 }
@@ -285,6 +291,14 @@ int gn(Ctx& c, const float* x, const std::string& name, bf16_t* y, bf16_t* ylo, 
 int conv3(Ctx& c, const bf16_t* x, const bf16_t* xlo, const std::string& name, const float* resid, float* out, int H, int W, int cin,
           int cout, int mode) {
     showo_vq* v = c.v;
+    c.stats_of = nullptr;
+    if (v->split && (cout % 128) == 0) {  // every such conv feeds a GroupNorm: its statistics come with it
+        TRY(showo_conv3x3_bf16x3_gn(x, xlo, v->W(name), v->Wl(name), v->Bv(name), resid, out, v->stats, c.B, H, W, cin, cout, mode, c.s));
+        c.stats_of = out;
+        c.stats_hw = mode == 1 ? 4 * H * W : mode == 2 ? (H / 2) * (W / 2) : H * W;
+        c.stats_c = cout;
+        return 0;
+    }
     if (v->split)
         return showo_conv3x3_bf16x3(x, xlo, v->W(name), v->Wl(name), v->Bv(name), resid, out, c.B, H, W, cin, cout, mode, c.s);
     return showo_conv3x3_bf16(x, v->W(name), v->Bv(name), resid, out, c.B, H, W, cin, cout, mode, c.s);
@@ -293,6 +307,7 @@ int conv3(Ctx& c, const bf16_t* x, const bf16_t* xlo, const std::string& name, c
 // out fp32 [M,N] (ldo) = A[M,K] * W[N,K]^T (+ bias) (+ resid); operands as images (hi, lo)
 int gemm32(Ctx& c, const bf16_t* A, const bf16_t* Alo, int lda, const bf16_t* W, const bf16_t* Wlo, int ldw, const float* bias,
            int bias_per_row, float* out, int ldo, const float* resid, int M, int N, int K) {
+    if (out == c.stats_of) c.stats_of = nullptr;
     if (c.v->split) return showo_gemm_bf16x3(A, Alo, lda, W, Wlo, ldw, bias, bias_per_row, out, ldo, resid, ldo, M, N, K, c.s);
     return showo_gemm_bf16(A, lda, W, ldw, bias, bias_per_row, out, ldo, resid, ldo, M, N, K,
                            resid ? SHOWO_EPI_RESID_F32 : SHOWO_EPI_F32, c.s);

@@ -151,9 +151,19 @@ __global__ void lfq_unpack_nhwc_kernel(const int64_t* __restrict__ ids, float* _
 
 }  // namespace
 
+// [B, 32, 2] result + per-block partials: one per GN_PIX_PER_BLOCK pixels for showo_gn_stats, one per 256-pixel conv tile when the
+// statistics come from the convolution epilogue (showo_conv3x3_bf16x3_gn) -- sized for the latter
 extern "C" int showo_gn_stats_doubles(int B, int HW) {
-    int nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
+    int nblk = (HW + 255) / 256;
     return B * GN_GROUPS * 2 * (1 + nblk);
+}
+
+// stats[b][g][2] = sum over k < nblk of part[b][k][g][2], in k order
+extern "C" int showo_gn_finalize(const double* part, double* stats, int B, int nblk, void* stream) {
+    if (B <= 0 || nblk <= 0) return 0;
+    gn_finalize_kernel<<<dim3(B), dim3(GN_GROUPS * 2), 0, (hipStream_t)stream>>>(part, stats, nblk);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int showo_gn_stats(const float* x, double* stats, int B, int HW, int C, void* stream) {

@@ -222,6 +222,9 @@ class Trainer:
         lab = labels.to(torch.int64).contiguous()
         mask = train_mask(tr, attention_mask)
         losses = torch.empty(3, dtype=torch.float32, device=ids.device)
+        # the weights of the three losses are known up front here (training/train.py:600): the forward's cross-entropy pass also
+        # writes d(loss)/d(logits), so the backward does not read the [B*L, V] logits again
+        _lib.call("showo_train_set_loss_weights", tr, self.coeffs[0], self.coeffs[1], self.coeffs[2], 1)
         try:
             _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
                       batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())

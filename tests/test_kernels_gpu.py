@@ -677,6 +677,13 @@ def test_fused_qkv_fc1_save_matches_training_launches(variant):
         ffn1 = torch.zeros((M, F), dtype=torch.int16, device="cuda")
         L().call("showo_gemm_qkv_fc1_save_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos), L().ptr(sin),
                  L().ptr(Q1), L().ptr(K1), L().ptr(V1), L().ptr(raw1), 3 * H, L().ptr(pre1), L().ptr(ffn1), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp, 0, S())
+        # raw-only form (Q = K = Vt = NULL): the three saved tensors alone, same bits
+        raw2 = torch.zeros_like(raw1); pre2 = torch.zeros_like(pre1); ffn2 = torch.zeros_like(ffn1)
+        L().call("showo_gemm_qkv_fc1_save_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos), L().ptr(sin),
+                 None, None, None, L().ptr(raw2), 3 * H, L().ptr(pre2), L().ptr(ffn2), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp, 0, S())
+        with pytest.raises(RuntimeError):  # K without Q
+            L().call("showo_gemm_qkv_fc1_save_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), *[L().ptr(t) for t in ln], L().ptr(cos), L().ptr(sin),
+                     None, L().ptr(K1), None, L().ptr(raw2), 3 * H, L().ptr(pre2), L().ptr(ffn2), F, F, B, Lq, nH, 32, 1e-5, 0, Lq, Lp, 0, S())
         Q0, K0, V0 = bufs()
         raw0 = torch.zeros_like(raw1); pre0 = torch.zeros_like(pre1); ffn0 = torch.zeros_like(ffn1)
         L().call("showo_gemm_bf16", L().ptr(h), H, L().ptr(W), H, L().ptr(bias), 0, L().ptr(raw0), 3 * H, None, 0, M, 3 * H, H, 0, S())
@@ -688,6 +695,7 @@ def test_fused_qkv_fc1_save_matches_training_launches(variant):
     finally:
         L().call("showo_gemm_tune", 8, 0, None)
     assert torch.equal(raw1, raw0) and torch.equal(pre1, pre0) and torch.equal(ffn1, ffn0) and torch.equal(V1, V0)
+    assert torch.equal(raw2, raw0) and torch.equal(pre2, pre0) and torch.equal(ffn2, ffn0)
     for a, b in ((Q1, Q0), (K1, K0)):
         fa, fb = from_bf16_bits(a).cpu(), from_bf16_bits(b).cpu()
         assert float(fb.abs().max()) > 0.1
@@ -842,6 +850,44 @@ def test_split_gemm_and_conv_track_fp32():
                 ref = ref + res.double()
             err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
             assert err < 3e-5, (B, H, Wd, Cin, Cout, mode, err)
+
+
+def test_split_conv_with_groupnorm_statistics_equals_conv_then_gn_stats():
+    """showo_conv3x3_bf16x3_gn: same output bits as the plain call, and the (sum, sumsq) of its output per (image, group) equal to
+    showo_gn_stats on that output to the precision of the double sums -- through the epilogue-fused path (256-pixel tiles inside one
+    image, channels per group 4 / 8 / 16, with and without residual, all three gather modes) and through the fallback."""
+    torch.manual_seed(11)
+    cases = [(2, 32, 32, 128, 128, 0, True), (8, 16, 16, 256, 256, 0, True), (8, 16, 16, 128, 512, 0, False), (2, 16, 32, 128, 128, 1, False),
+             (8, 32, 32, 128, 256, 2, False), (3, 48, 16, 64, 128, 0, True), (1, 16, 16, 128, 128, 0, False), (2, 30, 34, 128, 128, 0, True)]
+    for (B, H, Wd, Cin, Cout, mode, with_res) in cases:
+        Ho, Wo = (H, Wd) if mode == 0 else (2 * H, 2 * Wd) if mode == 1 else (H // 2, Wd // 2)
+        x = torch.randn(B, H, Wd, Cin) + 0.2
+        wgt = torch.randn(Cout, 3, 3, Cin) * 0.03
+        bias = torch.randn(Cout)
+        res = dev(torch.randn(B, Ho * Wo, Cout)) if with_res else None
+        xh, xl = _split(x)
+        wh, wl = _split(wgt)
+        out0 = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        out1 = torch.full_like(out0, float("nan"))
+        nd = L().load().showo_gn_stats_doubles(B, Ho * Wo)
+        st1 = torch.full((nd,), float("nan"), dtype=torch.float64, device="cuda")
+        st0 = torch.zeros_like(st1)
+        rp = None if res is None else L().ptr(res)
+        L().call("showo_conv3x3_bf16x3", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), rp, L().ptr(out0),
+                 B, H, Wd, Cin, Cout, mode, S())
+        L().call("showo_conv3x3_bf16x3_gn", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), rp, L().ptr(out1),
+                 L().ptr(st1), B, H, Wd, Cin, Cout, mode, S())
+        assert torch.equal(out0, out1), (B, H, Wd, Cin, Cout, mode)
+        L().call("showo_gn_stats", L().ptr(out0), L().ptr(st0), B, Ho * Wo, Cout, S())
+        a, b = st1[:B * 64].cpu(), st0[:B * 64].cpu()
+        assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=1e-12, atol=1e-9), (B, H, Wd, Cin, Cout, mode, float((a - b).abs().max()))
+        og = out0.cpu().double().reshape(B, Ho * Wo, 32, Cout // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+        assert torch.allclose(a.reshape(B, 32, 2)[..., 0], og.sum(-1), rtol=1e-11, atol=1e-8)
+        assert torch.allclose(a.reshape(B, 32, 2)[..., 1], (og * og).sum(-1), rtol=1e-11)
+        st2 = torch.full_like(st1, float("nan"))  # deterministic
+        L().call("showo_conv3x3_bf16x3_gn", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), rp, L().ptr(out1),
+                 L().ptr(st2), B, H, Wd, Cin, Cout, mode, S())
+        assert torch.equal(st1[:B * 64], st2[:B * 64])
 
 
 # --------------------------------------------------------------------------------------------- AR decode sampler
