@@ -77,6 +77,19 @@ int showo_gemm_set_impl(int impl);
  * launches with few tiles off / on (default on: tiles x splits ~ 256 blocks, partials summed in split order by the last block). */
 int showo_gemm_tune(int gn, int flags, unsigned long long* dbg);
 
+/* Weight-gradient GEMM on token-major operands (training/train.py:612 loss.backward(): autograd of F.linear): out fp32 [M, N] (ldo)
+ * (+)= A^T B, A = dY bf16 [T, M] (lda), B = X bf16 [T, N] (ldb), contraction over the T token rows -- dW = dY^T X without transposing
+ * either operand (gfx950's transposing LDS read feeds the MFMA; gemm_tn.hip).  lda, ldb multiples of 8 that cover M, N rounded up
+ * to 8; operands 16-byte aligned; any T >= 1.  accumulate != 0 adds into out.  rows_padded != 0: both buffers are readable up to
+ * row roundup(T, 64) - 1 (contents arbitrary; zeroed in registers) -- with lda, ldb covering whole 256-column tiles this selects the
+ * fast form (unchecked DMAs, 3-deep operand ring); otherwise every fetch is checked.  Split-K by the rule of the production GEMM
+ * (a function of (M, N, T) alone: run-to-run identical bits).  Bias gradients: showo_colsum_bf16 on the same dY. */
+int showo_gemm_tn_bf16(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* out, int ldo, int M, int N, int T,
+                       int accumulate, int rows_padded, void* stream);
+/* colsum[c] (+)= sum_t x[t][c], x bf16 [T, C] (row stride ld, 16-byte aligned, ld % 8 == 0); colpart: fp32 scratch of
+ * (ceil(T / 64) + 8) * C floats.  Deterministic (per-64-row partials in row order, then a fixed two-level sum). */
+int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float* colpart, float* colsum, int accumulate, void* stream);
+
 /* Launch counters of the production GEMM family (gemm2p / gemm3w): out3[0] = launches, out3[1] = of those the fused [Wqkv ; W1]
  * save-for-backward form (showo_gemm_qkv_fc1_save_bf16), out3[2] = launches that split K; reset != 0 zeroes them after reading.
  * Parity tests use it to assert that a training batch ran the T >= 256 kernels that the benchmark times. */

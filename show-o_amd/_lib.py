@@ -76,6 +76,8 @@ _PROTOS = {
     "showo_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i,
                        c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_bf16x3": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_colsum_bf16": [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "showo_conv3x3_bf16x3": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_conv3x3_bf16x3_gn": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],

@@ -144,7 +144,7 @@ extern "C" int showo_engine_create(const showo_engine_config* c, showo_engine** 
     rc |= e->alloc(&e->x, T * H); rc |= e->alloc(&e->h, T * H); rc |= e->alloc(&e->qkv, T * 3 * H);
     rc |= e->alloc(&e->Q, T * H); rc |= e->alloc(&e->K, T * H);
     rc |= e->alloc(&e->Vt, (int64_t)c->max_batch * H * Lp);
-    rc |= e->alloc(&e->attn, T * H); rc |= e->alloc(&e->ffn, T * F); rc |= e->alloc(&e->hf, T * H);
+    rc |= e->alloc(&e->attn, T * H); rc |= e->alloc(&e->ffn, T * F); rc |= e->alloc(&e->hf, (T + 64) * H);  // + 64 rows: the trainer's lm_head weight gradient reads hf up to the next multiple of 64 rows
     rc |= e->alloc(&e->iv, T * 4); rc |= e->alloc(&e->flag, 4); rc |= e->alloc(&e->rows, T);
     rc |= e->alloc(&e->ids_all, T); rc |= e->alloc(&e->cur, T); rc |= e->alloc(&e->sampled, T); rc |= e->alloc(&e->sel, T);
     rc |= e->alloc(&e->iv1, 4); rc |= e->alloc(&e->tok1, 1);

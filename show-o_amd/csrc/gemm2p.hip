@@ -475,6 +475,7 @@ int pick_bm(int M, int N) {
 // stream is being captured (the model is used), and with SHOWO_GEMM_TUNE=0.  In-place residual launches are timed on a scratch output.
 // g_bm_cache / the split-K workspaces are process-wide: guarded by g_gemm_mu (autograd's backward thread launches GEMMs too).
 std::mutex g_gemm_mu;
+
 std::map<std::tuple<int, int, int, int>, int> g_bm_cache;  // (M, N, K, EPI) -> variant | tile-group width << 16
 int g_gemm_tune = -1;
 
@@ -563,6 +564,19 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace
+
+// split-K policy / workspace / launch counters shared with gemm_tn.hip (the caller holds no lock; the workspace table is guarded here)
+int gemm_splitk_count(int M, int N, int K) { return splitk_count(M, N, K); }
+bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
+    std::lock_guard<std::mutex> lock(g_gemm_mu);
+    return splitk_ws(s, need, ws, tick);
+}
+int gemm_splitk_ticks() { return SPLITK_TICKS; }
+void gemm_count_launch(bool split) {
+    std::lock_guard<std::mutex> lock(g_gemm_mu);
+    g_cnt_gemm2p++;
+    if (split) g_cnt_splitk++;
+}
 
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);

@@ -41,6 +41,8 @@ struct GemmArgs {
     // tile's ticket sums the `splits` partials IN SPLIT ORDER (its own included, read back from ws) and runs the ordinary epilogue:
     // the result does not depend on which block arrived last.
     int splits = 1; float4* ws = nullptr; unsigned* tick = nullptr;
+    // gemm_tn only (token-major operands, contraction over rows): rows k >= Klim of both operands read as zero (K = Klim rounded up to 64)
+    int Klim = 0;
 };
 
 constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
@@ -455,6 +457,11 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 
 // production kernel (gemm2p.hip)
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
+// split-K policy and per-stream workspace of the production family (gemm2p.hip), shared with gemm_tn.hip
+int gemm_splitk_count(int M, int N, int K);
+bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
+int gemm_splitk_ticks();
+void gemm_count_launch(bool split);
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);

@@ -30,6 +30,7 @@ struct LayerT {
     // saved activations
     float* x = nullptr;
     bf16_t *h = nullptr, *qkv = nullptr, *Q = nullptr, *K = nullptr, *Vt = nullptr, *attn = nullptr, *f = nullptr;
+    bf16_t* a = nullptr;  // gelu_new(f) [T, F]: the token-major operand of the fc2 weight gradient (showo_gemm_tn_bf16)
     float* lse = nullptr;
     // gradients (fp32, reference parameter layout)
     float *gwqkv = nullptr, *gbqkv = nullptr, *gwd = nullptr, *gbd = nullptr, *gw1 = nullptr, *gb1 = nullptr, *gw2 = nullptr, *gb2 = nullptr;
@@ -38,6 +39,15 @@ struct LayerT {
 };
 struct Grad { float* p; int64_t n; };
 struct Bound { std::string key; float *p, *m, *v; int64_t n; bool decay; };
+
+// SHOWO_TRAIN_TN (default 1): weight gradients by showo_gemm_tn_bf16 on the token-major tensors the backward already holds (dY, and the
+// activations saved by the forward) + showo_colsum_bf16 for the bias gradients; 0 = transpose both operands and run the k-contiguous
+// GEMM (the round-2 path: 243 transposes per step).  Read once per process: the per-layer gelu(fc1) buffers exist only in TN mode.
+bool train_tn() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SHOWO_TRAIN_TN"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
 }  // namespace
 
 struct showo_trainer {
@@ -118,7 +128,7 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     t->Tmax = max_batch * max_seq;
     t->Tp = ((t->Tmax + 63) / 64) * 64;
     t->Lp = ((max_seq + 63) / 64) * 64;
-    t->Vp = ((e->V + 63) / 64) * 64;
+    t->Vp = ((e->V + 255) / 256) * 256;  // whole 256-column tiles: the lm_head weight gradient (gemm_tn.hip) fetches its dY columns unchecked
     const int64_t H = e->H, F = e->F, V = e->V, T = t->Tmax, Tp = t->Tp, Vp = t->Vp, nH = e->nH;
     int rc = 0;
     t->L.resize(e->nL);
@@ -135,9 +145,12 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     for (int i = 0; i < e->nL; ++i) {
         LayerT& l = t->L[i];
         rc |= t->alloc(&l.wqkvT, H * 3 * H); rc |= t->alloc(&l.wdT, H * H); rc |= t->alloc(&l.w1T, H * F); rc |= t->alloc(&l.w2T, F * H);
-        rc |= t->alloc(&l.x, T * H); rc |= t->alloc(&l.h, T * H); rc |= t->alloc(&l.qkv, T * 3 * H);
+        // token-major operands of showo_gemm_tn_bf16 (h, attn, a; dy16 / dff / dqkv / dlogits below) are allocated with Tp rows: the
+        // kernel reads -- and zeroes in registers -- the rows between T and the next multiple of 64
+        rc |= t->alloc(&l.x, T * H); rc |= t->alloc(&l.h, Tp * H); rc |= t->alloc(&l.qkv, T * 3 * H);
         rc |= t->alloc(&l.Q, T * H); rc |= t->alloc(&l.K, T * H); rc |= t->alloc(&l.Vt, (int64_t)max_batch * H * t->Lp);
-        rc |= t->alloc(&l.attn, T * H); rc |= t->alloc(&l.f, T * F); rc |= t->alloc(&l.lse, (int64_t)max_batch * nH * max_seq);
+        rc |= t->alloc(&l.attn, Tp * H); rc |= t->alloc(&l.f, T * F); rc |= t->alloc(&l.lse, (int64_t)max_batch * nH * max_seq);
+        if (train_tn()) rc |= t->alloc(&l.a, Tp * F);
         if (rc) break;
         hipMemset(l.Vt, 0, (size_t)max_batch * H * t->Lp * sizeof(bf16_t));
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
@@ -178,14 +191,14 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
         t->grads["showo.model.final_layernorm.bias"] = Grad{t->gfln + H, H};
     }
     rc |= t->alloc(&t->logits, T * V);
-    rc |= t->alloc(&t->dlogits, T * Vp);
+    rc |= t->alloc(&t->dlogits, Tp * Vp);
     // bigT holds the transposed dY side of every wgrad GEMM: dlogits^T [Vp, Tp], df^T [F, Tp], dqkv^T [3H, Tp] -- the tallest wins
     // (round 3: sizing it by max(Vp, F) alone overflowed for geometries with 3H > max(Vp, F), found by the SMALL training fixture)
     const int64_t bigrows = std::max<int64_t>(std::max<int64_t>(Vp, F), 3 * H);
     rc |= t->alloc(&t->bigT, bigrows * Tp);
     rc |= t->alloc(&t->xT, std::max<int64_t>(F, H) * Tp);
-    rc |= t->alloc(&t->dy, T * H); rc |= t->alloc(&t->dh, T * H); rc |= t->alloc(&t->dy16, T * H); rc |= t->alloc(&t->d_o, T * H);
-    rc |= t->alloc(&t->dff, T * F); rc |= t->alloc(&t->dqk, T * 2 * H); rc |= t->alloc(&t->dqkv, T * 3 * H);
+    rc |= t->alloc(&t->dy, T * H); rc |= t->alloc(&t->dh, T * H); rc |= t->alloc(&t->dy16, Tp * H); rc |= t->alloc(&t->d_o, T * H);
+    rc |= t->alloc(&t->dff, Tp * F); rc |= t->alloc(&t->dqk, T * 2 * H); rc |= t->alloc(&t->dqkv, Tp * 3 * H);
     rc |= t->alloc(&t->QT, (int64_t)max_batch * H * t->Lp); rc |= t->alloc(&t->KT, (int64_t)max_batch * H * t->Lp);
     rc |= t->alloc(&t->dOT, (int64_t)max_batch * H * t->Lp);
     rc |= t->alloc(&t->D, (int64_t)max_batch * nH * max_seq);
@@ -295,6 +308,7 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
         // The layer's input (saved for ln_bwd) lives in l.x already: the previous layer's fc2 epilogue wrote it there.  The residual
         // stream ping-pongs l.x -> e->x (after dense) -> L[i + 1].x (after fc2; e->x for the last layer): no 92 MB copy per layer.
         float* xnext = (i + 1 < e->nL) ? t->L[i + 1].x : e->x;
+        bf16_t* ffn = l.a ? l.a : e->ffn;  // TN mode keeps gelu(fc1) per layer for the fc2 weight gradient
         TRY(showo_layernorm_f32_bf16(l.x, w.ln_w, w.ln_b, l.h, nullptr, T, H, e->cfg.ln_eps, s));
         if (fused_proj) {
             // q/k/v_proj + q/k LayerNorm + RoPE + relayout AND fc1 + gelu_new in one launch that also saves qkv and the fc1
@@ -303,12 +317,12 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
                 // raw-only form: the launch stores qkv / the fc1 pre-activation / gelu and the q/k LayerNorm + RoPE + relayout run as
                 // showo_qk_prep on the saved qkv (same bits: both start from the rounded values)
                 TRY(showo_gemm_qkv_fc1_save_bf16(l.h, H, w.wqkv, H, w.bqkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, nullptr, nullptr,
-                                                 nullptr, l.qkv, 3 * H, l.f, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
+                                                 nullptr, l.qkv, 3 * H, l.f, ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
                 TRY(showo_qk_prep(l.qkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt, B, L, nH, e->cfg.rotary_dim,
                                   e->cfg.ln_eps, 0, L, Lp, s));
             } else
             TRY(showo_gemm_qkv_fc1_save_bf16(l.h, H, w.wqkv, H, w.bqkv, w.qln_w, w.qln_b, w.kln_w, w.kln_b, e->cosT, e->sinT, l.Q, l.K, l.Vt,
-                                             l.qkv, 3 * H, l.f, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
+                                             l.qkv, 3 * H, l.f, ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, 0, L, Lp, 0, s));
             TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
             TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, l.x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
         } else {
@@ -318,9 +332,9 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
             TRY(showo_attn_fwd_lse(l.Q, l.K, l.Vt, iv, flag, mask, l.attn, l.lse, B, nH, L, L, L, Lp, H, s));
             TRY(showo_gemm_bf16(l.attn, H, w.wd, H, w.bd, 0, e->x, H, l.x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
             TRY(showo_gemm_bf16(l.h, H, w.w1, H, w.b1, 0, l.f, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));
-            TRY(showo_gelu_bf16(l.f, e->ffn, (int64_t)T * F, s));
+            TRY(showo_gelu_bf16(l.f, ffn, (int64_t)T * F, s));
         }
-        TRY(showo_gemm_bf16(e->ffn, F, w.w2, F, w.b2, 0, xnext, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+        TRY(showo_gemm_bf16(ffn, F, w.w2, F, w.b2, 0, xnext, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
     }
     TRY(showo_layernorm_f32_bf16(e->x, e->fln_w, e->fln_b, e->hf, nullptr, T, H, e->cfg.ln_eps, s));
     TRY(showo_gemm_bf16(e->hf, H, e->wlm, H, e->blm, 0, t->logits, V, nullptr, 0, T, V, H, SHOWO_EPI_F32, s));
@@ -388,9 +402,14 @@ extern "C" int showo_train_backward_head(showo_trainer* t, const int64_t* labels
     if (!have_dl)
         TRY(showo_ce_loss(t->logits, V, labels, B, L, V, b_t2i, b_lm, b_mmu, max_seq_len, g_t2i, g_lm, g_mmu, t->ce_rows, t->counts,
                           t->rowloss, t->dlogits, Vp, nullptr, s));
+    if (train_tn()) {
+        TRY(showo_colsum_bf16(t->dlogits, Vp, T, Vp, t->colpart, t->gblm, 0, s));                                        // lm_head bias grad
+        TRY(showo_gemm_tn_bf16(t->dlogits, Vp, e->hf, H, t->gwlm, H, V, H, T, 0, 1, s));                                    // dWlm [V,H]
+    } else {
     TRY(showo_transpose_bf16(t->dlogits, Vp, t->bigT, T, Vp, Tp, 0, t->colpart, t->gblm, 0, s));  // dlogits^T + lm_head bias grad
     TRY(showo_transpose_bf16(e->hf, H, t->xT, T, H, Tp, 0, nullptr, nullptr, 0, s));
     TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, t->gwlm, H, nullptr, 0, V, H, Tp, SHOWO_EPI_F32, s));      // dWlm [V,H]
+    }
     TRY(showo_gemm_bf16(t->dlogits, Vp, t->wlmT, Vp, nullptr, 0, t->dh, H, nullptr, 0, T, H, Vp, SHOWO_EPI_F32, s));   // d hf
     SHOWO_CHECK_HIP(hipMemsetAsync(t->dy, 0, (size_t)T * H * sizeof(float), s));
     TRY(showo_ln_bwd(e->x, e->fln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, t->gfln, T, H, e->cfg.ln_eps, s));
@@ -403,6 +422,29 @@ extern "C" int showo_train_backward_layer(showo_trainer* t, int i, void* stream)
     {
         Layer& w = e->layers[i];
         LayerT& l = t->L[i];
+        if (train_tn() && l.a) {
+            // weight gradients straight from the token-major tensors: dW = dY^T X by showo_gemm_tn_bf16, db = column sums of dY
+            TRY(showo_colsum_bf16(t->dy16, H, T, H, t->colpart, l.gb2, 0, s));                                                  // db2 = dbd
+            SHOWO_CHECK_HIP(hipMemcpyAsync(l.gbd, l.gb2, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            TRY(showo_gemm_tn_bf16(t->dy16, H, l.a, F, l.gw2, F, H, F, T, 0, 1, s));                                               // dW2 [H,F]
+            TRY(showo_gemm_tn_bf16(t->dy16, H, l.attn, H, l.gwd, H, H, H, T, 0, 1, s));                                            // dWd [H,H]
+            TRY(showo_gemm_bf16(t->dy16, H, l.w2T, H, nullptr, 0, t->dff, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));          // d a
+            TRY(showo_dgelu_bf16(t->dff, l.f, t->dff, (int64_t)T * F, s));                                                      // d f
+            TRY(showo_colsum_bf16(t->dff, F, T, F, t->colpart, l.gb1, 0, s));                                                   // db1
+            TRY(showo_gemm_tn_bf16(t->dff, F, l.h, H, l.gw1, H, F, H, T, 0, 1, s));                                                // dW1 [F,H]
+            TRY(showo_gemm_bf16(t->dff, F, l.w1T, F, nullptr, 0, t->dh, H, nullptr, 0, T, H, F, SHOWO_EPI_F32, s));             // dh (mlp)
+            // attention
+            TRY(showo_gemm_bf16(t->dy16, H, l.wdT, H, nullptr, 0, t->d_o, H, nullptr, 0, T, H, H, SHOWO_EPI_BF16, s));          // d o
+            TRY(showo_head_transpose(l.Q, t->QT, B, nH, L, Lp, (int64_t)nH * L * 64, (int64_t)L * 64, 64, s));
+            TRY(showo_head_transpose(l.K, t->KT, B, nH, L, Lp, (int64_t)nH * L * 64, (int64_t)L * 64, 64, s));
+            TRY(showo_attn_bwd(l.Q, l.K, t->QT, t->KT, l.qkv + 2 * H, 3 * H, l.attn, t->d_o, H, t->dOT, l.lse, t->D, iv, nullptr, t->dqk, 2 * H,
+                               t->dqk + H, 2 * H, t->dqkv + 2 * H, 3 * H, B, nH, L, Lp, s));
+            TRY(showo_qkln_rope_bwd(t->dqk, t->dqk + H, 2 * H, l.qkv, w.qln_w, w.kln_w, e->cosT, e->sinT, t->dqkv, t->qkpart, l.gqk, T, L,
+                                    nH, e->cfg.rotary_dim, e->cfg.ln_eps, s));
+            TRY(showo_colsum_bf16(t->dqkv, 3 * H, T, 3 * H, t->colpart, l.gbqkv, 0, s));                                        // dbqkv
+            TRY(showo_gemm_tn_bf16(t->dqkv, 3 * H, l.h, H, l.gwqkv, H, 3 * H, H, T, 0, 1, s));                                     // dWqkv [3H,H]
+            TRY(showo_gemm_bf16(t->dqkv, 3 * H, l.wqkvT, 3 * H, nullptr, 0, t->dh, H, t->dh, H, T, H, 3 * H, SHOWO_EPI_RESID_F32, s));  // dh += attn part
+        } else {
         // dy^T (+ bias grads of fc2 and dense: both are column sums of dy)
         TRY(showo_transpose_bf16(t->dy16, H, t->bigT, T, H, Tp, 0, t->colpart, l.gb2, 0, s));
         SHOWO_CHECK_HIP(hipMemcpyAsync(l.gbd, l.gb2, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -428,6 +470,7 @@ extern "C" int showo_train_backward_layer(showo_trainer* t, int i, void* stream)
         TRY(showo_transpose_bf16(t->dqkv, 3 * H, t->bigT, T, 3 * H, Tp, 0, t->colpart, l.gbqkv, 0, s));                     // dqkv^T, dbqkv
         TRY(showo_gemm_bf16(t->bigT, Tp, t->xT, Tp, nullptr, 0, l.gwqkv, H, nullptr, 0, 3 * H, H, Tp, SHOWO_EPI_F32, s));   // dWqkv (xT = h^T)
         TRY(showo_gemm_bf16(t->dqkv, 3 * H, l.wqkvT, 3 * H, nullptr, 0, t->dh, H, t->dh, H, T, H, 3 * H, SHOWO_EPI_RESID_F32, s));  // dh += attn part
+        }
         // LayerNorm + residual
         TRY(showo_ln_bwd(l.x, w.ln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, l.gln, T, H, e->cfg.ln_eps, s));
         }

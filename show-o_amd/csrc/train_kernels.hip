@@ -102,6 +102,35 @@ static inline void colsum_reduce(const float* part, float* out, int nblk, int C,
     colsum_combine_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sub8, out, C, accumulate);
 }
 
+// Column sums of a token-major bf16 matrix X [T, C] (row stride ld): the bias gradient of a Linear is the column sum of its dY.
+// Block (cb, rb) sums rows 64 rb .. 64 rb + 63 of columns 2048 cb ..; a thread owns 8 consecutive columns (one 16-byte load per row,
+// a row of the block is 4 KiB contiguous).  part[rb][c] partials in row order, reduced by colsum_reduce: no atomics.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int T, int C, int ld) {
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8, r0 = blockIdx.y * 64;
+    if (c0 >= C) return;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    const int rend = min(r0 + 64, T);
+    const bf16_t* p = x + (int64_t)r0 * ld + c0;
+    const bool full = c0 + 8 <= C;
+#pragma unroll 8
+    for (int r = r0; r < rend; ++r, p += ld) {
+        if (full) {
+            const uint4 u = *reinterpret_cast<const uint4*>(p);
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += bf2f(e[j]);
+        } else {
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < C) a[j] += bf2f(p[j]);
+        }
+    }
+    float* o = part + (int64_t)blockIdx.y * C + c0;
+    for (int j = 0; j < 8; ++j)
+        if (c0 + j < C) o[j] = a[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward fused with the residual add of the parallel block (y = x + f(LN(x)), phi.py:774-790):
 //   dx = dy + LN'(x)^T dh.   One wave per row; a block walks LNB_ROWS rows and keeps per-lane column partials of
@@ -615,6 +644,20 @@ extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int
     hipStream_t s = (hipStream_t)stream;
     transpose_kernel<<<dim3((C + 63) / 64, Tp / 64), dim3(256), 0, s>>>(x, xt, colsum ? colpart : nullptr, T, C, ld, Tp, mode);
     if (colsum) colsum_reduce(colpart, colsum, Tp / 64, C, accumulate, s);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// colsum[c] (+)= sum_t x[t][c] of a token-major bf16 matrix (bias gradients next to showo_gemm_tn_bf16).  colpart: fp32 scratch of
+// (ceil(T / 64) + 8) * C floats.  Deterministic two-level sum.
+extern "C" int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float* colpart, float* colsum, int accumulate, void* stream) {
+    if (T <= 0 || C <= 0) return 0;
+    if (!x || !colpart || !colsum) return set_error_msg(1, "colsum: null argument");
+    if ((ld % 8) || (((uintptr_t)x) & 15)) return set_error_msg(1, "colsum: x must be 16-byte aligned with ld a multiple of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (T + 63) / 64;
+    colsum_bf16_kernel<<<dim3((C + 2047) / 2048, nblk), dim3(256), 0, s>>>(x, colpart, T, C, ld);
+    colsum_reduce(colpart, colsum, nblk, C, accumulate, s);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -702,6 +702,40 @@ def test_fused_qkv_fc1_save_matches_training_launches(variant):
         assert ((fa - fb).abs() <= 2 ** -7 * fb.abs() + 1e-6).all(), float((fa - fb).abs().max())
 
 
+@pytest.mark.parametrize("M,N,T,lda", [(256, 256, 200, 256), (264, 520, 1000, 320), (512, 768, 2100, 512), (128, 384, 135, 128),
+                                       (300, 2048, 777, 304)])
+def test_gemm_tn_weight_gradient_on_token_major_operands(M, N, T, lda):
+    """showo_gemm_tn_bf16: out[M, N] = A^T B over the T token rows (dW = dY^T X) straight from token-major bf16 operands, against fp64
+    on the same bf16 values: T not a multiple of 64 (zero page), ragged / non-multiple-of-8 M, a strided A, the split-K shape,
+    accumulation, run-to-run identical bits; showo_colsum_bf16 (the bias gradient) next to it."""
+    torch.manual_seed(M + N + T)
+    A = torch.randn(T, lda)
+    B = torch.randn(T, N) * 0.5
+    Ab, Bb = dev(to_bf16_bits(A)), dev(to_bf16_bits(B))
+    ref = bf16_round(A[:, :M]).double().T @ bf16_round(B).double()
+    scale = float(ref.abs().max())
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    L().call("showo_gemm_tn_bf16", L().ptr(Ab), lda, L().ptr(Bb), N, L().ptr(out), N, M, N, T, 0, 0, S())
+    sync()
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * scale * max(1.0, (T / 512) ** 0.5), (err, scale)
+    out2 = torch.full_like(out, float("nan"))
+    L().call("showo_gemm_tn_bf16", L().ptr(Ab), lda, L().ptr(Bb), N, L().ptr(out2), N, M, N, T, 0, 0, S())
+    assert torch.equal(out, out2)
+    L().call("showo_gemm_tn_bf16", L().ptr(Ab), lda, L().ptr(Bb), N, L().ptr(out2), N, M, N, T, 1, 0, S())  # accumulate
+    assert float((out2.cpu().double() - 2 * ref).abs().max()) < 4e-5 * scale * max(1.0, (T / 512) ** 0.5)
+    # bias gradient: column sums of the same dY
+    part = torch.empty((((T + 63) // 64 + 8) * M,), dtype=torch.float32, device="cuda")
+    cs = torch.full((M,), float("nan"), dtype=torch.float32, device="cuda")
+    L().call("showo_colsum_bf16", L().ptr(Ab), lda, T, M, L().ptr(part), L().ptr(cs), 0, S())
+    want = bf16_round(A[:, :M]).double().sum(0)
+    assert float((cs.cpu().double() - want).abs().max()) < 1e-5 * float(want.abs().max()) + 1e-4
+    L().call("showo_colsum_bf16", L().ptr(Ab), lda, T, M, L().ptr(part), L().ptr(cs), 1, S())
+    assert float((cs.cpu().double() - 2 * want).abs().max()) < 2e-5 * float(want.abs().max()) + 2e-4
+    with pytest.raises(RuntimeError):  # a row must hold the 8-column unit of its last column
+        L().call("showo_gemm_tn_bf16", L().ptr(Ab), lda, L().ptr(Bb), N, L().ptr(out), N, lda + 4, N, T, 0, 0, S())
+
+
 SPLITK_OFF, SPLITK_ON = 64, 128  # showo_gemm_tune flag bits
 
 

@@ -83,6 +83,55 @@ int main(int argc, char** argv) {
     }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (quick == 5) {  // weight-gradient shapes: showo_gemm_tn_bf16 on token-major operands vs two transposes + the k-contiguous GEMM
+        struct TS { int M, N, T; const char* name; };
+        const TS ts[] = {{256, 256, 200, "edge 1 tile"}, {264, 520, 1000, "edge ragged"}, {512, 768, 2100, "split-K"}, {2048, 8192, 11223, "dW2"},
+                         {8192, 2048, 11223, "dW1"}, {6144, 2048, 11223, "dWqkv"}, {2048, 2048, 11223, "dWd"}, {58498, 2048, 11223, "dWlm"}};
+        for (const TS& s : ts) {
+            const int Tp = ((s.T + 63) / 64) * 64, lda = ((s.M + 63) / 64) * 64, ldb = s.N;
+            uint16_t *A, *B, *At, *Bt; float *o_tn, *o_nt;
+            CK(hipMalloc(&A, (size_t)Tp * lda * 2)); CK(hipMalloc(&B, (size_t)Tp * ldb * 2));  // rows_padded: readable up to Tp
+            CK(hipMemsetAsync(A, 0xff, (size_t)Tp * lda * 2, st)); CK(hipMemsetAsync(B, 0xff, (size_t)Tp * ldb * 2, st));  // NaN bit patterns behind row T
+            CK(hipMalloc(&At, (size_t)lda * Tp * 2)); CK(hipMalloc(&Bt, (size_t)s.N * Tp * 2));
+            CK(hipMalloc(&o_tn, (size_t)s.M * s.N * 4)); CK(hipMalloc(&o_nt, (size_t)s.M * s.N * 4));
+            fill_kernel<<<1024, 256, 0, st>>>(A, (size_t)s.T * lda, 5u, 1.0f);
+            fill_kernel<<<1024, 256, 0, st>>>(B, (size_t)s.T * ldb, 6u, 0.5f);
+            CK(hipMemsetAsync(o_tn, 0xff, (size_t)s.M * s.N * 4, st));
+            RC(showo_gemm_set_impl(0));
+            auto nt = [&]() {
+                RC(showo_transpose_bf16(A, lda, At, s.T, lda, Tp, 0, nullptr, nullptr, 0, st));
+                RC(showo_transpose_bf16(B, ldb, Bt, s.T, s.N, Tp, 0, nullptr, nullptr, 0, st));
+                RC(showo_gemm_bf16(At, Tp, Bt, Tp, nullptr, 0, o_nt, s.N, nullptr, 0, s.M, s.N, Tp, 2, st));
+            };
+            auto tn = [&]() { RC(showo_gemm_tn_bf16(A, lda, B, ldb, o_tn, s.N, s.M, s.N, s.T, 0, 1, st)); };
+            nt(); tn();
+            CK(hipStreamSynchronize(st));
+            std::vector<float> h0((size_t)s.M * s.N), h1((size_t)s.M * s.N);
+            CK(hipMemcpy(h0.data(), o_nt, h0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o_tn, h1.size() * 4, hipMemcpyDeviceToHost));
+            double maxd = 0, maxr = 0; size_t bad = 0, same = 0;
+            for (size_t i = 0; i < h0.size(); ++i) {
+                const double d = fabs((double)h0[i] - h1[i]);
+                if (!(d <= 1e-3 * (1 + fabs(h0[i])))) bad++;
+                if (h0[i] == h1[i]) same++;
+                maxd = std::max(maxd, d); maxr = std::max(maxr, (double)fabs(h0[i]));
+            }
+            float ms_nt, ms_tn, ms_g;
+            const int iters = 8;
+            for (int i = 0; i < 2; ++i) { nt(); tn(); }
+            CK(hipEventRecord(e0, st)); for (int i = 0; i < iters; ++i) nt(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_nt, e0, e1));
+            CK(hipEventRecord(e0, st)); for (int i = 0; i < iters; ++i) tn(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_tn, e0, e1));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) RC(showo_gemm_bf16(At, Tp, Bt, Tp, nullptr, 0, o_nt, s.N, nullptr, 0, s.M, s.N, Tp, 2, st));
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_g, e0, e1));
+            const double fl = 2.0 * s.M * s.N * s.T * iters / 1e9;
+            printf("%-12s M=%5d N=%5d T=%5d | transposes + NT %7.1f us (GEMM alone %7.1f us, %6.1f TF) | TN %7.1f us %6.1f TF | max|d| %.3g of %.3g, equal bits %.4f %s\n",
+                   s.name, s.M, s.N, s.T, ms_nt / iters * 1e3, ms_g / iters * 1e3, fl / ms_g, ms_tn / iters * 1e3, fl / ms_tn, maxd, maxr,
+                   (double)same / h0.size(), bad ? "**MISMATCH**" : "");
+            fflush(stdout);
+            CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(At)); CK(hipFree(Bt)); CK(hipFree(o_tn)); CK(hipFree(o_nt));
+        }
+        return 0;
+    }
     for (const Shape& s : shapes) {
         if (quick == 1 && (size_t)s.M * s.N * s.K > (size_t)6192 * 14336 * 2048) continue;
         const size_t nA = (size_t)s.M * s.K, nW = (size_t)s.N * s.K, nO = (size_t)s.M * s.N;
