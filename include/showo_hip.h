@@ -265,6 +265,10 @@ int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int T, int C, 
 int showo_ln_bwd(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16, float* part,
                  float* dgb, int T, int H, float eps, void* stream);
 int showo_ln_bwd_blocks(int T);
+/* the same plus dxsum[H] = column sums of dx16: dx is the output gradient of the block below, whose dense / fc2 bias gradients are
+ * exactly these sums (no second pass over dx16).  part: scratch fp32 [showo_ln_bwd_blocks(T), 3, H]. */
+int showo_ln_bwd_colsum(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16, float* part,
+                        float* dgb, float* dxsum, int T, int H, float eps, void* stream);
 /* Backward of q/k LayerNorm(64) + partial rotary + the 1/8 fold (phi.py:661-694): dq, dk bf16 [T, ldg] (w.r.t. the stored Q,
  * K), raw qkv bf16 [T, 3*nH*64] -> dqkv bf16 [T, 3*nH*64] (q and k sections), dparams fp32 [4,64] = (dq_ln_w, dq_ln_b,
  * dk_ln_w, dk_ln_b); part: scratch fp32 [showo_qkln_rope_bwd_blocks(T, nH), 4, 64]. */
@@ -295,6 +299,10 @@ int showo_grad_wire_pack(const float* grad, uint16_t* wire, int64_t n, float sca
 int showo_grad_wire_unpack(const uint16_t* wire, float* grad, int64_t n, void* stream);
 /* df = da * gelu_new'(f) (bf16, elementwise) */
 int showo_dgelu_bf16(const uint16_t* da, const uint16_t* f, uint16_t* df, int64_t n, void* stream);
+/* showo_dgelu_bf16 on a [T, C] matrix (row stride ld) fused with the column sums of its result (the fc1 bias gradient, like
+ * showo_colsum_bf16 on df); colpart: fp32 scratch of (ceil(T / 64) + 8) * C floats; df may alias da. */
+int showo_dgelu_colsum_bf16(const uint16_t* da, const uint16_t* f, uint16_t* df, int ld, int T, int C, float* colpart, float* colsum,
+                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * t2i sampler (reference models/modeling_showo.py:140-179, models/sampling.py:14-36)

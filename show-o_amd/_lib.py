@@ -43,6 +43,7 @@ _PROTOS = {
     "showo_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "showo_ln_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "showo_ln_bwd_blocks": [c_i],
+    "showo_ln_bwd_colsum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "showo_qkln_rope_bwd": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "showo_qkln_rope_bwd_blocks": [c_i, c_i],
     "showo_ce_loss": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
@@ -52,6 +53,7 @@ _PROTOS = {
     "showo_grad_wire_pack": [c_p, c_p, c_i64, c_f, c_p],
     "showo_grad_wire_unpack": [c_p, c_p, c_i64, c_p],
     "showo_dgelu_bf16": [c_p, c_p, c_p, c_i64, c_p],
+    "showo_dgelu_colsum_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "showo_gelu_bf16": [c_p, c_p, c_i64, c_p],
     "showo_train_create": [c_p, c_i, c_i, c_p],
     "showo_train_invalidate_weights": [c_p],

@@ -203,7 +203,7 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     rc |= t->alloc(&t->dOT, (int64_t)max_batch * H * t->Lp);
     rc |= t->alloc(&t->D, (int64_t)max_batch * nH * max_seq);
     rc |= t->alloc(&t->colpart, (Tp / 64 + 8) * bigrows);
-    rc |= t->alloc(&t->lnpart, (int64_t)showo_ln_bwd_blocks((int)T) * 2 * H);
+    rc |= t->alloc(&t->lnpart, (int64_t)showo_ln_bwd_blocks((int)T) * 3 * H);
     rc |= t->alloc(&t->qkpart, (int64_t)showo_qkln_rope_bwd_blocks((int)T, (int)nH) * 256);
     rc |= t->alloc(&t->rowloss, 2 * T);
     rc |= t->alloc((char**)&t->ce_rows, 12 * T);
@@ -412,6 +412,9 @@ extern "C" int showo_train_backward_head(showo_trainer* t, const int64_t* labels
     }
     TRY(showo_gemm_bf16(t->dlogits, Vp, t->wlmT, Vp, nullptr, 0, t->dh, H, nullptr, 0, T, H, Vp, SHOWO_EPI_F32, s));   // d hf
     SHOWO_CHECK_HIP(hipMemsetAsync(t->dy, 0, (size_t)T * H * sizeof(float), s));
+    if (train_tn() && e->nL > 0) {  // + column sums of dy16 = the dense / fc2 bias gradients of the top block
+        TRY(showo_ln_bwd_colsum(e->x, e->fln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, t->gfln, t->L[e->nL - 1].gb2, T, H, e->cfg.ln_eps, s));
+    } else
     TRY(showo_ln_bwd(e->x, e->fln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, t->gfln, T, H, e->cfg.ln_eps, s));
     return 0;
 }
@@ -424,13 +427,12 @@ extern "C" int showo_train_backward_layer(showo_trainer* t, int i, void* stream)
         LayerT& l = t->L[i];
         if (train_tn() && l.a) {
             // weight gradients straight from the token-major tensors: dW = dY^T X by showo_gemm_tn_bf16, db = column sums of dY
-            TRY(showo_colsum_bf16(t->dy16, H, T, H, t->colpart, l.gb2, 0, s));                                                  // db2 = dbd
+            // db2 = dbd = column sums of dy16: written into l.gb2 by the LayerNorm backward that produced dy16 (showo_ln_bwd_colsum)
             SHOWO_CHECK_HIP(hipMemcpyAsync(l.gbd, l.gb2, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
             TRY(showo_gemm_tn_bf16(t->dy16, H, l.a, F, l.gw2, F, H, F, T, 0, 1, s));                                               // dW2 [H,F]
             TRY(showo_gemm_tn_bf16(t->dy16, H, l.attn, H, l.gwd, H, H, H, T, 0, 1, s));                                            // dWd [H,H]
             TRY(showo_gemm_bf16(t->dy16, H, l.w2T, H, nullptr, 0, t->dff, F, nullptr, 0, T, F, H, SHOWO_EPI_BF16, s));          // d a
-            TRY(showo_dgelu_bf16(t->dff, l.f, t->dff, (int64_t)T * F, s));                                                      // d f
-            TRY(showo_colsum_bf16(t->dff, F, T, F, t->colpart, l.gb1, 0, s));                                                   // db1
+            TRY(showo_dgelu_colsum_bf16(t->dff, l.f, t->dff, F, T, F, t->colpart, l.gb1, s));                                   // d f, db1
             TRY(showo_gemm_tn_bf16(t->dff, F, l.h, H, l.gw1, H, F, H, T, 0, 1, s));                                                // dW1 [F,H]
             TRY(showo_gemm_bf16(t->dff, F, l.w1T, F, nullptr, 0, t->dh, H, nullptr, 0, T, H, F, SHOWO_EPI_F32, s));             // dh (mlp)
             // attention
@@ -472,6 +474,9 @@ extern "C" int showo_train_backward_layer(showo_trainer* t, int i, void* stream)
         TRY(showo_gemm_bf16(t->dqkv, 3 * H, l.wqkvT, 3 * H, nullptr, 0, t->dh, H, t->dh, H, T, H, 3 * H, SHOWO_EPI_RESID_F32, s));  // dh += attn part
         }
         // LayerNorm + residual
+        if (train_tn() && i > 0 && t->L[i - 1].a) {
+            TRY(showo_ln_bwd_colsum(l.x, w.ln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, l.gln, t->L[i - 1].gb2, T, H, e->cfg.ln_eps, s));
+        } else
         TRY(showo_ln_bwd(l.x, w.ln_w, t->dh, t->dy, t->dy, t->dy16, t->lnpart, l.gln, T, H, e->cfg.ln_eps, s));
         }
     return 0;

@@ -137,17 +137,21 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 //   dgamma / dbeta, written as part[blk][2][H].  dx goes to dx32 (may alias dy) and, rounded, to dx16 (GEMM operand).
 // ------------------------------------------------------------------------------------------------
 constexpr int LNB_ROWS = 32;
+// DXS: also the column sums of the ROUNDED dx (dx16) -> part2[blk][H]: dx is the output gradient of the block below, and the bias
+// gradients of its dense and fc2 are exactly these column sums (saves a pass over dx16)
+template <bool DXS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dh, const float* dy, float* dx32,
-                                                     bf16_t* __restrict__ dx16, float* __restrict__ part, int T, int H, float eps) {
+                                                     bf16_t* __restrict__ dx16, float* __restrict__ part, float* __restrict__ part2, int T,
+                                                     int H, float eps) {
     extern __shared__ float red[];  // [4][2][H] cross-wave reduction of the column partials
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = (H + 255) / 256;  // float4 groups per lane (H % 4 == 0; lanes past the row end idle)
-    float ag[8][4], ab[8][4];
+    float ag[8][4], ab[8][4], ad[DXS ? 8 : 1][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; if (DXS) ad[DXS ? i : 0][j] = 0.f; }
     const int r0 = blockIdx.x * LNB_ROWS;
     for (int rr = wave; rr < LNB_ROWS; rr += 4) {
         const int r = r0 + rr;
@@ -207,6 +211,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                     pk.x = pack_bf2(o.x, o.y);
                     pk.y = pack_bf2(o.z, o.w);
                     *reinterpret_cast<uint2*>(dx16 + (int64_t)r * H + c) = pk;
+                    if (DXS) {
+                        ad[DXS ? i : 0][0] += bf2f((bf16_t)(pk.x & 0xffffu)); ad[DXS ? i : 0][1] += bf2f((bf16_t)(pk.x >> 16));
+                        ad[DXS ? i : 0][2] += bf2f((bf16_t)(pk.y & 0xffffu)); ad[DXS ? i : 0][3] += bf2f((bf16_t)(pk.y >> 16));
+                    }
                 }
             }
     }
@@ -227,6 +235,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const float v = (red[(0 * 2 + which) * H + col] + red[(1 * 2 + which) * H + col]) +
                         (red[(2 * 2 + which) * H + col] + red[(3 * 2 + which) * H + col]);
         part[((int64_t)blockIdx.x * 2 + which) * H + col] = v;
+    }
+    if (DXS) {  // second use of the reduction buffer: the column sums of dx16
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nv && (i * 64 + lane) * 4 < H) {
+                const int c = (i * 64 + lane) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[wave * H + c + j] = ad[DXS ? i : 0][j];
+            }
+        __syncthreads();
+        for (int col = threadIdx.x; col < H; col += 256)
+            part2[(int64_t)blockIdx.x * H + col] = (red[col] + red[H + col]) + (red[2 * H + col] + red[3 * H + col]);
     }
 }
 
@@ -634,6 +655,38 @@ __global__ void dgelu_kernel(const bf16_t* __restrict__ da, const bf16_t* __rest
     }
 }
 
+// d_f = d_a * gelu_new'(f) on a [T, C] matrix (row stride ld) with the column sums of the ROUNDED result (the fc1 bias gradient) as
+// per-64-row partials: block (cb, rb) = rows 64 rb .. x columns 2048 cb ..; a thread owns 8 consecutive columns.  df may alias da.
+__global__ __launch_bounds__(256) void dgelu_colsum_kernel(const bf16_t* da, const bf16_t* __restrict__ f, bf16_t* df, float* __restrict__ part,
+                                                          int T, int C, int ld) {
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8, r0 = blockIdx.y * 64;
+    if (c0 >= C) return;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    const int rend = min(r0 + 64, T);
+#pragma unroll 4
+    for (int r = r0; r < rend; ++r) {
+        const int64_t o = (int64_t)r * ld + c0;
+        const uint4 ua = *reinterpret_cast<const uint4*>(da + o);
+        const uint4 ub = *reinterpret_cast<const uint4*>(f + o);
+        const bf16_t* ea = reinterpret_cast<const bf16_t*>(&ua);
+        const bf16_t* eb = reinterpret_cast<const bf16_t*>(&ub);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf2f(ea[j]) * gelu_new_grad(bf2f(eb[j]));
+        uint4 u;
+        u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(df + o) = u;
+        const bf16_t* eo = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += bf2f(eo[j]);
+    }
+    float* p = part + (int64_t)blockIdx.y * C + c0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = a[j];
+}
+
 }  // namespace
 
 extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int T, int C, int Tp, int mode, float* colpart,
@@ -662,22 +715,38 @@ extern "C" int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float*
     return 0;
 }
 
-extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16,
-                            float* part, float* dgb, int T, int H, float eps, void* stream) {
+static int ln_bwd_impl(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16, float* part,
+                       float* dgb, float* dxsum, int T, int H, float eps, void* stream) {
     if (T <= 0) return 0;
     if ((H % 4) || H > 2048) return set_error_msg(1, "ln_bwd: H must be a multiple of 4 and <= 2048");
+    if (dxsum && !dx16) return set_error_msg(1, "ln_bwd: the column sums are those of dx16");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (T + LNB_ROWS - 1) / LNB_ROWS;  // the partial buffer holds nblk + 8 rows (showo_ln_bwd_blocks)
     static bool attr_set = false;
     if (!attr_set) {
-        SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_set = true;
     }
-    ln_bwd_kernel<<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, T, H, eps);
+    float* part2 = part + (int64_t)(nblk + 8) * 2 * H;  // [nblk + 8][H] behind the [nblk + 8][2][H] region
+    if (dxsum) ln_bwd_kernel<true><<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, part2, T, H, eps);
+    else ln_bwd_kernel<false><<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, nullptr, T, H, eps);
     // part is [nblk][2][H]: reduce it as a [nblk, 2H] matrix -> dgb = (dgamma[H], dbeta[H])
     colsum_reduce(part, dgb, nblk, 2 * H, 0, s);
+    if (dxsum) colsum_reduce(part2, dxsum, nblk, H, 0, s);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
+}
+extern "C" int showo_ln_bwd(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16,
+                            float* part, float* dgb, int T, int H, float eps, void* stream) {
+    return ln_bwd_impl(x, gamma, dh, dy, dx32, dx16, part, dgb, nullptr, T, H, eps, stream);
+}
+// the same, plus dxsum[H] = column sums of dx16 (the bias gradients of the projections that consume dx as their dY); part: scratch
+// fp32 [showo_ln_bwd_blocks(T), 3, H]
+extern "C" int showo_ln_bwd_colsum(const float* x, const float* gamma, const float* dh, const float* dy, float* dx32, uint16_t* dx16,
+                                   float* part, float* dgb, float* dxsum, int T, int H, float eps, void* stream) {
+    if (!dxsum) return set_error_msg(1, "ln_bwd_colsum: dxsum required");
+    return ln_bwd_impl(x, gamma, dh, dy, dx32, dx16, part, dgb, dxsum, T, H, eps, stream);
 }
 extern "C" int showo_ln_bwd_blocks(int T) { return (T + LNB_ROWS - 1) / LNB_ROWS + 8; }  // + 8 rows of reduction scratch
 
@@ -819,6 +888,22 @@ extern "C" int showo_dgelu_bf16(const uint16_t* da, const uint16_t* f, uint16_t*
     int blocks = (int)((n / 8 + 255) / 256);
     if (blocks > 65536) blocks = 65536;
     dgelu_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(da, f, df, n);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// showo_dgelu_bf16 on a [T, C] matrix (row stride ld; C % 8 == 0, 16-byte aligned) fused with showo_colsum_bf16 of its result:
+// colsum[c] = sum_t df[t][c] (the fc1 bias gradient).  colpart: fp32 scratch of (ceil(T / 64) + 8) * C floats.  df may alias da.
+extern "C" int showo_dgelu_colsum_bf16(const uint16_t* da, const uint16_t* f, uint16_t* df, int ld, int T, int C, float* colpart,
+                                       float* colsum, void* stream) {
+    if (T <= 0 || C <= 0) return 0;
+    if (!da || !f || !df || !colpart || !colsum) return set_error_msg(1, "dgelu_colsum: null argument");
+    if ((C % 8) || (ld % 8) || ((((uintptr_t)da) | ((uintptr_t)f) | ((uintptr_t)df)) & 15))
+        return set_error_msg(1, "dgelu_colsum: C, ld multiples of 8 and 16-byte aligned tensors required");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (T + 63) / 64;
+    dgelu_colsum_kernel<<<dim3((C + 2047) / 2048, nblk), dim3(256), 0, s>>>(da, f, df, colpart, T, C, ld);
+    colsum_reduce(colpart, colsum, nblk, C, 0, s);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

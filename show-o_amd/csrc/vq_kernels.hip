@@ -47,11 +47,16 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
         o[1] = c;
     }
 }
-__global__ void gn_finalize_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
-    const int b = blockIdx.x, t = threadIdx.x;  // t = g*2 + which
+// stats[b][t] = sum_k part[b][k][t], t = g * 2 + which.  256 threads: four quarters of the k range (k = q, q + 4, ..) are summed in
+// parallel and combined in a fixed order ((q0 + q1) + (q2 + q3)): same bits on every run.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+    __shared__ double sq[4][GN_GROUPS * 2];
+    const int b = blockIdx.x, t = threadIdx.x & 63, q = threadIdx.x >> 6;
     double a = 0.0;
-    for (int k = 0; k < nblk; ++k) a += part[((int64_t)b * nblk + k) * (GN_GROUPS * 2) + t];
-    stats[(int64_t)b * GN_GROUPS * 2 + t] = a;
+    for (int k = q; k < nblk; k += 4) a += part[((int64_t)b * nblk + k) * (GN_GROUPS * 2) + t];
+    sq[q][t] = a;
+    __syncthreads();
+    if (q == 0) stats[(int64_t)b * GN_GROUPS * 2 + t] = (sq[0][t] + sq[1][t]) + (sq[2][t] + sq[3][t]);
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
@@ -161,7 +166,7 @@ extern "C" int showo_gn_stats_doubles(int B, int HW) {
 // stats[b][g][2] = sum over k < nblk of part[b][k][g][2], in k order
 extern "C" int showo_gn_finalize(const double* part, double* stats, int B, int nblk, void* stream) {
     if (B <= 0 || nblk <= 0) return 0;
-    gn_finalize_kernel<<<dim3(B), dim3(GN_GROUPS * 2), 0, (hipStream_t)stream>>>(part, stats, nblk);
+    gn_finalize_kernel<<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(part, stats, nblk);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -172,7 +177,7 @@ extern "C" int showo_gn_stats(const float* x, double* stats, int B, int HW, int 
     const int nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
     double* part = stats + (int64_t)B * GN_GROUPS * 2;  // per-block partials live behind the [B,32,2] result
     gn_partial_kernel<<<dim3(nblk, B), dim3(256), 0, (hipStream_t)stream>>>(x, part, HW, C);
-    gn_finalize_kernel<<<dim3(B), dim3(GN_GROUPS * 2), 0, (hipStream_t)stream>>>(part, stats, nblk);
+    gn_finalize_kernel<<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(part, stats, nblk);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -139,6 +139,15 @@ def test_layernorm_backward(T, H):
     assert torch.equal(from_bf16_bits(dx16).cpu(), bf16_round(dx32.cpu()))
     assert (dgb[0].cpu() - gamma.grad).abs().max() < 1e-4 * float(gamma.grad.abs().max()) + 1e-5
     assert (dgb[1].cpu() - beta.grad).abs().max() < 1e-4 * float(beta.grad.abs().max()) + 1e-5
+    # showo_ln_bwd_colsum: the same outputs, plus the column sums of dx16 (bias gradients of the projections below)
+    part3 = torch.zeros((nblk, 3, H), dtype=torch.float32, device="cuda")
+    dgb2, dxs = torch.zeros_like(dgb), torch.full((H,), float("nan"), dtype=torch.float32, device="cuda")
+    dx32b, dx16b = dev(dy.clone()), torch.zeros_like(dx16)
+    L().call("showo_ln_bwd_colsum", L().ptr(dev(x.detach())), L().ptr(dev(gamma.detach())), L().ptr(dev(dh)), L().ptr(dx32b), L().ptr(dx32b),
+             L().ptr(dx16b), L().ptr(part3), L().ptr(dgb2), L().ptr(dxs), T, H, 1e-5, S())
+    assert torch.equal(dx32b, dx32) and torch.equal(dx16b, dx16) and torch.equal(dgb2, dgb)
+    want = from_bf16_bits(dx16).cpu().double().sum(0)
+    assert (dxs.cpu().double() - want).abs().max() < 1e-5 * float(want.abs().max()) + 1e-5
 
 
 def test_qk_layernorm_rope_backward():
@@ -246,6 +255,19 @@ def test_dgelu():
     out = torch.zeros((64, 128), dtype=torch.int16, device="cuda")
     L().call("showo_dgelu_bf16", L().ptr(_bits(da)), L().ptr(_bits(f.detach())), L().ptr(out), 64 * 128, S())
     assert (from_bf16_bits(out).cpu() - f.grad).abs().max() < 2 ** -8 * float(f.grad.abs().max()) + 1e-6
+    # fused with the fc1 bias gradient (column sums of the rounded result), strided rows, in place
+    T, C, ld = 150, 136, 160
+    fb = bf16_round(torch.randn(T, ld) * 2)
+    dab = bf16_round(torch.randn(T, ld))
+    ref = torch.zeros((T, ld), dtype=torch.int16, device="cuda")
+    L().call("showo_dgelu_bf16", L().ptr(_bits(dab)), L().ptr(_bits(fb)), L().ptr(ref), T * ld, S())
+    buf = _bits(dab).clone()
+    part = torch.empty((((T + 63) // 64 + 8) * C,), dtype=torch.float32, device="cuda")
+    cs = torch.full((C,), float("nan"), dtype=torch.float32, device="cuda")
+    L().call("showo_dgelu_colsum_bf16", L().ptr(buf), L().ptr(_bits(fb)), L().ptr(buf), ld, T, C, L().ptr(part), L().ptr(cs), S())
+    assert torch.equal(buf[:, :C], ref[:, :C]) and torch.equal(buf[:, C:], _bits(dab)[:, C:])  # columns >= C untouched
+    want = from_bf16_bits(ref[:, :C]).cpu().double().sum(0)
+    assert (cs.cpu().double() - want).abs().max() < 1e-5 * float(want.abs().max()) + 1e-5
 
 
 def test_tiny_training_step_vs_reference_golden():
