@@ -1,7 +1,7 @@
 #!/bin/bash
 # local wrapper: make sure libshowo_hip.so and tools/gemm_bench match the sources, then hand the command to gpurun
 # usage: scripts/gpurun_built.sh <timeout_s> '<command>'
-set -e
+set -e -o pipefail
 cd "$(dirname "$0")/.."
 bash show-o_amd/csrc/build.sh | tail -1
 if [ ! -f tools/gemm_bench ] || [ tools/gemm_bench.cpp -nt tools/gemm_bench ] || [ show-o_amd/libshowo_hip.so -nt tools/gemm_bench ]; then

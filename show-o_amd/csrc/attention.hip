@@ -398,8 +398,8 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
             int key_ = (KT) + pik[i];                                                                  \
             key_ = key_ < a.Lk ? key_ : a.Lk - 1; /* clamped rows are masked out below */              \
-            glds16(Kg + (int64_t)key_ * 64 + kch[i], sK_ + (wave + 4 * i) * 512);                      \
-            glds16(Vg + voff[i] + (KT), sV_ + (wave + 4 * i) * 512);                                   \
+            glds16_untracked(Kg + (int64_t)key_ * 64 + kch[i], lds_addr_of(sK_ + (wave + 4 * i) * 512)); \
+            glds16_untracked(Vg + voff[i] + (KT), lds_addr_of(sV_ + (wave + 4 * i) * 512));            \
         }                                                                                              \
     }
 
@@ -411,12 +411,14 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     const int fsw = (qi >> 1) & 7;  // swizzle of the fragment rows qi and 32 + qi (same (r >> 1) & 7)
     const int kt0 = bmin >= 0x7fffffff ? 0 : (bmin & ~63);
     if (kt0 < bmax) AT_STAGE(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // everything loaded so far is retired HERE, with the registers named: a tracked load still pending at loop entry would make the
+    // compiler wait for it inside the loop -- with a vmcnt(0) that also drains the (untracked) prefetch DMAs of every iteration
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(lo1), "+v"(hi1), "+v"(lo2), "+v"(hi2)::"memory");
     __syncthreads();
     int buf = 0;
     for (int kt = kt0; kt < bmax; kt += 64, buf ^= 1) {
         const bool more = kt + 64 < bmax;
-        if (more) AT_STAGE(kt + 64, buf ^ 1);  // lands under this tile's MFMAs
+        if (more) AT_STAGE(kt + 64, buf ^ 1);  // lands under this tile's MFMAs (untracked DMA: no compiler wait in front of the reads)
         const bf16_t* sK = sm + buf * 2 * AT_TILE;
         const bf16_t* sV = sK + AT_TILE;
 #pragma unroll 1

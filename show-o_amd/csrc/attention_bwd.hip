@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdArgs a) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
             int key_ = (KT_) + pik[i];                                                                 \
             key_ = key_ < a.L ? key_ : a.L - 1;                                                        \
-            glds16(Kg + (int64_t)key_ * 64 + kch[i], s_ + (wave + 4 * i) * 512);                       \
-            glds16(Vg + (int64_t)key_ * a.ldv + kch[i], s_ + BT + (wave + 4 * i) * 512);               \
-            glds16(KTg + toff[i] + (KT_), s_ + 2 * BT + (wave + 4 * i) * 512);                         \
+            glds16_untracked(Kg + (int64_t)key_ * 64 + kch[i], lds_addr_of(s_ + (wave + 4 * i) * 512));           \
+            glds16_untracked(Vg + (int64_t)key_ * a.ldv + kch[i], lds_addr_of(s_ + BT + (wave + 4 * i) * 512));   \
+            glds16_untracked(KTg + toff[i] + (KT_), lds_addr_of(s_ + 2 * BT + (wave + 4 * i) * 512));             \
         }                                                                                              \
     } while (0)
 
@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdArgs a) {
     const int fsw = (qi >> 1) & 7;
     const int kt0 = bmin >= 0x7fffffff ? 0 : (bmin & ~63);
     if (kt0 < bmax) DQ_STAGE(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // retire every tracked load before the loop, registers named (see attention.hip: a pending one would put a vmcnt(0) inside the loop)
+    float lse_p = lse_l2, Dq_p = Dq;
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(dof[0]), "+v"(dof[1]), "+v"(dof[2]), "+v"(dof[3]), "+v"(lse_p),
+                   "+v"(Dq_p), "+v"(lo1), "+v"(hi1), "+v"(lo2), "+v"(hi2)::"memory");
     __syncthreads();
     int buf = 0;
     for (int kt = kt0; kt < bmax; kt += 64, buf ^= 1) {
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int key = ks + 16 * (r >> 3) + 8 * hh + (r & 7);
                 const bool vis = ((unsigned)(key - lo1) < len1) | ((unsigned)(key - lo2) < len2);
-                const float p = vis ? __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lse_l2)) : 0.f;
-                ds[r] = p * (dp[r] - Dq);
+                const float p = vis ? __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lse_p)) : 0.f;
+                ds[r] = p * (dp[r] - Dq_p);
             }
             bf16x8 db0 = pack8v(ds), db1 = pack8v(ds + 8);
 #pragma unroll
@@ -275,27 +279,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
         qch[i] = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
         toff[i] = (int64_t)r * a.Lp + qch[i];
     }
+    // The tile DMAs are untracked (common.h): nothing the compiler waits for may be in flight between their issue and the end-of-tile
+    // wait.  The per-query scalars of the NEXT tile (lse, D, intervals) are therefore loaded into registers up front (DKV_LOAD, ahead
+    // of the DMAs) and only stored to LDS at the end of the tile (DKV_STORE, next to the explicit wait).
+    float st_lse = 0.f, st_D = 0.f;
+    int4 st_iv = make_int4(0, 0, 0, 0);
+#define DKV_LOAD(QT_)                                                                                  \
+    if (tid < 64) {                                                                                    \
+        const int q_ = (QT_) + tid;                                                                    \
+        const bool ok_ = q_ < a.L;                                                                     \
+        const int qc_ = ok_ ? q_ : a.L - 1;                                                            \
+        st_lse = a.lse[bh * a.L + qc_] * LOG2E;                                                        \
+        st_D = ok_ ? a.D[bh * a.L + qc_] : 0.f;                                                        \
+        int l1_, h1_, l2_, h2_;                                                                        \
+        load_iv(a, b, qc_, l1_, h1_, l2_, h2_);                                                        \
+        if (!ok_) { l1_ = h1_ = l2_ = h2_ = 0; }                                                       \
+        st_iv = make_int4(l1_, h1_, l2_, h2_);                                                         \
+    }
+#define DKV_STORE(BUF)                                                                                 \
+    if (tid < 64) { s_lse[BUF][tid] = st_lse; s_D[BUF][tid] = st_D; s_iv[BUF][tid] = st_iv; }
 #define DKV_STAGE(QT_, BUF)                                                                            \
     do {                                                                                               \
         bf16_t* s_ = sm + (BUF) * 4 * BT;                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
             int q_ = (QT_) + piq[i];                                                                   \
             q_ = q_ < a.L ? q_ : a.L - 1;                                                              \
-            glds16(Qg + (int64_t)q_ * 64 + qch[i], s_ + (wave + 4 * i) * 512);                         \
-            glds16(dOg + (int64_t)q_ * a.lddo + qch[i], s_ + BT + (wave + 4 * i) * 512);               \
-            glds16(QTg + toff[i] + (QT_), s_ + 2 * BT + (wave + 4 * i) * 512);                         \
-            glds16(dOTg + toff[i] + (QT_), s_ + 3 * BT + (wave + 4 * i) * 512);                        \
-        }                                                                                              \
-        if (tid < 64) {                                                                                \
-            const int q_ = (QT_) + tid;                                                                \
-            const bool ok_ = q_ < a.L;                                                                 \
-            const int qc_ = ok_ ? q_ : a.L - 1;                                                        \
-            s_lse[BUF][tid] = a.lse[bh * a.L + qc_] * LOG2E;                                           \
-            s_D[BUF][tid] = ok_ ? a.D[bh * a.L + qc_] : 0.f;                                           \
-            int l1_, h1_, l2_, h2_;                                                                    \
-            load_iv(a, b, qc_, l1_, h1_, l2_, h2_);                                                    \
-            if (!ok_) { l1_ = h1_ = l2_ = h2_ = 0; }                                                   \
-            s_iv[BUF][tid] = make_int4(l1_, h1_, l2_, h2_);                                            \
+            glds16_untracked(Qg + (int64_t)q_ * 64 + qch[i], lds_addr_of(s_ + (wave + 4 * i) * 512));                 \
+            glds16_untracked(dOg + (int64_t)q_ * a.lddo + qch[i], lds_addr_of(s_ + BT + (wave + 4 * i) * 512));       \
+            glds16_untracked(QTg + toff[i] + (QT_), lds_addr_of(s_ + 2 * BT + (wave + 4 * i) * 512));                 \
+            glds16_untracked(dOTg + toff[i] + (QT_), lds_addr_of(s_ + 3 * BT + (wave + 4 * i) * 512));                \
         }                                                                                              \
     } while (0)
 
@@ -304,12 +316,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     for (int r = 0; r < 16; ++r) { dv0[r] = 0.f; dv1[r] = 0.f; dk0[r] = 0.f; dk1[r] = 0.f; }
     const int fsw = (ki >> 1) & 7;
     const int nqt = (a.L + 63) / 64;
+    DKV_LOAD(0)
     DKV_STAGE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DKV_STORE(0)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3])::"memory");
     __syncthreads();
     int buf = 0;
     for (int qt = 0; qt < nqt; ++qt, buf ^= 1) {
-        if (qt + 1 < nqt) DKV_STAGE((qt + 1) * 64, buf ^ 1);
+        const bool more = qt + 1 < nqt;
+        if (more) {
+            DKV_LOAD((qt + 1) * 64)
+            // the scalar loads above are the only tracked VMEM of the loop: retire them HERE, before the DMAs are issued, so that no
+            // compiler-placed wait (which would be a vmcnt(0): it does not count the DMAs) lands between the DMA issue and the tile
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(st_lse), "+v"(st_D), "+v"(st_iv.x), "+v"(st_iv.y), "+v"(st_iv.z), "+v"(st_iv.w)::"memory");
+            DKV_STAGE((qt + 1) * 64, buf ^ 1);
+        }
         const bf16_t* sQ = sm + buf * 4 * BT;
         const bf16_t* sdO = sQ + BT;
         const bf16_t* sQT = sQ + 2 * BT;
@@ -359,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
                 dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1, kk ? db1 : db0, dk1, 0, 0, 0);
             }
         }
+        if (more) { DKV_STORE(buf ^ 1) }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -379,6 +402,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
         *reinterpret_cast<uint2*>(kp + 32 + 8 * g) = w;
     }
 #undef DKV_STAGE
+#undef DKV_STORE
+#undef DKV_LOAD
 }
 
 }  // namespace

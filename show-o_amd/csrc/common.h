@@ -85,6 +85,19 @@ __device__ inline void glds16(const bf16_t* src, bf16_t* lds_dst_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
+// The same DMA issued from inline assembly: the compiler does not see an LDS write in flight.  With the builtin, its wait-count pass
+// puts `s_waitcnt vmcnt(0)` in front of the first LDS read that MAY alias a pending DMA destination -- always the case when the buffer
+// index is a run-time value (buf ^= 1 loops) or the read is ds_read_b64_tr_b16 -- which turns a prefetch into a blocking load.  The
+// caller orders the data itself: an explicit s_waitcnt vmcnt + barrier before the tile is read.  lds_wave_base: LDS BYTE address
+// (lds_addr_of), wave-uniform.  No other M0 user may live in a kernel that uses this (LDS instructions do not need M0 on gfx9+).
+__device__ inline uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+__device__ inline void glds16_untracked(const bf16_t* src, uint32_t lds_wave_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);  // the value is wave-uniform; this tells the compiler so
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+}
+
 // Philox4x32-10 counter RNG (Salmon et al. 2011) — the on-device noise source of the sampler.
 struct Philox {
     uint32_t k0, k1;
