@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 consolidated pass: full GPU suite, smoke, the bench lines (headline with train_step + cpu baselines, train, t2i512, mmu, vq,
 # batch 1), rocprofv3 kernel tables of the t2i / training / mmu benches, PMC traffic of the bench command
-TAG=${1:-r3g}
+TAG=${1:-r3k}
 R=$(pwd)
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/${TAG}_gpu_tests.log | tail -3
@@ -27,3 +27,8 @@ find gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_train gpurun_out/prof_${TAG}_mm
 head -8 gpurun_out/prof_$TAG/prof_kernel_stats.csv | cut -c1-170
 head -12 gpurun_out/prof_${TAG}_train/prof_kernel_stats.csv | cut -c1-170
 bash scripts/gpu_pmc3.sh $TAG 2>&1 | tail -3
+# same-box A/B of the training step: round-2 weight-gradient path (transposes + k-contiguous GEMM) and unfused GroupNorm statistics
+for cfg in "SHOWO_TRAIN_TN=1" "SHOWO_TRAIN_TN=0" "SHOWO_CONV_GN_FUSE=0"; do
+  env $cfg timeout 400 python bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train_ab.log 2>&1
+  echo "$cfg $(grep -h '"metric"' gpurun_out/${TAG}_train_ab.log | tail -1 | cut -c 75-130)" | tee -a gpurun_out/${TAG}_train_ab.txt
+done
