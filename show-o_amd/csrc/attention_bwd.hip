@@ -18,6 +18,7 @@
 #include "common.h"
 #include "../../include/showo_hip.h"
 #include "prof.h"
+#include <cstdlib>
 
 using namespace showo;
 
@@ -99,7 +100,28 @@ struct BwdArgs {
     const int32_t* iv;                    // [B,L,4] or NULL (causal)
     bf16_t *dQ, *dK, *dV; int ldq, ldk, ldvo;  // token-major outputs (row strides), head h at column h*64
     int B, nH, L, Lp;
+    int nxb;  // > 0: 1-D grid in the XCD-aware order of the forward kernel (bwd_block_coords), nxb = blocks per (batch, head); 0: 3-D grid
 };
+
+// Blocks of one (batch, head) stream the same Q / dO / K / V tiles.  Consecutive block ids land on different XCDs (id % 8), each with
+// its own L2, so the natural (x, head, batch) grid fetches every tile once per block.  As in attention.hip::attn_block_coords, 8 (batch,
+// head) pairs form a group of 8 * nxb ids in which pair j owns j, j + 8, j + 16, ..: same XCD, dispatched back to back.
+__device__ __forceinline__ void bwd_block_coords(const BwdArgs& a, int& xb, int& head, int& b) {
+    if (a.nxb == 0) { xb = blockIdx.x; head = blockIdx.y; b = blockIdx.z; return; }
+    const int lin = blockIdx.x, nbh = a.nH * a.B, per = 8 * a.nxb, full = nbh & ~7;
+    int bh;
+    if (lin < (full >> 3) * per) {
+        const int grp = lin / per, rem = lin - grp * per;
+        xb = rem >> 3;
+        bh = grp * 8 + (rem & 7);
+    } else {
+        const int t = lin - (full >> 3) * per, tail = nbh - full;
+        xb = t / tail;
+        bh = full + (t - xb * tail);
+    }
+    b = bh / a.nH;
+    head = bh - b * a.nH;
+}
 
 __device__ __forceinline__ void load_iv(const BwdArgs& a, int b, int q, int& lo1, int& hi1, int& lo2, int& hi2) {
     if (a.iv) {
@@ -115,9 +137,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 3 * BT];  // [buf][K rows(pi) | V rows(pi) | K^T]
     __shared__ int s_hull[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qblk = blockIdx.x * 4 + wave;
+    int xb_, head, b;
+    bwd_block_coords(a, xb_, head, b);
+    const int qblk = xb_ * 4 + wave;
     const bool wactive = qblk * 32 < a.L;
-    const int head = blockIdx.y, b = blockIdx.z;
     const int qi = lane & 31, hh = lane >> 5;
     const int qrow_raw = qblk * 32 + qi;
     const int qrow = qrow_raw < a.L ? qrow_raw : a.L - 1;
@@ -245,8 +268,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     __shared__ float s_lse[2][64], s_D[2][64];
     __shared__ int4 s_iv[2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kblk = blockIdx.x * 4 + wave;
-    const int head = blockIdx.y, b = blockIdx.z;
+    int xb_, head, b;
+    bwd_block_coords(a, xb_, head, b);
+    const int kblk = xb_ * 4 + wave;
     const int ki = lane & 31, hh = lane >> 5;
     const int key_raw = kblk * 32 + ki;
     const int key = key_raw < a.L ? key_raw : a.L - 1;
@@ -262,8 +286,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
             vf[m] = *reinterpret_cast<const bf16x8*>(Vp + 16 * m);
         }
     }
-    const int kb0 = blockIdx.x * 128;  // first key of the block (for the query-range bound of the causal case)
-    (void)kb0;
 
     const int prow = lane >> 3;
     const bf16_t* Qg = a.Q + bh * a.L * 64;
@@ -442,8 +464,17 @@ extern "C" int showo_attn_bwd(const uint16_t* Q, const uint16_t* K, const uint16
     a.B = B; a.nH = nH; a.L = L; a.Lp = Lp;
     ProfScope prof(PROF_ATTN, 10.0 * B * nH * (double)L * L * 64, s);  // 5 L x L x 64 products
     const int blocks = ((L + 31) / 32 + 3) / 4;
-    attn_bwd_dq_kernel<<<dim3(blocks, nH, B), dim3(256), 0, s>>>(a);
-    attn_bwd_dkv_kernel<<<dim3(blocks, nH, B), dim3(256), 0, s>>>(a);
+    static int xcd = -1;  // SHOWO_ATTN_XCD (default 1), shared with the forward kernel
+    if (xcd < 0) { const char* e = getenv("SHOWO_ATTN_XCD"); xcd = e ? atoi(e) : 1; }
+    if (xcd && (int64_t)blocks * nH * B < ((int64_t)1 << 31)) {
+        a.nxb = blocks;
+        attn_bwd_dq_kernel<<<dim3(blocks * nH * B), dim3(256), 0, s>>>(a);
+        attn_bwd_dkv_kernel<<<dim3(blocks * nH * B), dim3(256), 0, s>>>(a);
+    } else {
+        a.nxb = 0;
+        attn_bwd_dq_kernel<<<dim3(blocks, nH, B), dim3(256), 0, s>>>(a);
+        attn_bwd_dkv_kernel<<<dim3(blocks, nH, B), dim3(256), 0, s>>>(a);
+    }
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 //   dx = dy + LN'(x)^T dh.   One wave per row; a block walks LNB_ROWS rows and keeps per-lane column partials of
 //   dgamma / dbeta, written as part[blk][2][H].  dx goes to dx32 (may alias dy) and, rounded, to dx16 (GEMM operand).
 // ------------------------------------------------------------------------------------------------
-constexpr int LNB_ROWS = 32;
+constexpr int LNB_ROWS = 16;  // 702 blocks at the stage-1 batch: two resident blocks on every CU (32 rows left a third of the slots empty)
 // DXS: also the column sums of the ROUNDED dx (dx16) -> part2[blk][H]: dx is the output gradient of the block below, and the bias
 // gradients of its dense and fc2 are exactly these column sums (saves a pass over dx16)
 template <bool DXS>
