@@ -87,7 +87,7 @@ int showo_gemm_tune(int gn, int flags, unsigned long long* dbg);
 int showo_gemm_tn_bf16(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* out, int ldo, int M, int N, int T,
                        int accumulate, int rows_padded, void* stream);
 /* colsum[c] (+)= sum_t x[t][c], x bf16 [T, C] (row stride ld, 16-byte aligned, ld % 8 == 0); colpart: fp32 scratch of
- * (ceil(T / 64) + 8) * C floats.  Deterministic (per-64-row partials in row order, then a fixed two-level sum). */
+ * (ceil(T / 32) + 8) * C floats.  Deterministic (per-64-row partials in row order, then a fixed two-level sum). */
 int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float* colpart, float* colsum, int accumulate, void* stream);
 
 /* Launch counters of the production GEMM family (gemm2p / gemm3w): out3[0] = launches, out3[1] = of those the fused [Wqkv ; W1]

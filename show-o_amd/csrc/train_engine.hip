@@ -202,7 +202,7 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     rc |= t->alloc(&t->QT, (int64_t)max_batch * H * t->Lp); rc |= t->alloc(&t->KT, (int64_t)max_batch * H * t->Lp);
     rc |= t->alloc(&t->dOT, (int64_t)max_batch * H * t->Lp);
     rc |= t->alloc(&t->D, (int64_t)max_batch * nH * max_seq);
-    rc |= t->alloc(&t->colpart, (Tp / 64 + 8) * bigrows);
+    rc |= t->alloc(&t->colpart, (Tp / 32 + 8) * bigrows);  // showo_colsum_bf16 writes one partial row per 32 tokens
     rc |= t->alloc(&t->lnpart, (int64_t)showo_ln_bwd_blocks((int)T) * 3 * H);
     rc |= t->alloc(&t->qkpart, (int64_t)showo_qkln_rope_bwd_blocks((int)T, (int)nH) * 256);
     rc |= t->alloc(&t->rowloss, 2 * T);

@@ -18,7 +18,9 @@ __device__ __forceinline__ float gelu_new_f(float x) { return gelu_new_fast(x); 
 __device__ __forceinline__ float gelu_new_grad(float x) {
     const float c = 0.7978845608028654f;
     const float u = c * (x + 0.044715f * x * x * x);
-    const float t = tanhf(u);
+    // tanh(u) = 1 - 2 / (1 + e^(2u)) with the hardware exp / rcp (the forward's gelu_new_fast uses the same pair): ~1e-6 relative, far
+    // below the bf16 rounding of the product; libm's tanhf made the dgelu pass VALU-bound (132 us where its HBM floor is ~100)
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
@@ -103,15 +105,16 @@ static inline void colsum_reduce(const float* part, float* out, int nblk, int C,
 }
 
 // Column sums of a token-major bf16 matrix X [T, C] (row stride ld): the bias gradient of a Linear is the column sum of its dY.
-// Block (cb, rb) sums rows 64 rb .. 64 rb + 63 of columns 2048 cb ..; a thread owns 8 consecutive columns (one 16-byte load per row,
-// a row of the block is 4 KiB contiguous).  part[rb][c] partials in row order, reduced by colsum_reduce: no atomics.
+// Block (cb, rb) sums rows 32 rb .. 32 rb + 31 of columns 2048 cb ..; a thread owns 8 consecutive columns (one 16-byte load per row,
+// a row of the block is 4 KiB contiguous; 32 rows: ~8 resident blocks per CU at the [T, 3H] shape, 64 left it at 2 and 2.5 TB/s).
+// part[rb][c] partials in row order, reduced by colsum_reduce: no atomics.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int T, int C, int ld) {
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8, r0 = blockIdx.y * 64;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8, r0 = blockIdx.y * 32;
     if (c0 >= C) return;
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    const int rend = min(r0 + 64, T);
+    const int rend = min(r0 + 32, T);
     const bf16_t* p = x + (int64_t)r0 * ld + c0;
     const bool full = c0 + 8 <= C;
 #pragma unroll 8
@@ -702,13 +705,13 @@ extern "C" int showo_transpose_bf16(const uint16_t* x, int ld, uint16_t* xt, int
 }
 
 // colsum[c] (+)= sum_t x[t][c] of a token-major bf16 matrix (bias gradients next to showo_gemm_tn_bf16).  colpart: fp32 scratch of
-// (ceil(T / 64) + 8) * C floats.  Deterministic two-level sum.
+// (ceil(T / 32) + 8) * C floats.  Deterministic two-level sum.
 extern "C" int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float* colpart, float* colsum, int accumulate, void* stream) {
     if (T <= 0 || C <= 0) return 0;
     if (!x || !colpart || !colsum) return set_error_msg(1, "colsum: null argument");
     if ((ld % 8) || (((uintptr_t)x) & 15)) return set_error_msg(1, "colsum: x must be 16-byte aligned with ld a multiple of 8");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (T + 63) / 64;
+    const int nblk = (T + 31) / 32;
     colsum_bf16_kernel<<<dim3((C + 2047) / 2048, nblk), dim3(256), 0, s>>>(x, colpart, T, C, ld);
     colsum_reduce(colpart, colsum, nblk, C, accumulate, s);
     SHOWO_CHECK_HIP(hipGetLastError());

@@ -725,7 +725,7 @@ def test_gemm_tn_weight_gradient_on_token_major_operands(M, N, T, lda):
     L().call("showo_gemm_tn_bf16", L().ptr(Ab), lda, L().ptr(Bb), N, L().ptr(out2), N, M, N, T, 1, 0, S())  # accumulate
     assert float((out2.cpu().double() - 2 * ref).abs().max()) < 4e-5 * scale * max(1.0, (T / 512) ** 0.5)
     # bias gradient: column sums of the same dY
-    part = torch.empty((((T + 63) // 64 + 8) * M,), dtype=torch.float32, device="cuda")
+    part = torch.empty((((T + 31) // 32 + 8) * M,), dtype=torch.float32, device="cuda")
     cs = torch.full((M,), float("nan"), dtype=torch.float32, device="cuda")
     L().call("showo_colsum_bf16", L().ptr(Ab), lda, T, M, L().ptr(part), L().ptr(cs), 0, S())
     want = bf16_round(A[:, :M]).double().sum(0)
