@@ -26,7 +26,7 @@ cd $R
 find gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_train gpurun_out/prof_${TAG}_mmu -type f ! -name "*stats*" -size +2M -delete
 head -8 gpurun_out/prof_$TAG/prof_kernel_stats.csv | cut -c1-170
 head -12 gpurun_out/prof_${TAG}_train/prof_kernel_stats.csv | cut -c1-170
-bash scripts/gpu_pmc3.sh $TAG 2>&1 | tail -3
+if [ "${SKIP_PMC:-0}" != "1" ]; then bash scripts/gpu_pmc3.sh $TAG 2>&1 | tail -3; fi
 # same-box A/B of the training step: round-2 weight-gradient path (transposes + k-contiguous GEMM) and unfused GroupNorm statistics
 for cfg in "SHOWO_TRAIN_TN=1" "SHOWO_TRAIN_TN=0" "SHOWO_CONV_GN_FUSE=0"; do
   env $cfg timeout 400 python bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_train_ab.log 2>&1

@@ -4,6 +4,7 @@
 // models/modeling_showo.py:80-98) and torch.optim.AdamW.step (training/train.py:225-231, 617).
 // All reductions are fixed-order (per-block partials + a finalize pass): the same inputs give the same bits.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/showo_hip.h"
 
 using namespace showo;
@@ -90,18 +91,22 @@ __global__ __launch_bounds__(256) void colsum_subset_kernel(const float* __restr
     __syncthreads();
     if (w == 0 && c < C) sub8[(int64_t)j * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
-__global__ void colsum_combine_kernel(const float* __restrict__ sub8, float* __restrict__ out, int C, int accumulate) {
+__global__ void colsum_combine_kernel(const float* __restrict__ sub8, float* __restrict__ out, float* __restrict__ out2, int C1, int C,
+                                      int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float s = ((sub8[c] + sub8[(int64_t)C + c]) + (sub8[2 * (int64_t)C + c] + sub8[3 * (int64_t)C + c])) +
                     ((sub8[4 * (int64_t)C + c] + sub8[5 * (int64_t)C + c]) + (sub8[6 * (int64_t)C + c] + sub8[7 * (int64_t)C + c]));
-    out[c] = accumulate ? out[c] + s : s;
+    float* o = c < C1 ? out + c : out2 + (c - C1);
+    *o = accumulate ? *o + s : s;
 }
-// part: [nblk][C] partials followed by 8*C floats of scratch
-static inline void colsum_reduce(const float* part, float* out, int nblk, int C, int accumulate, hipStream_t s) {
+// part: [nblk][C] partials followed by 8*C floats of scratch.  Columns >= C1 go to out2[c - C1] when out2 is given (two destinations
+// from one partial buffer: the LayerNorm backward).  (A one-launch form -- 64 columns per 512-thread block, eight waves over the
+// partial rows -- measured 1.5-3 ms per training step SLOWER than these two launches: C / 64 blocks leave most CUs idle.)
+static inline void colsum_reduce(const float* part, float* out, int nblk, int C, int accumulate, hipStream_t s, float* out2 = nullptr, int C1 = 0) {
     float* sub8 = const_cast<float*>(part) + (int64_t)nblk * C;
     colsum_subset_kernel<<<dim3((C + 63) / 64, 8), dim3(256), 0, s>>>(part, sub8, nblk, C);
-    colsum_combine_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sub8, out, C, accumulate);
+    colsum_combine_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sub8, out, out2, out2 ? C1 : C, C, accumulate);
 }
 
 // Column sums of a token-major bf16 matrix X [T, C] (row stride ld): the bias gradient of a Linear is the column sum of its dY.
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const int which = c / H, col = c - which * H;
         const float v = (red[(0 * 2 + which) * H + col] + red[(1 * 2 + which) * H + col]) +
                         (red[(2 * 2 + which) * H + col] + red[(3 * 2 + which) * H + col]);
-        part[((int64_t)blockIdx.x * 2 + which) * H + col] = v;
+        part[((int64_t)blockIdx.x * (DXS ? 3 : 2) + which) * H + col] = v;
     }
     if (DXS) {  // second use of the reduction buffer: the column sums of dx16
         __syncthreads();
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             }
         __syncthreads();
         for (int col = threadIdx.x; col < H; col += 256)
-            part2[(int64_t)blockIdx.x * H + col] = (red[col] + red[H + col]) + (red[2 * H + col] + red[3 * H + col]);
+            part2[(int64_t)blockIdx.x * 3 * H + col] = (red[col] + red[H + col]) + (red[2 * H + col] + red[3 * H + col]);
     }
 }
 
@@ -731,12 +736,15 @@ static int ln_bwd_impl(const float* x, const float* gamma, const float* dh, cons
         SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_set = true;
     }
-    float* part2 = part + (int64_t)(nblk + 8) * 2 * H;  // [nblk + 8][H] behind the [nblk + 8][2][H] region
-    if (dxsum) ln_bwd_kernel<true><<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, part2, T, H, eps);
-    else ln_bwd_kernel<false><<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, nullptr, T, H, eps);
-    // part is [nblk][2][H]: reduce it as a [nblk, 2H] matrix -> dgb = (dgamma[H], dbeta[H])
-    colsum_reduce(part, dgb, nblk, 2 * H, 0, s);
-    if (dxsum) colsum_reduce(part2, dxsum, nblk, H, 0, s);
+    if (dxsum) {
+        // part is [nblk][3][H] (dgamma | dbeta | column sums of dx16): ONE reduce, columns < 2H -> dgb, the rest -> dxsum
+        ln_bwd_kernel<true><<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, part + 2 * H, T, H, eps);
+        colsum_reduce(part, dgb, nblk, 3 * H, 0, s, dxsum, 2 * H);
+    } else {
+        // part is [nblk][2][H]: reduce it as a [nblk, 2H] matrix -> dgb = (dgamma[H], dbeta[H])
+        ln_bwd_kernel<false><<<dim3(nblk), dim3(256), (size_t)8 * H * sizeof(float), s>>>(x, gamma, dh, dy, dx32, dx16, part, nullptr, T, H, eps);
+        colsum_reduce(part, dgb, nblk, 2 * H, 0, s);
+    }
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
