@@ -65,7 +65,7 @@ struct showo_trainer {
     bool adam_dirty = true;
     // head
     float *logits = nullptr, *gembed = nullptr, *gfln = nullptr, *gwlm = nullptr, *gblm = nullptr;
-    bf16_t *dlogits = nullptr, *bigT = nullptr;  // bigT: [max(Vp, F), Tp] transposed image of the dY side
+    bf16_t *dlogits = nullptr, *bigT = nullptr;  // bigT: [max(Vp, F, 3H), Tp] transposed image of the dY side (SHOWO_TRAIN_TN=0 only)
     // backward scratch
     float *dy = nullptr, *dh = nullptr, *colpart = nullptr, *lnpart = nullptr, *qkpart = nullptr, *D = nullptr, *rowloss = nullptr;
     bf16_t *dy16 = nullptr, *d_o = nullptr, *dff = nullptr, *dqk = nullptr, *dqkv = nullptr, *xT = nullptr, *QT = nullptr, *KT = nullptr, *dOT = nullptr;
@@ -195,8 +195,10 @@ extern "C" int showo_train_create(showo_engine* e, int max_batch, int max_seq, s
     // bigT holds the transposed dY side of every wgrad GEMM: dlogits^T [Vp, Tp], df^T [F, Tp], dqkv^T [3H, Tp] -- the tallest wins
     // (round 3: sizing it by max(Vp, F) alone overflowed for geometries with 3H > max(Vp, F), found by the SMALL training fixture)
     const int64_t bigrows = std::max<int64_t>(std::max<int64_t>(Vp, F), 3 * H);
-    rc |= t->alloc(&t->bigT, bigrows * Tp);
-    rc |= t->alloc(&t->xT, std::max<int64_t>(F, H) * Tp);
+    if (!train_tn()) {  // the transposed operand images exist only on the transpose + NT path (1.5 GB at the stage-1 geometry)
+        rc |= t->alloc(&t->bigT, bigrows * Tp);
+        rc |= t->alloc(&t->xT, std::max<int64_t>(F, H) * Tp);
+    }
     rc |= t->alloc(&t->dy, T * H); rc |= t->alloc(&t->dh, T * H); rc |= t->alloc(&t->dy16, Tp * H); rc |= t->alloc(&t->d_o, T * H);
     rc |= t->alloc(&t->dff, Tp * F); rc |= t->alloc(&t->dqk, T * 2 * H); rc |= t->alloc(&t->dqkv, Tp * 3 * H);
     rc |= t->alloc(&t->QT, (int64_t)max_batch * H * t->Lp); rc |= t->alloc(&t->KT, (int64_t)max_batch * H * t->Lp);
