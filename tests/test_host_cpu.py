@@ -555,3 +555,16 @@ def test_measurement_tools_parse_their_inputs(tmp_path):
     g = t["gemm2p_kernel"]  # both kernels of the family, launch-weighted; fetch = 2 x KiB x 1024, write = KiB x 1024
     assert g["launches"] == 2 and abs(g["fetch_bytes_per_launch"] - 2 * 1024 * 2000.0) < 1e-6 and abs(g["write_bytes_per_launch"] - 1024 * 200.0) < 1e-6
     assert abs(t["attn_fwd_lds_kernel"]["bytes_per_launch"] - (2 * 1024 * 500.0 + 1024 * 50.0)) < 1e-6
+
+
+def test_build_script_compiles_every_kernel_file():
+    """a new .hip file that is not in build.sh's list would link an old library silently (the GPU box runs what was built here)"""
+    import glob
+    import re
+    csrc = os.path.join(util.ROOT, "show-o_amd", "csrc")
+    sh = open(os.path.join(csrc, "build.sh")).read()
+    m = re.search(r"for f in ([^;]+); do", sh)
+    assert m, "build.sh: file list not found"
+    listed = set(m.group(1).split())
+    present = {os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(csrc, "*.hip"))}
+    assert present == listed, (sorted(present - listed), sorted(listed - present))
