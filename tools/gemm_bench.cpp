@@ -34,6 +34,45 @@ __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed, float scale) {
     }
 }
 
+// LDS read-rate probe (mode 6): cycles per wave-instruction of ds_read_b128 vs ds_read_b64_tr_b16 at the conflict-free layouts the
+// GEMMs use, with NW waves of one block issuing them back to back (16 reads in flight, then s_waitcnt): what one wave / one CU sustains.
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 probe_bf16x4;
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(512) void lds_probe_kernel(unsigned long long* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(sm)[i] = i * 2654435761u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    unsigned acc = 0;
+    // MODE 0: b128, row fr of a 16-row fragment (128-B rows), chunk fg ^ (fr & 7): gemm2p's read
+    const unsigned a0 = wave * 4096 + fr * 128 + ((fg ^ (fr & 7)) << 4);
+    // MODE 1: transposing read, gemm_tn's addressing (piece = 1 KiB: 8 rows x 128 B)
+    const int swz = (((fr >> 3) & 1) << 1) | ((fg & 1) << 2);
+    const unsigned a1 = wave * 4096 + fg * 1024 + (fr >> 2) * 128 + (fr & 1) * 8 + (((0 + ((fr >> 1) & 1)) ^ swz) << 4);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        unsigned b0 = a0, b1 = a1;
+        asm volatile("" : "+v"(b0), "+v"(b1));  // the addresses are opaque per iteration: no hoisting of the reads
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                probe_f4 v = *reinterpret_cast<const probe_f4*>(sm + ((b0 + k * 2048) & 65535));
+                acc += __float_as_uint(v[0]) ^ __float_as_uint(v[3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                probe_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) probe_bf16x4*)(sm + ((b1 + (k & 1) * 512 + (k >> 1) * 4096) & 65535)));
+                acc += (unsigned)__builtin_bit_cast(unsigned long long, v);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) { out[wave * 2] = t1 - t0; out[wave * 2 + 1] = acc; }
+}
+
 struct Shape { int M, N, K, epi; const char* name; };
 
 int main(int argc, char** argv) {
@@ -83,6 +122,23 @@ int main(int argc, char** argv) {
     }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (quick == 6) {  // LDS read-rate probe
+        unsigned long long* d; CK(hipMalloc(&d, 64 * 8));
+        const int iters = 4096;
+        for (int mode = 0; mode < 2; ++mode)
+            for (int nw : {1, 4, 8}) {
+                CK(hipMemset(d, 0, 64 * 8));
+                if (mode == 0) lds_probe_kernel<0><<<1, nw * 64, 65536, st>>>(d, iters);
+                else lds_probe_kernel<1><<<1, nw * 64, 65536, st>>>(d, iters);
+                CK(hipStreamSynchronize(st));
+                unsigned long long h[16]; CK(hipMemcpy(h, d, 16 * 8, hipMemcpyDeviceToHost));
+                unsigned long long mx = 0; for (int w = 0; w < nw; ++w) mx = std::max(mx, h[2 * w]);
+                const double per = (double)mx / (iters * 16.0);
+                printf("%-22s %d wave(s): %.1f cycles per wave-instruction (counter units), %.1f B per counter cycle per CU\n",
+                       mode == 0 ? "ds_read_b128" : "ds_read_b64_tr_b16", nw, per, nw * (mode == 0 ? 1024.0 : 512.0) / per);
+            }
+        return 0;
+    }
     if (quick == 5) {  // weight-gradient shapes: showo_gemm_tn_bf16 on token-major operands vs two transposes + the k-contiguous GEMM
         struct TS { int M, N, T; const char* name; };
         const TS ts[] = {{256, 256, 200, "edge 1 tile"}, {264, 520, 1000, "edge ragged"}, {512, 768, 2100, "split-K"}, {2048, 8192, 11223, "dW2"},
