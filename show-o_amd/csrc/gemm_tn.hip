@@ -374,7 +374,11 @@ extern "C" int showo_gemm_tn_bf16(const uint16_t* A, int lda, const uint16_t* B,
     g.A = A; g.lda = lda; g.W = B; g.ldw = ldb; g.Wlo = nullptr; g.bias = nullptr; g.bias_per_row = 0;
     g.out = out; g.ldo = ldo; g.resid = accumulate ? out : nullptr; g.ldr = ldo;
     g.M = M; g.N = N; g.K = ((T + GEMM_BK - 1) / GEMM_BK) * GEMM_BK; g.Klim = T;
-    g.gn = g_gemm_gn > 0 ? g_gemm_gn : 4; g.flags = rows_padded ? 1 : 0; g.dbg = nullptr;
+    // tile-group width (n-panels per XCD group): 8 measured best on the weight-gradient shapes (back-to-back launches, same box:
+    // gn 4 / 8 / 32 = 1 157 / 1 195 / 1 134 TF/s on dW2, 1 136 / 1 167 / 1 186 on dW1, 986 / 1 007 / 1 039 on dWqkv); SHOWO_GEMM_TN_GN overrides
+    static int tn_gn = 0;
+    if (!tn_gn) { const char* e = getenv("SHOWO_GEMM_TN_GN"); tn_gn = (e && atoi(e) > 0) ? atoi(e) : 8; }
+    g.gn = tn_gn; g.flags = rows_padded ? 1 : 0; g.dbg = nullptr;
     g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & 15) == 0);
     ProfScope prof(PROF_GEMM, 2.0 * M * N * T, (hipStream_t)stream);
     if (accumulate) return launch_tn<SHOWO_EPI_RESID_F32>(g, (hipStream_t)stream);
