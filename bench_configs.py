@@ -154,12 +154,18 @@ def mmu(a):
     t_tok = max(1e-9, (td - tf) / (NEW - 1))
     bytes_per_token = 2.0 * (24 * (4 * 2048 * 2048 + 2 * 2048 * 8192) + 58498 * 2048)  # bf16 weights streamed once per token
     ach = bytes_per_token / t_tok / 1e9
-    copy_peak = None
-    try:
-        import os
-        copy_peak = 1e3 * json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_ceiling.json")))["measured_peak"]["hbm_TBps_copy"]
-    except (OSError, KeyError, TypeError, ValueError):
-        pass
+    # the copy ceiling of THIS box in THIS run (no stale file)
+    L = showo_amd._lib
+    src, dst = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"), torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    L.call("showo_copy_b128", L.ptr(src), L.ptr(dst), src.numel(), L.stream())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        L.call("showo_copy_b128", L.ptr(src), L.ptr(dst), src.numel(), L.stream())
+    e1.record()
+    torch.cuda.synchronize()
+    copy_peak = 2 * src.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
     return {"metric": "mmu AR decode tokens/sec (w_clip_vit, 631-embedding prompt, 100 new tokens, batch 1)", "value": NEW / td, "unit": "tokens/s",
             "n_gpus": 1, "steps": n_img, "warmup": a.warmup, "ms_per_step": td * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -242,6 +248,43 @@ def vq(a):
                          "unit": "GB/s", "frac": dom["GBps"] / 8000.0, "traffic": None,
                          "frac_of_copy_ceiling": dom["GBps"] / copy},
             "cpu_baseline": None}
+
+
+def vq_hbm_quick(L):
+    """the default bench line's `vq_hbm` field (north_star: "achieved HBM GB/s on the VQ/argmin path" in a DRIVER-run record): the LFQ
+    sign-pack / unpack and the GroupNorm + swish apply pass at bandwidth-deciding sizes, about 100 ms in total.  Algorithmic bytes
+    (each tensor once) / launch time from HIP events on the launch stream."""
+    s = L.stream
+
+    def timed(fn, reps=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    B, Cz, hw = 16, 13, 131072
+    z = torch.randn(B, Cz, hw, device="cuda")
+    ids = torch.empty(B, hw, dtype=torch.int64, device="cuda")
+    by = B * hw * (Cz * 4 + 8)
+    t_pack = timed(lambda: L.call("showo_lfq_pack_nchw", L.ptr(z), L.ptr(ids), B, Cz, hw, s()))
+    zq = torch.empty_like(z)
+    t_unpack = timed(lambda: L.call("showo_lfq_unpack_nchw", L.ptr(ids), L.ptr(zq), B, Cz, hw, s()))
+    assert torch.equal(zq > 0, z > 0)
+    del z, zq, ids
+    Bn, HW, Cc = 8, 65536, 128
+    x = torch.randn(Bn, HW, Cc, device="cuda")
+    stats = torch.empty(L.load().showo_gn_stats_doubles(Bn, HW), dtype=torch.float64, device="cuda")
+    gam, bet = torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda")
+    y, ylo = torch.empty(Bn, HW, Cc, dtype=torch.int16, device="cuda"), torch.empty(Bn, HW, Cc, dtype=torch.int16, device="cuda")
+    t_stats = timed(lambda: L.call("showo_gn_stats", L.ptr(x), L.ptr(stats), Bn, HW, Cc, s()))
+    t_apply = timed(lambda: L.call("showo_gn_apply", L.ptr(x), L.ptr(stats), L.ptr(gam), L.ptr(bet), L.ptr(y), L.ptr(ylo), Bn, HW, Cc, 1e-6, 1, s()))
+    return {"lfq_pack_GBps": by / t_pack / 1e9, "lfq_unpack_GBps": by / t_unpack / 1e9, "gn_stats_GBps": x.numel() * 4 / t_stats / 1e9,
+            "gn_apply_GBps": x.numel() * 8 / t_apply / 1e9, "peak_GBps": 8000.0,
+            "sizes": "LFQ: 16 x 131 072 tokens x 13 fp32 channels (60 B per token); GroupNorm + swish -> (hi, lo) bf16 on [8, 65 536, 128] fp32 (8 B per element)"}
 
 
 def main(argv):

@@ -86,6 +86,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (A/B of their overhead)")
     ap.add_argument("--event-stride", type=int, default=5)
+    ap.add_argument("--roofline-steps", type=int, default=1, help="steps of the separate HIP-event leg after the timed region that feeds `roofline` (0: skip)")
     ap.add_argument("--wire", default="bf16", help="gradient wire of the data-parallel exchange: bf16 (default) | fp32")
     a = ap.parse_args(argv)
     import bench
@@ -153,8 +154,7 @@ def main(argv=None):
     for _ in range(a.warmup):
         losses = step()
     L.call("showo_prof_reset")
-    L.call("showo_prof_set_stride", a.event_stride)  # per-launch events on a systematic sample of the launches
-    L.call("showo_prof_enable", 0 if a.no_events else 1)
+    L.call("showo_prof_enable", 0)  # the timed region carries NO per-launch events: they run in a second leg below
     if trainer.exchange is not None:
         trainer.exchange.measure(True)
     barrier()
@@ -163,7 +163,17 @@ def main(argv=None):
         losses = step()
     barrier()
     dt = time.perf_counter() - t0
-    L.call("showo_prof_enable", 0)
+    exposed_ms = trainer.exchange.exposed_ms() if trainer.exchange is not None else None  # of the timed steps only
+    if trainer.exchange is not None:
+        trainer.exchange.measure(False)
+    # ---- roofline leg, after the timed region: the same steps with every n-th launch of each kernel kind bracketed by HIP events
+    if not a.no_events and a.roofline_steps > 0:
+        L.call("showo_prof_set_stride", a.event_stride)  # per-launch events on a systematic sample of the launches
+        L.call("showo_prof_enable", 1)
+        for _ in range(a.roofline_steps):
+            step()
+        barrier()
+        L.call("showo_prof_enable", 0)
     prof = {}
     for kind, name in ((0, "gemm"), (1, "attention_fwd"), (2, "vq_conv")):
         ms_k, n_k, fl_k = C.c_double(), C.c_int64(), C.c_double()
@@ -176,19 +186,20 @@ def main(argv=None):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    exposed_ms = trainer.exchange.exposed_ms() if trainer.exchange is not None else None
     wire_bytes = trainer.exchange.wire_bytes() if trainer.exchange is not None else None
     if rank == 0:
         T = (bt + bl + bm) * 387
         ms = dt / a.steps * 1e3
         flop = 3 * T * 2.732e9 + (0 if vq is None else (bt + bm) * 0.355e12)  # 3 x 11 223 x F(387) + encoder
         gm = prof["gemm"]
+        n_evt_steps = 0 if a.no_events else a.roofline_steps
         ach = gm["flop_timed"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM: forward, dgrad and wgrad projections + lm_head, every epilogue)",
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                     "launches": gm["launches"], "timed_launches": gm["timed"], "avg_launch_ms": gm["ms"] / max(1, gm["timed"]),
-                    "executed_tflop_per_step": gm["flop"] / a.steps / 1e12,
-                    "time_share_of_step": (gm["flop"] / max(1e-9, ach * 1e12)) / dt if ach > 0 else None,
+                    "executed_tflop_per_step": gm["flop"] / max(1, n_evt_steps) / 1e12,
+                    "time_share_of_step": (gm["flop"] / max(1, n_evt_steps) / max(1e-9, ach * 1e12)) / (dt / a.steps) if ach > 0 else None,
+                    "measured_in": f"{n_evt_steps} extra step(s) with HIP events after the timed region",
                     "attention_fwd": {"achieved": prof["attention_fwd"]["flop_timed"] / max(1e-9, prof["attention_fwd"]["ms"] * 1e-3) / 1e12},
                     "vq_conv": {"achieved": prof["vq_conv"]["flop_timed"] / max(1e-9, prof["vq_conv"]["ms"] * 1e-3) / 1e12}}
         cpu = None

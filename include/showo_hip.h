@@ -544,6 +544,12 @@ int showo_clip_load(showo_clip* c, const char* key, const float* src, int64_t n,
 int showo_clip_missing(const showo_clip* c);
 /* images fp32 [B,3,S,S] (normalised) -> features fp32 [B, (S/patch)^2, hidden] */
 int showo_clip_features(showo_clip* c, const float* images, int B, float* features, void* stream);
+/* 0 (default): bf16 GEMM / attention operands.  1: accuracy mode -- every GEMM on the split-bf16 MFMA kernel (hi + lo operand pairs),
+ * LayerNorm / attention / quick_gelu in fp32: the fp32 tower of transformers' CLIPVisionModel (models/clip_encoder.py:29-49 runs it in
+ * the model's dtype) to ~1e-4.  The low halves of the weights are kept from every showo_clip_load; the fp32 workspace is allocated
+ * by the first call with precision 1. */
+int showo_clip_set_precision(showo_clip* c, int precision);
+int showo_clip_get_precision(const showo_clip* c);
 /* mm_projector: Linear(in,out) -> exact GELU -> Linear(out,out).  Keys "0.weight", "0.bias", "2.weight", "2.bias" (optionally
  * prefixed "mm_projector."); x fp32 [T,in] -> out fp32 [T,out], T <= max_rows. */
 typedef struct showo_projector showo_projector;
@@ -551,6 +557,8 @@ int showo_projector_create(int in_dim, int out_dim, int max_rows, showo_projecto
 void showo_projector_destroy(showo_projector* p);
 int showo_projector_load(showo_projector* p, const char* key, const float* src, int64_t n, void* stream);
 int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream);
+/* 0: bf16 operands (default, also what showo_projector_backward differentiates); 1: split-bf16 GEMMs + fp32 exact GELU (inference) */
+int showo_projector_set_precision(showo_projector* p, int precision);
 /* backward of the LAST showo_projector_forward (same T rows): dout fp32 [T,out] -> gw0 fp32 [out,in], gb0 [out], gw1 [out,out],
  * gb1 [out], dx fp32 [T,in] (optional).  Autograd of nn.Sequential(Linear, GELU(), Linear) (training/train_w_clip_vit.py trains it). */
 int showo_projector_backward(showo_projector* p, const float* dout, int T, float* dx, float* gw0, float* gb0, float* gw1, float* gb1,

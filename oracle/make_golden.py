@@ -669,9 +669,129 @@ def make_small_train():
     print("  rows", ids_all.shape[0] * L, "losses", out["losses"], "tensors", len(out))
 
 
+def make_full_cfg3():
+    """BASELINE cfg3 at MODEL SCALE (configs/showo_demo_512x512.yaml: 1 024 image tokens, batch 4, CFG-doubled -> [8,1155], centred
+    16x16-token inpainting hole, inference_t2i.py:100-113): the REAL reference's logits on one mask-predict forward
+    (models/modeling_showo.py:104-181 calls self(...) on exactly this tensor), a rows x cols subset -> tests/golden/showo_full_cfg3.npz.
+    Weights = make_showo_state(seed 0) as in showo_full_logits_subset.npz (num_vq_tokens does not enter the state dict)."""
+    print("[full-size showo, cfg3: [8,1155] inpainting batch]  (needs ~30 GB RAM, several minutes)")
+    d = Wt.ShowoDims(num_vq_tokens=1024)
+    sd_np = Wt.make_showo_state(d, seed=0)
+    ref = ref_showo_from_state(d, sd_np)
+    P = R.load_reference().prompting
+    rs = np.random.RandomState(23)
+    B, N = 4, d.num_vq_tokens
+    grid = np.zeros((32, 32), dtype=bool)
+    grid[8:24, 8:24] = True
+    hole = grid.reshape(-1)
+    codes = rs.randint(0, d.codebook, size=(B, N)) + d.image_offset
+    img = np.where(hole[None], d.mask_token_id, codes)
+    ids_c = t2i_ids(d, [3 + 7 * i for i in range(B)], rs, bos=50256, image_tokens=img.tolist())
+    ids_u = t2i_ids(d, [3] * B, rs, bos=50256, image_tokens=img.tolist())
+    ids = torch.cat([ids_c, ids_u])
+    assert tuple(ids.shape) == (8, 1155)
+    mask = P.create_attention_mask_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id, rm_pad_in_image=True)
+    with torch.no_grad():
+        lg = ref(ids, attention_mask=mask)
+    del ref
+    # rows: pads, text, <soi>, kept tokens, hole tokens (the rows t2i_generate samples from), <eoi>
+    T0 = 130
+    rows = np.array([0, 64, 122, 127, 128, 129, T0, T0 + 31, T0 + 8 * 32 + 7, T0 + 8 * 32 + 8, T0 + 12 * 32 + 16, T0 + 23 * 32 + 23,
+                     T0 + 23 * 32 + 24, T0 + 1023, 1154])
+    cols = np.concatenate([np.arange(0, d.vocab, 29), np.arange(d.image_offset, d.image_offset + 128)])
+    sub = lg[:, rows][:, :, cols].numpy()
+    sd = O.to_torch(sd_np)
+    o = O.showo_logits(sd, d, ids, attention_mask=mask)
+    assert report("full cfg3 logits", o, lg) < 2e-3
+    np.savez_compressed(os.path.join(GOLD, "showo_full_cfg3.npz"), seed=0, ids=ids.numpy().astype(np.int32), rows=rows, cols=cols,
+                        logits=sub, hole=hole, logit_absmax=float(lg.abs().max()), logit_std=float(lg.std()))
+
+
+def make_full_cfg4():
+    """BASELINE cfg4 at MODEL SCALE (inference_mmu.py:100-150, w_clip_vit): 631 prompt embeddings = [<mmu>, 28 system ids, <soi>] +
+    mm_projector(576 CLIP patch features) + [<eoi>, 24 question ids], the reference's create_attention_mask_for_mmu_vit
+    (training/prompting_utils.py:606-624) and its own `mmu_generate` (models/modeling_showo.py:183-240: no KV cache, whole sequence
+    re-run per token) for 8 greedy tokens.  Recorded: the tokens, every step's last-row logits (column subset + top-2 gap), and a
+    rows x cols subset of the PREFILL logits -> tests/golden/showo_full_cfg4.npz.  The CLIP features are regenerated from their seed
+    by the test (RandomState(41).standard_normal((1, 576, 1024))); the tower itself is pinned by clip_vision.npz."""
+    print("[full-size showo, cfg4: 631-embedding mmu_vit prefill + 8 greedy tokens]  (several minutes)")
+    d = Wt.ShowoDims(w_clip_vit=True)
+    sd_np = Wt.make_showo_state(d, seed=0)
+    ref = ref_showo_from_state(d, sd_np)
+    P = R.load_reference().prompting
+    rs = np.random.RandomState(41)
+    feats = torch.from_numpy(rs.standard_normal((1, 576, 1024)).astype(np.float32))
+    sys_ids = rs.randint(0, 50256, size=28).tolist()
+    q_ids = rs.randint(0, 50256, size=24).tolist()
+    ids_llava = torch.tensor([[d.mmu_id] + sys_ids + [d.soi_id, d.eoi_id] + q_ids], dtype=torch.long)
+    NEW = 8
+    rec = []
+    with torch.no_grad():
+        img_emb = ref.mm_projector(feats)
+        txt = ref.showo.model.embed_tokens(ids_llava)
+        emb = torch.cat([txt[:, :30], img_emb, txt[:, 30:]], dim=1)
+        assert emb.shape[1] == 631
+        am = P.create_attention_mask_for_mmu_vit(emb, system_prompt_len=28)
+        orig_forward = ref.forward
+
+        def rec_forward(*a, **kw):
+            out = orig_forward(*a, **kw)
+            rec.append(out.detach().clone())
+            return out
+        ref.forward = rec_forward
+        toks = ref.mmu_generate(input_embeddings=emb, attention_mask=am[0].unsqueeze(0), max_new_tokens=NEW, top_k=1)
+        ref.forward = orig_forward
+    toks = np.array([int(t) for t in toks])
+    assert len(rec) == NEW and rec[0].shape[1] == 631
+    cols = np.concatenate([np.arange(0, d.vocab, 29), np.arange(d.image_offset, d.image_offset + 64)])
+    last = np.stack([r[0, -1].numpy() for r in rec])  # [NEW, V]: the logits each token was drawn from
+    srt = np.sort(last, axis=1)
+    gap = srt[:, -1] - srt[:, -2]
+    assert np.array_equal(last.argmax(1), toks)
+    rows = np.array([0, 1, 15, 28, 29, 30, 31, 300, 605, 606, 607, 620, 630])
+    pre = rec[0][0][rows][:, cols].numpy()
+    print("  tokens", toks.tolist(), "top-2 gaps", np.round(gap, 4).tolist(), "logit std", float(rec[0].std()))
+    sd = O.to_torch(sd_np)
+    o_emb = torch.cat([txt[:, :30], O.mm_projector({k[len("mm_projector."):]: v for k, v in sd.items() if k.startswith("mm_projector.")},
+                                                    feats), txt[:, 30:]], dim=1)
+    report("oracle mm_projector splice", o_emb, emb)
+    o = O.showo_logits(sd, d, None, input_embeddings=o_emb, attention_mask=am)
+    assert report("full cfg4 prefill logits", o, rec[0]) < 2e-3
+    np.savez_compressed(os.path.join(GOLD, "showo_full_cfg4.npz"), seed=0, feat_seed=41, ids_llava=ids_llava.numpy().astype(np.int32),
+                        tokens=toks, cols=cols, last_logits=last[:, cols], last_top2_gap=gap.astype(np.float32),
+                        last_absmax=np.abs(last).max(1).astype(np.float32), rows=rows, prefill_logits=pre,
+                        logit_absmax=float(rec[0].abs().max()), logit_std=float(rec[0].std()),
+                        emb_absmax=float(emb.abs().max()), img_emb_rows=img_emb[0, ::64].numpy())
+
+
+def make_magvit_512():
+    """512x512 VQ fixture (BASELINE cfg3 / cfg4 encode and decode at this size: 1 024 tokens, 32x32 latent): the REFERENCE MAGVITv2
+    (models/modeling_magvitv2.py:416-433) on one image -> all 1 024 ids, the full latent, every 8th pixel of decode_code(ids) and one
+    dense 64x64 crop -> tests/golden/magvit_512.npz.  Input regenerated by the test from RandomState(33)."""
+    print("[magvit 512x512]")
+    sd_np = Wt.make_magvit_state(seed=21)
+    ref = R.build_reference_magvit()
+    ref.load_state_dict(O.to_torch(sd_np), strict=True)
+    x = torch.from_numpy(np.random.RandomState(33).uniform(-1, 1, size=(1, 3, 512, 512)).astype(np.float32))
+    with torch.no_grad():
+        z = ref.encoder(x)
+        ids = ref.get_code(x)
+        img = ref.decode_code(ids)
+    assert tuple(ids.shape) == (1, 1024) and tuple(img.shape) == (1, 3, 512, 512)
+    sd = O.to_torch(sd_np)
+    o_ids, o_z = O.magvit_get_code(sd, x, return_z=True)
+    report("encoder z @512", o_z, z)
+    assert torch.equal(o_ids, ids)
+    assert report("decode_code @512", O.magvit_decode_code(sd, ids), img) < 1e-3
+    np.savez_compressed(os.path.join(GOLD, "magvit_512.npz"), seed=21, x_seed=33, z=z.numpy(), ids=ids.numpy(),
+                        image_s8=img[:, :, ::8, ::8].contiguous().numpy(), image_crop=img[:, :, 224:288, 192:256].contiguous().numpy(),
+                        image_absmax=float(img.abs().max()), image_rms=float(img.pow(2).mean().sqrt()),
+                        z_absmin=float(z.abs().min()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--full", action="store_true", help="also make the full-size (1.45B) logits fixture")
+    ap.add_argument("--full", action="store_true", help="also make the model-scale fixtures (1.45B logits [2,387], cfg3 [8,1155], cfg4 631-embedding decode, MAGVIT 512x512)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -696,4 +816,10 @@ if __name__ == "__main__":
         make_small_train()
     if a.full or a.only == "full":
         make_full_showo()
+    if a.full or a.only == "magvit512":
+        make_magvit_512()
+    if a.full or a.only == "full_cfg3":
+        make_full_cfg3()
+    if a.full or a.only == "full_cfg4":
+        make_full_cfg4()
     print("done")

@@ -162,6 +162,17 @@ class CLIPVisionTower(nn.Module):
         if self._clip is not None:
             self._versions = {}
 
+    def set_precision(self, precision):
+        """0 (default): bf16 GEMM / attention operands with fp32 accumulation.  1: accuracy mode -- split-bf16 (hi + lo) MFMA GEMMs,
+        fp32 LayerNorm / attention / quick_gelu (csrc/clip_engine.hip, csrc/precise.hip): the fp32 tower the reference runs
+        (models/clip_encoder.py:29-49) to ~1e-4.  Inference only; returns self."""
+        if int(precision) not in (0, 1):
+            raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
+        self._precision = int(precision)
+        if self._clip is not None:
+            _lib.call("showo_clip_set_precision", self._clip, self._precision)
+        return self
+
     def engine(self, batch=1):
         _lib.require_gpu()
         lib = _lib.load()
@@ -181,6 +192,7 @@ class CLIPVisionTower(nn.Module):
             h = C.c_void_p()
             _lib.check(lib.showo_clip_create(C.byref(cfg), C.byref(h)), "showo_clip_create")
             self._clip, self._versions = h, {}
+            _lib.call("showo_clip_set_precision", self._clip, int(getattr(self, "_precision", 0)))
         for k, v in self.vision_tower.state_dict().items():
             ver = (v.data_ptr(), v._version)
             if self._versions.get(k) != ver:

@@ -4,7 +4,9 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libshowo_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-result -Wno-unused-value"
+# -Wno-inline-asm: the LDS-DMA helpers (common.h glds16_untracked, gemm_tn.hip glds16_sa) list "m0" as clobbered so that the compiler
+# never assumes M0 survives them; the backend notes for every inlined copy that m0 is a reserved register (a remark, not a defect)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
 OBJS=""
 PIDS=""
 mkdir -p _build

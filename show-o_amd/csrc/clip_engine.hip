@@ -19,6 +19,13 @@
 
 using namespace showo;
 
+namespace showo {  // csrc/precise.hip: the fp32-class building blocks of the accuracy mode (shared with the Phi engine)
+int precise_ln_split(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* hi, bf16_t* lo, int rows, int H,
+                     float eps, hipStream_t s);
+int precise_attention(const float* Q, const float* K, const float* V, const int32_t* iv, const int32_t* flag, const float* dense, float* O,
+                      int B, int nH, int Lq, int Lk, int Lcap, int ldo, hipStream_t s);
+}
+
 namespace {
 
 #define TRY(expr)            \
@@ -29,7 +36,8 @@ namespace {
 
 // pixel_values fp32 [B,3,S,S] -> bf16 patch rows [B*P, Kp]; column k = c*ps*ps + dy*ps + dx (the flattening of the conv weight
 // [hidden,3,ps,ps]); columns >= 3*ps*ps are zero
-__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int S, int ps, int G, int Kp, int64_t total) {
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo, int S, int ps, int G,
+                                int Kp, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int k = (int)(i % Kp);
@@ -43,7 +51,9 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
         const int y = (p / G) * ps + dy, x = (p % G) * ps + dx;
         v = img[((b * 3 + c) * S + y) * S + x];
     }
-    out[i] = f2bf(v);
+    const bf16_t h = f2bf(v);
+    out[i] = h;
+    if (out_lo) out_lo[i] = f2bf(v - bf2f(h));
 }
 
 // x[b,0,:] = cls + pos[0];  x[b,1+p,:] = patch[b*P+p,:] + pos[1+p]      (CLIPVisionEmbeddings.forward)
@@ -88,6 +98,35 @@ __global__ void act_kernel(const float* __restrict__ f, bf16_t* __restrict__ a, 
         a[i] = f2bf(y);
     }
 }
+// accuracy mode: the same activations with IEEE expf, output as a (hi, lo) bf16 pair
+template <int MODE>
+__global__ void act_split_kernel(const float* __restrict__ f, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = f[i];
+        float y;
+        if (MODE == 0) y = v / (1.0f + expf(-1.702f * v));
+        else y = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        const bf16_t h = f2bf(y);
+        hi[i] = h;
+        lo[i] = f2bf(y - bf2f(h));
+    }
+}
+// accuracy mode: qkv fp32 [T, 3 nH 64] -> Q, K, V fp32 [B, nH, L, 64] (CLIPAttention: no q/k norm, no rotary; the 1/8 scale is applied
+// by the attention kernel).  One thread per element.
+__global__ void qkv_heads_f32_kernel(const float* __restrict__ qkv, float* __restrict__ Q, float* __restrict__ K, float* __restrict__ V, int L,
+                                     int nH, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int Hq = nH * 64;
+    const int c = (int)(i % (3 * Hq));
+    const int64_t t = i / (3 * Hq);
+    const int which = c / Hq, head = (c % Hq) / 64, d = c % 64;
+    const int64_t b = t / L, l = t % L;
+    float* dst = which == 0 ? Q : (which == 1 ? K : V);
+    dst[((b * nH + head) * L + l) * 64 + d] = qkv[i];
+}
 
 __global__ void fill_full_intervals_kernel(int32_t* iv, int L, int rows) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,6 +135,7 @@ __global__ void fill_full_intervals_kernel(int32_t* iv, int L, int rows) {
 
 struct ClipLayer {
     bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    bf16_t *wqkv_lo = nullptr, *wo_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;  // low halves (accuracy mode)
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
 };
@@ -110,7 +150,11 @@ struct showo_clip {
     std::vector<void*> allocs;
     std::set<std::string> loaded;
     int expected = 0;
-    bf16_t* wpatch = nullptr;
+    bf16_t *wpatch = nullptr, *wpatch_lo = nullptr;
+    int precision = 0;
+    // accuracy-mode workspace (allocated by the first showo_clip_set_precision(c, 1))
+    bf16_t *patches_lo = nullptr, *h_lo = nullptr, *act_lo = nullptr;
+    float *p_qkv = nullptr, *p_Q = nullptr, *p_K = nullptr, *p_V = nullptr, *p_a = nullptr;
     float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
     std::vector<ClipLayer> layers;
     // workspace
@@ -149,12 +193,13 @@ extern "C" int showo_clip_create(const showo_clip_config* cf, showo_clip** out) 
     const int64_t H = c->H, F = c->F, B = cf->max_batch, T = B * c->L;
     const int Lp = ((c->L + 63) / 64) * 64;
     int rc = 0;
-    rc |= c->alloc(&c->wpatch, H * c->Kp); rc |= c->alloc(&c->cls, H); rc |= c->alloc(&c->pos, c->L * H);
+    rc |= c->alloc(&c->wpatch, H * c->Kp); rc |= c->alloc(&c->wpatch_lo, H * c->Kp); rc |= c->alloc(&c->cls, H); rc |= c->alloc(&c->pos, c->L * H);
     rc |= c->alloc(&c->pre_w, H); rc |= c->alloc(&c->pre_b, H);
     c->layers.resize(c->nRun);
     for (auto& l : c->layers) {
         rc |= c->alloc(&l.wqkv, 3 * H * H); rc |= c->alloc(&l.bqkv, 3 * H); rc |= c->alloc(&l.wo, H * H); rc |= c->alloc(&l.bo, H);
         rc |= c->alloc(&l.w1, F * H); rc |= c->alloc(&l.b1, F); rc |= c->alloc(&l.w2, H * F); rc |= c->alloc(&l.b2, H);
+        rc |= c->alloc(&l.wqkv_lo, 3 * H * H); rc |= c->alloc(&l.wo_lo, H * H); rc |= c->alloc(&l.w1_lo, F * H); rc |= c->alloc(&l.w2_lo, H * F);
         rc |= c->alloc(&l.ln1_w, H); rc |= c->alloc(&l.ln1_b, H); rc |= c->alloc(&l.ln2_w, H); rc |= c->alloc(&l.ln2_b, H);
     }
     rc |= c->alloc(&c->patches, B * c->P * c->Kp); rc |= c->alloc(&c->pout, B * c->P * H);
@@ -165,6 +210,7 @@ extern "C" int showo_clip_create(const showo_clip_config* cf, showo_clip** out) 
     if (rc) { showo_clip_destroy(c); return rc; }
     hipMemset(c->Vt, 0, (size_t)B * H * Lp * sizeof(bf16_t));
     hipMemset(c->wpatch, 0, (size_t)H * c->Kp * sizeof(bf16_t));
+    hipMemset(c->wpatch_lo, 0, (size_t)H * c->Kp * sizeof(bf16_t));
     c->expected = 5 + c->nRun * 16;
     *out = c;
     return 0;
@@ -178,15 +224,19 @@ int copy_f32(float* dst, const float* src, int64_t n, int64_t expect, hipStream_
     SHOWO_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
-int cast_w(bf16_t* dst, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+// bf16 image + its low half (w = hi + lo to 2^-17): the hi half is the round-to-nearest cast the bf16 path has always used
+int split_w(bf16_t* dst, bf16_t* dst_lo, const float* src, int64_t n, int64_t expect, hipStream_t s) {
     if (n != expect) return set_error_msg(2, "clip_load: element count mismatch");
-    return showo_cast_f32_bf16(src, dst, n, s);
+    return showo_split_f32_bf16(src, dst, dst_lo, n, s);
 }
 // conv weight fp32 [H, 3*ps*ps] -> bf16 [H, Kp] (row stride Kp, pad columns stay zero)
-__global__ void pad_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int K, int Kp, int64_t total) {
+__global__ void pad_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, bf16_t* __restrict__ dst_lo, int K, int Kp,
+                                int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    dst[(i / K) * Kp + (i % K)] = f2bf(src[i]);
+    const bf16_t h = f2bf(src[i]);
+    dst[(i / K) * Kp + (i % K)] = h;
+    dst_lo[(i / K) * Kp + (i % K)] = f2bf(src[i] - bf2f(h));
 }
 }  // namespace
 
@@ -208,7 +258,7 @@ extern "C" int showo_clip_load(showo_clip* c, const char* key, const float* src,
     const int K = 3 * c->cfg.patch_size * c->cfg.patch_size;
     if (k == "vision_model.embeddings.patch_embedding.weight") {
         if (n != H * K) return set_error_msg(2, "clip_load: element count mismatch");
-        pad_rows_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(src, c->wpatch, K, c->Kp, n);
+        pad_rows_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(src, c->wpatch, c->wpatch_lo, K, c->Kp, n);
         rc = 0;
     } else if (k == "vision_model.embeddings.class_embedding") rc = copy_f32(c->cls, src, n, H, s);
     else if (k == "vision_model.embeddings.position_embedding.weight") rc = copy_f32(c->pos, src, n, (int64_t)c->L * H, s);
@@ -220,27 +270,45 @@ extern "C" int showo_clip_load(showo_clip* c, const char* key, const float* src,
         if (li >= c->nRun) return 0;
         ClipLayer& l = c->layers[li];
         std::string t(sub);
-        if (t == "self_attn.q_proj.weight") rc = cast_w(l.wqkv, src, n, H * H, s);
-        else if (t == "self_attn.k_proj.weight") rc = cast_w(l.wqkv + H * H, src, n, H * H, s);
-        else if (t == "self_attn.v_proj.weight") rc = cast_w(l.wqkv + 2 * H * H, src, n, H * H, s);
+        if (t == "self_attn.q_proj.weight") rc = split_w(l.wqkv, l.wqkv_lo, src, n, H * H, s);
+        else if (t == "self_attn.k_proj.weight") rc = split_w(l.wqkv + H * H, l.wqkv_lo + H * H, src, n, H * H, s);
+        else if (t == "self_attn.v_proj.weight") rc = split_w(l.wqkv + 2 * H * H, l.wqkv_lo + 2 * H * H, src, n, H * H, s);
         else if (t == "self_attn.q_proj.bias") rc = copy_f32(l.bqkv, src, n, H, s);
         else if (t == "self_attn.k_proj.bias") rc = copy_f32(l.bqkv + H, src, n, H, s);
         else if (t == "self_attn.v_proj.bias") rc = copy_f32(l.bqkv + 2 * H, src, n, H, s);
-        else if (t == "self_attn.out_proj.weight") rc = cast_w(l.wo, src, n, H * H, s);
+        else if (t == "self_attn.out_proj.weight") rc = split_w(l.wo, l.wo_lo, src, n, H * H, s);
         else if (t == "self_attn.out_proj.bias") rc = copy_f32(l.bo, src, n, H, s);
         else if (t == "layer_norm1.weight") rc = copy_f32(l.ln1_w, src, n, H, s);
         else if (t == "layer_norm1.bias") rc = copy_f32(l.ln1_b, src, n, H, s);
         else if (t == "layer_norm2.weight") rc = copy_f32(l.ln2_w, src, n, H, s);
         else if (t == "layer_norm2.bias") rc = copy_f32(l.ln2_b, src, n, H, s);
-        else if (t == "mlp.fc1.weight") rc = cast_w(l.w1, src, n, F * H, s);
+        else if (t == "mlp.fc1.weight") rc = split_w(l.w1, l.w1_lo, src, n, F * H, s);
         else if (t == "mlp.fc1.bias") rc = copy_f32(l.b1, src, n, F, s);
-        else if (t == "mlp.fc2.weight") rc = cast_w(l.w2, src, n, H * F, s);
+        else if (t == "mlp.fc2.weight") rc = split_w(l.w2, l.w2_lo, src, n, H * F, s);
         else if (t == "mlp.fc2.bias") rc = copy_f32(l.b2, src, n, H, s);
     }
     if (rc == -1) return set_error_msg(3, "clip_load: unknown state-dict key");
     if (rc == 0) c->loaded.insert(k);
     return rc;
 }
+
+// 0: bf16 GEMM / attention operands (the timed default).  1: accuracy mode -- split-bf16 GEMMs, fp32 LayerNorm / attention / quick_gelu;
+// the low halves of the weights are kept from every load, the fp32 workspace is allocated on first use.
+extern "C" int showo_clip_set_precision(showo_clip* c, int precision) {
+    if (!c) return set_error_msg(1, "clip_set_precision: null handle");
+    if (precision != 0 && precision != 1) return set_error_msg(1, "clip_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class)");
+    if (precision == 1 && !c->p_qkv) {
+        const int64_t H = c->H, F = c->F, T = (int64_t)c->cfg.max_batch * c->L;
+        int rc = 0;
+        rc |= c->alloc(&c->patches_lo, (int64_t)c->cfg.max_batch * c->P * c->Kp); rc |= c->alloc(&c->h_lo, T * H);
+        rc |= c->alloc(&c->act_lo, T * F); rc |= c->alloc(&c->p_qkv, T * 3 * H); rc |= c->alloc(&c->p_Q, T * H);
+        rc |= c->alloc(&c->p_K, T * H); rc |= c->alloc(&c->p_V, T * H); rc |= c->alloc(&c->p_a, T * H);
+        if (rc) { c->p_qkv = nullptr; return rc; }
+    }
+    c->precision = precision;
+    return 0;
+}
+extern "C" int showo_clip_get_precision(const showo_clip* c) { return c ? c->precision : -1; }
 
 // images fp32 [B,3,S,S] (already normalised by the image processor) -> features fp32 [B, P, hidden] =
 // CLIPVisionModel(images, output_hidden_states=True).hidden_states[run_layers][:, 1:]   (clip_encoder.py:29-37, 40-49)
@@ -254,14 +322,36 @@ extern "C" int showo_clip_features(showo_clip* c, const float* images, int B, fl
     const float eps = c->cfg.ln_eps;
     {   // patch embedding: im2col (bf16) + GEMM, then class token / position embeddings, then pre-LayerNorm (fp32 in place)
         const int64_t n = (int64_t)B * P * c->Kp;
-        patchify_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(images, c->patches, S, c->cfg.patch_size, c->G, c->Kp, n);
-        TRY(showo_gemm_bf16(c->patches, c->Kp, c->wpatch, c->Kp, nullptr, 0, c->pout, H, nullptr, 0, B * P, H, c->Kp, SHOWO_EPI_F32, s));
+        const bool precise = c->precision == 1;
+        patchify_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(images, c->patches, precise ? c->patches_lo : nullptr, S, c->cfg.patch_size,
+                                                                c->G, c->Kp, n);
+        if (precise)
+            TRY(showo_gemm_bf16x3(c->patches, c->patches_lo, c->Kp, c->wpatch, c->wpatch_lo, c->Kp, nullptr, 0, c->pout, H, nullptr, 0, B * P, H,
+                                  c->Kp, s));
+        else
+            TRY(showo_gemm_bf16(c->patches, c->Kp, c->wpatch, c->Kp, nullptr, 0, c->pout, H, nullptr, 0, B * P, H, c->Kp, SHOWO_EPI_F32, s));
         const int64_t m = (int64_t)T * H;
         assemble_kernel<<<dim3(launch1d(m)), dim3(256), 0, s>>>(c->pout, c->cls, c->pos, c->x, L, H, m);
         ln_f32_kernel<<<dim3((T + 3) / 4), dim3(256), 0, s>>>(c->x, c->pre_w, c->pre_b, T, H, eps);
         fill_full_intervals_kernel<<<dim3(launch1d(T)), dim3(256), 0, s>>>(c->iv, L, T);
     }
-    for (int li = 0; li < c->nRun; ++li) {
+    for (int li = 0; li < c->nRun && c->precision == 1; ++li) {
+        // accuracy mode: split-bf16 (hi + lo) MFMA GEMMs, fp32 LayerNorm / attention / quick_gelu -- the same recipe as the Phi engine's
+        // precision 1 (csrc/precise.hip); transformers' CLIPEncoderLayer order (modeling_clip.py, pinned 4.41.1)
+        ClipLayer& l = c->layers[li];
+        TRY(showo::precise_ln_split(c->x, l.ln1_w, l.ln1_b, nullptr, c->h, c->h_lo, T, H, eps, s));
+        TRY(showo_gemm_bf16x3(c->h, c->h_lo, H, l.wqkv, l.wqkv_lo, H, l.bqkv, 0, c->p_qkv, 3 * H, nullptr, 0, T, 3 * H, H, s));
+        const int64_t nq = (int64_t)T * 3 * H;
+        qkv_heads_f32_kernel<<<dim3(launch1d(nq)), dim3(256), 0, s>>>(c->p_qkv, c->p_Q, c->p_K, c->p_V, L, nH, nq);
+        TRY(showo::precise_attention(c->p_Q, c->p_K, c->p_V, c->iv, nullptr, nullptr, c->p_a, B, nH, L, L, L, H, s));
+        TRY(showo_split_f32_bf16(c->p_a, c->attn, c->act_lo, (int64_t)T * H, s));
+        TRY(showo_gemm_bf16x3(c->attn, c->act_lo, H, l.wo, l.wo_lo, H, l.bo, 0, c->x, H, c->x, H, T, H, H, s));
+        TRY(showo::precise_ln_split(c->x, l.ln2_w, l.ln2_b, nullptr, c->h, c->h_lo, T, H, eps, s));
+        TRY(showo_gemm_bf16x3(c->h, c->h_lo, H, l.w1, l.w1_lo, H, l.b1, 0, c->f, F, nullptr, 0, T, F, H, s));
+        act_split_kernel<0><<<dim3(2048), dim3(256), 0, s>>>(c->f, c->act, c->act_lo, (int64_t)T * F);
+        TRY(showo_gemm_bf16x3(c->act, c->act_lo, F, l.w2, l.w2_lo, F, l.b2, 0, c->x, H, c->x, H, T, H, F, s));
+    }
+    for (int li = 0; li < c->nRun && c->precision == 0; ++li) {
         ClipLayer& l = c->layers[li];
         TRY(showo_layernorm_f32_bf16(c->x, l.ln1_w, l.ln1_b, c->h, nullptr, T, H, eps, s));
         TRY(showo_gemm_bf16(c->h, H, l.wqkv, H, l.bqkv, 0, c->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
@@ -287,6 +377,8 @@ extern "C" int showo_clip_features(showo_clip* c, const float* images, int B, fl
 struct showo_projector {
     int in_dim, out_dim, max_rows;
     bf16_t *w0 = nullptr, *w1 = nullptr, *xb = nullptr, *act = nullptr;
+    bf16_t *w0_lo = nullptr, *w1_lo = nullptr, *xb_lo = nullptr, *act_lo = nullptr;  // low halves (accuracy mode)
+    int precision = 0;
     float *b0 = nullptr, *b1 = nullptr, *f = nullptr;
     std::set<std::string> loaded;
     // backward workspace (allocated by the first showo_projector_backward): transposed weight images, bf16 gradients, transposes
@@ -298,6 +390,8 @@ struct showo_projector {
 
 extern "C" void showo_projector_destroy(showo_projector* p) {
     if (!p) return;
+    for (void* q : {(void*)p->w0_lo, (void*)p->w1_lo, (void*)p->xb_lo, (void*)p->act_lo})
+        if (q) hipFree(q);
     for (void* q : {(void*)p->w0, (void*)p->w1, (void*)p->xb, (void*)p->act, (void*)p->b0, (void*)p->b1, (void*)p->f, (void*)p->w0T,
                     (void*)p->w1T, (void*)p->dout16, (void*)p->dact16, (void*)p->df16, (void*)p->tA, (void*)p->tB, (void*)p->dx16,
                     (void*)p->colpart})
@@ -312,6 +406,8 @@ extern "C" int showo_projector_create(int in_dim, int out_dim, int max_rows, sho
     p->in_dim = in_dim; p->out_dim = out_dim; p->max_rows = max_rows;
     const int64_t I = in_dim, D = out_dim, T = max_rows;
     bool ok = hipMalloc((void**)&p->w0, D * I * 2) == hipSuccess && hipMalloc((void**)&p->w1, D * D * 2) == hipSuccess &&
+              hipMalloc((void**)&p->w0_lo, D * I * 2) == hipSuccess && hipMalloc((void**)&p->w1_lo, D * D * 2) == hipSuccess &&
+              hipMalloc((void**)&p->xb_lo, T * I * 2) == hipSuccess && hipMalloc((void**)&p->act_lo, T * D * 2) == hipSuccess &&
               hipMalloc((void**)&p->b0, D * 4) == hipSuccess && hipMalloc((void**)&p->b1, D * 4) == hipSuccess &&
               hipMalloc((void**)&p->xb, T * I * 2) == hipSuccess && hipMalloc((void**)&p->f, T * D * 4) == hipSuccess &&
               hipMalloc((void**)&p->act, T * D * 2) == hipSuccess;
@@ -328,13 +424,20 @@ extern "C" int showo_projector_load(showo_projector* p, const char* key, const f
     if (k.rfind("mm_projector.", 0) == 0) k = k.substr(13);
     const int64_t I = p->in_dim, D = p->out_dim;
     int rc;
-    if (k == "0.weight") rc = cast_w(p->w0, src, n, D * I, s);
+    if (k == "0.weight") rc = split_w(p->w0, p->w0_lo, src, n, D * I, s);
     else if (k == "0.bias") rc = copy_f32(p->b0, src, n, D, s);
-    else if (k == "2.weight") rc = cast_w(p->w1, src, n, D * D, s);
+    else if (k == "2.weight") rc = split_w(p->w1, p->w1_lo, src, n, D * D, s);
     else if (k == "2.bias") rc = copy_f32(p->b1, src, n, D, s);
     else return set_error_msg(3, "projector_load: unknown key");
     if (rc == 0) { p->loaded.insert(k); p->wT_valid = false; }
     return rc;
+}
+
+extern "C" int showo_projector_set_precision(showo_projector* p, int precision) {
+    if (!p) return set_error_msg(1, "projector_set_precision: null handle");
+    if (precision != 0 && precision != 1) return set_error_msg(1, "projector_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class)");
+    p->precision = precision;
+    return 0;
 }
 
 // x fp32 [T, in] -> out fp32 [T, out] = W1 gelu(W0 x + b0) + b1
@@ -344,6 +447,15 @@ extern "C" int showo_projector_forward(showo_projector* p, const float* x, int T
     if (T <= 0 || T > p->max_rows) return set_error_msg(5, "projector_forward: too many rows for the workspace");
     if (p->loaded.size() != 4) return set_error_msg(4, "projector_forward: weights missing");
     const int I = p->in_dim, D = p->out_dim;
+    if (p->precision == 1) {  // accuracy mode: split-bf16 GEMMs, exact GELU in fp32 -> (hi, lo); inference only (the backward keeps bf16)
+        TRY(showo_split_f32_bf16(x, p->xb, p->xb_lo, (int64_t)T * I, s));
+        TRY(showo_gemm_bf16x3(p->xb, p->xb_lo, I, p->w0, p->w0_lo, I, p->b0, 0, p->f, D, nullptr, 0, T, D, I, s));
+        act_split_kernel<1><<<dim3(1024), dim3(256), 0, s>>>(p->f, p->act, p->act_lo, (int64_t)T * D);
+        TRY(showo_gemm_bf16x3(p->act, p->act_lo, D, p->w1, p->w1_lo, D, p->b1, 0, out, D, nullptr, 0, T, D, D, s));
+        SHOWO_CHECK_HIP(hipGetLastError());
+        p->last_T = T;
+        return 0;
+    }
     TRY(showo_cast_f32_bf16(x, p->xb, (int64_t)T * I, s));
     TRY(showo_gemm_bf16(p->xb, I, p->w0, I, p->b0, 0, p->f, D, nullptr, 0, T, D, I, SHOWO_EPI_F32, s));
     act_kernel<1><<<dim3(1024), dim3(256), 0, s>>>(p->f, p->act, (int64_t)T * D);

@@ -95,7 +95,7 @@ __device__ inline uint32_t lds_addr_of(const void* p) {
 }
 __device__ inline void glds16_untracked(const bf16_t* src, uint32_t lds_wave_base) {
     const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);  // the value is wave-uniform; this tells the compiler so
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
 }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011) — the on-device noise source of the sampler.

@@ -49,7 +49,7 @@ constexpr int TN_TILE = 64 * 256;  // elements of one operand tile (32 KiB)
 // front of every ds_read_b64_tr_b16 (it cannot prove that the transposing read does not alias them), which drains the DMA queue once
 // per phase -- the opposite of the counted-vmcnt schedule.  Ordering is ours anyway: counted waits + barriers, as in gemm2p.
 static __device__ __forceinline__ void glds16_sa(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 
 // EDGE = false (the shapes of the training step): every 256-column tile of both operands lies inside a row (lda >= 256 tilesM, ldb >=

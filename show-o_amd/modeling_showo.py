@@ -203,14 +203,14 @@ class _MMProjector(nn.Sequential):
         self._proj, self._rows, self._versions = None, 0, None
 
     def set_precision(self, precision):
-        """0 (default): bf16 GEMM / attention operands with fp32 accumulation -- the timed path.  1: accuracy mode, the reference's
-        fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
-        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels, t2i_generate() and
-        mmu_generate() (which then runs the reference's own no-cache algorithm: the whole sequence per token); training keeps bf16
-        operands.  Costs a second bf16 image of the weights."""
+        """0 (default): bf16 GEMM operands.  1: accuracy mode of the projector -- split-bf16 (hi + lo) MFMA GEMMs and the exact GELU in
+        fp32 (csrc/clip_engine.hip showo_projector_set_precision): nn.Sequential(Linear, GELU, Linear) in fp32 to ~1e-5.  Inference
+        only (the backward differentiates the bf16-operand forward).  `Showo.set_precision` forwards here."""
         if int(precision) not in (0, 1):
             raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
         self._precision = int(precision)
+        if getattr(self, "_proj", None) is not None:
+            _lib.call("showo_projector_set_precision", self._proj, self._precision)
         return self
 
     def mark_weights_dirty(self):
@@ -242,6 +242,7 @@ class _MMProjector(nn.Sequential):
             self._rows = max(T, 576)
             _lib.check(_lib.load().showo_projector_create(din, dout, self._rows, C.byref(h)), "showo_projector_create")
             self._proj, self._versions = h, {}
+            _lib.call("showo_projector_set_precision", self._proj, int(getattr(self, "_precision", 0)))
         for k, v in self.state_dict().items():
             ver = (v.data_ptr(), v._version)
             if self._versions.get(k) != ver:
@@ -375,10 +376,12 @@ class Showo(PretrainedMixin, nn.Module):
         fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
         LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels, t2i_generate() and
         mmu_generate() (which then runs the reference's own no-cache algorithm: the whole sequence per token); training keeps bf16
-        operands.  Costs a second bf16 image of the weights."""
+        operands.  Costs a second bf16 image of the weights.  With w_clip_vit the mm_projector follows (its own accuracy mode)."""
         if int(precision) not in (0, 1):
             raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
         self._precision = int(precision)
+        if self.__dict__.get("_modules", {}).get("mm_projector") is not None:
+            self.mm_projector.set_precision(precision)
         return self
 
     def mark_weights_dirty(self):

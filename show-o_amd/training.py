@@ -232,8 +232,15 @@ class Trainer:
             _lib.call("showo_trainer_use_intervals", tr, None, None)
         ex = self.exchange
         nL = m.arch["num_hidden_layers"]
-        _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,
-                  self.coeffs[0], self.coeffs[1], self.coeffs[2], s())
+        # `lab` is this step's own contiguous copy / view and is not written between the forward above and this call: the d(logits) of
+        # the forward's cross-entropy pass is reused only for the SAME forward (every forward invalidates it), pointer, split and weights.
+        try:
+            _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,
+                      self.coeffs[0], self.coeffs[1], self.coeffs[2], s())
+        finally:
+            # the announcement is per step: a later forward with labels outside Trainer.step (the module's autograd path, an eval loop)
+            # must not write the T x Vp d(logits) tensor (1.3 GB at the stage-1 batch) for a backward that never comes
+            _lib.call("showo_train_set_loss_weights", tr, 0.0, 0.0, 0.0, 0)
         if ex is not None:
             ex.launch(nL + 1)
         for i in range(nL - 1, -1, -1):

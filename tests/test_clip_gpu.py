@@ -88,6 +88,47 @@ def test_clip_vit_l_14_336_full_size_vs_transformers_subset():
     assert rel_rms < 5.2e-2 and rel_max < 3.2e-2
 
 
+def test_clip_accuracy_mode_within_1e3_of_the_fp32_tower():
+    """`tower.set_precision(1)` (split-bf16 GEMMs, fp32 LayerNorm / attention / quick_gelu) against transformers' fp32
+    CLIPVisionModel outputs (tests/golden/clip_vision.npz): north_star's 1e-3, tiny AND ViT-L/14-336 (23 blocks, 577 tokens, the
+    rounding-amplifying synthetic weights the bf16 path is gated at 5.2e-2 on).  rel_max = max|d| / max|ref|, rel_rms = rms(d) / std."""
+    g = util.golden("clip_vision.npz")
+    tower, sd = _tower(Wt.CLIP_TINY, int(g["tiny_seed"]))
+    x = dev(g["tiny_x"])
+    out0 = tower(x)
+    assert tower.set_precision(1) is tower
+    out = tower(x)
+    ref = torch.from_numpy(g["tiny_features"])
+    rmax, rrms = util.relerr(out, ref)
+    print(f"[parity] clip tiny, accuracy mode: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rmax <= 1e-3 and rrms <= 1e-3
+    assert torch.equal(tower(x), out)
+    assert torch.equal(tower.set_precision(0)(x), out0)  # back on bf16 operands: the same bits as before
+    with pytest.raises(ValueError):
+        tower.set_precision(2)
+    del tower
+    seed = int(g["l336_seed"])
+    big, _ = _tower(Wt.CLIP_L336, seed, max_batch=1)
+    big.set_precision(1)
+    xb = torch.from_numpy(np.random.RandomState(seed + 100).standard_normal((1, 3, 336, 336)).astype(np.float32)).cuda()
+    ob = big(xb)
+    sub = ob[0][torch.from_numpy(g["l336_rows"]).cuda()][:, torch.from_numpy(g["l336_cols"]).cuda()].cpu()
+    refb = torch.from_numpy(g["l336_features"])
+    err = (sub - refb).abs()
+    rel_max, rel_rms = float(err.max()) / float(g["l336_absmax"]), float(err.pow(2).mean().sqrt()) / float(g["l336_std"])
+    print(f"[parity] CLIP ViT-L/14-336, accuracy mode, subset: rel_max(absmax)={rel_max:.3e} rel_rms(std)={rel_rms:.3e}")
+    assert rel_max <= 1e-3 and rel_rms <= 1e-3
+    # projector accuracy mode vs the torch nn.Sequential's fp32 output
+    proj = util.pkg().modeling_showo._MMProjector(128, 192)
+    proj.load_state_dict(O.to_torch(Wt.make_projector_state(128, 192, seed=23)))
+    proj = proj.cuda().set_precision(1)
+    with torch.no_grad():
+        po = proj(dev(g["proj_x"]).view(1, 37, 128))
+    pm, pr = util.relerr(po[0], torch.from_numpy(g["proj_out"]))
+    print(f"[parity] mm_projector, accuracy mode: rel_max={pm:.3e} rel_rms={pr:.3e}")
+    assert pm <= 1e-3 and pr <= 1e-3
+
+
 def test_mm_projector_hip_forward_vs_torch_module_golden():
     g = util.golden("clip_vision.npz")
     P = util.pkg()

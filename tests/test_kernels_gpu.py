@@ -736,6 +736,33 @@ def test_gemm_tn_weight_gradient_on_token_major_operands(M, N, T, lda):
         L().call("showo_gemm_tn_bf16", L().ptr(Ab), lda, L().ptr(Bb), N, L().ptr(out), N, lda + 4, N, T, 0, 0, S())
 
 
+@pytest.mark.parametrize("M,N,T", [(2048, 8192, 1024), (2048, 8192, 1100), (2048, 2048, 11223), (2048, 2048, 11264), (6144, 2048, 700)])
+def test_gemm_tn_fast_form_ignores_nan_padding_rows(M, N, T):
+    """the PRODUCTION forms of showo_gemm_tn_bf16 (rows_padded = 1: unchecked DMAs; the 3-deep operand ring when the launch
+    has more than 128 tiles, split-K with the partial last k-tile masked in registers otherwise) on operands allocated to
+    roundup(T, 64) rows whose padding rows hold NaN / Inf: equal bits to the fully checked form (rows_padded = 0), no NaN anywhere.
+    Shapes: one ring launch (256 tiles) with T % 64 == 0 and != 0, the stage-1 split-K shape (64 tiles, T = 11 223 and a multiple of
+    64), and a dqkv-shaped launch."""
+    torch.manual_seed(M + N + T)
+    Tp = (T + 63) // 64 * 64
+    A, B = torch.randn(Tp, M), torch.randn(Tp, N) * 0.5
+    A[T:], B[T:] = float("nan"), float("inf")
+    if Tp > T:
+        B[T, ::2] = float("nan")
+    Ab, Bb = dev(to_bf16_bits(A)), dev(to_bf16_bits(B))
+    fast = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    chk = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    L().call("showo_gemm_tn_bf16", L().ptr(Ab), M, L().ptr(Bb), N, L().ptr(fast), N, M, N, T, 0, 1, S())
+    L().call("showo_gemm_tn_bf16", L().ptr(Ab), M, L().ptr(Bb), N, L().ptr(chk), N, M, N, T, 0, 0, S())
+    sync()
+    assert torch.isfinite(fast).all() and torch.isfinite(chk).all()
+    assert torch.equal(fast, chk)
+    rows = torch.tensor([0, 1, 257, M - 1])
+    ref = bf16_round(A[:T][:, rows]).double().T @ bf16_round(B[:T]).double()
+    err = float((fast.cpu()[rows].double() - ref).abs().max())
+    assert err < 2e-5 * float(ref.abs().max()) * max(1.0, (T / 512) ** 0.5), err
+
+
 SPLITK_OFF, SPLITK_ON = 64, 128  # showo_gemm_tune flag bits
 
 

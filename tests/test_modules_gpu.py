@@ -419,10 +419,10 @@ def test_full_size_logits_vs_reference_subset():
     del lgp, subp
     m.set_precision(0)
     assert torch.equal(m(ids, attention_mask=mask), lg)  # back on the bf16 path: the same bits as before
-    # north_star's 1e-3, block by block at full size (blocks 0, 1, 11, 23 and the head: each on the GPU's own block input), and the
-    # end-to-end comparison with the rounding-point oracle for the record
+    # north_star's 1e-3, block by block at full size: ALL 24 blocks and the head, each on the GPU's own block input, and
+    # the end-to-end comparison with the rounding-point oracle for the record
     sdt = O.to_torch(Wt.make_showo_state(d, seed=int(g["seed"])))
-    lg2 = _blockwise_bf16_points(m, d, sdt, torch.from_numpy(g["ids"]), mask.cpu(), "full-size [2,387]", qkv_round=False, blocks=(0, 1, 11, 23))
+    lg2 = _blockwise_bf16_points(m, d, sdt, torch.from_numpy(g["ids"]), mask.cpu(), "full-size [2,387], all 24 blocks", qkv_round=False)
     assert torch.equal(lg2, lg.cpu())
     want = O.showo_logits(sdt, d, torch.from_numpy(g["ids"]), attention_mask=mask.cpu(), pts=O.Bf16Points())
     del sdt
@@ -452,6 +452,177 @@ def test_full_size_logits_vs_reference_subset():
     keep = img != d.mask_token_id
     assert torch.equal(img[keep] - d.image_offset, out[keep])
     assert torch.equal(icd[:, :130].cpu(), ic[:, :130])  # text prefix and <soi> untouched
+
+
+def _subset(lg, rows, cols):
+    return lg[:, torch.as_tensor(rows, device=lg.device)][:, :, torch.as_tensor(cols, device=lg.device)]
+
+
+def test_full_size_cfg3_inpainting_batch_logits_vs_reference_subset():
+    """BASELINE cfg3 at MODEL SCALE (VERDICT r3 #1a): 1.45 B parameters, the [8,1155] CFG-doubled 512x512 inpainting batch (1 024 image
+    tokens, centred 16x16-token hole), logits of one mask-predict forward against the REAL reference's (tests/golden/showo_full_cfg3.npz,
+    oracle/make_golden.py::make_full_cfg3): bf16 operands at the stated bounds, accuracy mode at north_star's 1e-3, dense mask == the
+    interval mask built on the device, and the per-block 1e-3 gate on 5 blocks spread over the stack (every block is gated at [2,387])."""
+    g = util.golden("showo_full_cfg3.npz")
+    d = Wt.ShowoDims(num_vq_tokens=1024)
+    sd = Wt.make_showo_state(d, seed=int(g["seed"]))
+    m = util.build_showo(d, sd, max_batch=8, max_seq=1155)
+    del sd
+    ids_cpu = torch.from_numpy(g["ids"].astype(np.int64))
+    assert tuple(ids_cpu.shape) == (8, 1155)
+    ids = ids_cpu.cuda()
+    mask = O.mask_t2i(ids_cpu, d.pad_id, d.soi_id, d.eoi_id).cuda()
+    lg = m(ids, attention_mask=mask)
+    ref = torch.from_numpy(g["logits"])
+    sub = _subset(lg, g["rows"], g["cols"])
+    rmax, rrms = util.relerr(sub, ref)
+    print(f"[parity] full-size cfg3 [8,1155] logits vs reference subset: rel_max={rmax:.3e} rel_rms={rrms:.3e} "
+          f"(logit absmax {float(g['logit_absmax']):.3f}, std {float(g['logit_std']):.3f})")
+    assert rrms <= REL_RMS and rmax <= REL_MAX
+    iv = util.pkg().prompting_utils.intervals_predict_next(ids, pad_id=d.pad_id, soi_id=d.soi_id, eoi_id=d.eoi_id, rm_pad_in_image=True)
+    assert torch.equal(m(ids, attention_mask=iv), lg)  # on-device interval mask == the reference's dense mask, bit for bit
+    del lg
+    m.set_precision(1)
+    lgp = m(ids, attention_mask=mask)
+    pmax, prms = util.relerr(_subset(lgp, g["rows"], g["cols"]), ref)
+    print(f"[parity] full-size cfg3 [8,1155] logits, accuracy mode vs the fp32 reference subset: rel_max={pmax:.3e} rel_rms={prms:.3e}")
+    assert pmax <= PRECISE_TOL and prms <= PRECISE_TOL
+    del lgp
+    m.set_precision(0)
+    sdt = O.to_torch(Wt.make_showo_state(d, seed=int(g["seed"])))
+    # 2 of the 8 sequences (one conditional, one unconditional) keep the CPU side of the per-block gate to about a minute
+    pick = torch.tensor([1, 5])
+    _blockwise_bf16_points(m, d, sdt, ids_cpu[pick], mask.cpu()[pick], "full-size cfg3 rows [2,1155]", qkv_round=False, blocks=(0, 6, 12, 18, 23))
+
+
+def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
+    """BASELINE cfg4 at MODEL SCALE (VERDICT r3 #1b): the 631-embedding w_clip_vit prompt (mm_projector of 576 CLIP features spliced between
+    the system prompt and the question, inference_mmu.py:124-141), the reference's create_attention_mask_for_mmu_vit, its prefill logits and
+    the first 8 greedy tokens of its no-cache mmu_generate with the logits each was drawn from (tests/golden/showo_full_cfg4.npz).
+      bf16 operands: prefill logits (rows x cols subset) and the TEACHER-FORCED decode-step logits (KV cache, reference's tokens fed
+        back) at the stated bounds; free-running greedy tokens equal the reference's wherever its top-2 gap exceeds twice the measured
+        logit error of that step (first divergence printed);
+      accuracy mode: projector output, prefill logits and every step's logits within 1e-3, the 8 tokens identical."""
+    g = util.golden("showo_full_cfg4.npz")
+    d = Wt.ShowoDims(w_clip_vit=True)
+    sd = Wt.make_showo_state(d, seed=int(g["seed"]))
+    m = util.build_showo(d, sd, max_batch=1, max_seq=768)
+    del sd
+    L = util.lib()
+    feats = torch.from_numpy(np.random.RandomState(int(g["feat_seed"])).standard_normal((1, 576, 1024)).astype(np.float32)).cuda()
+    ids_llava = torch.from_numpy(g["ids_llava"].astype(np.int64)).cuda()
+    toks_ref = g["tokens"].tolist()
+    cols = torch.from_numpy(g["cols"]).cuda()
+    tab = m.showo.model.embed_tokens.weight
+
+    def splice():
+        with torch.no_grad():
+            img = m.mm_projector(feats)
+            txt = tab[ids_llava]
+            return img, torch.cat([txt[:, :30], img, txt[:, 30:]], dim=1).contiguous()
+
+    img, emb = splice()
+    assert emb.shape[1] == 631
+    r = util.relerr(img[0, ::64], torch.from_numpy(g["img_emb_rows"]))
+    print(f"[parity] cfg4 mm_projector rows vs reference: rel_max={r[0]:.3e} rel_rms={r[1]:.3e}")
+    assert r[1] <= REL_RMS and r[0] <= REL_MAX
+    P = util.pkg().prompting_utils
+    am = P.create_attention_mask_for_mmu_vit(emb, system_prompt_len=28)
+    assert torch.equal(am.float().cpu() == 0, O.mask_mmu_vit(1, 631, system_prompt_len=28) == 0)
+    # ---- bf16 operands: prefill
+    lg = m(None, input_embeddings=emb, attention_mask=am)
+    pre_ref = torch.from_numpy(g["prefill_logits"])
+    pre = lg[0][torch.from_numpy(g["rows"]).cuda()][:, cols]
+    rmax, rrms = util.relerr(pre, pre_ref)
+    print(f"[parity] full-size cfg4 prefill logits [1,631] vs reference subset: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rrms <= REL_RMS and rmax <= REL_MAX
+    del lg
+    # ---- bf16 operands: KV-cached decode, teacher-forced with the reference's tokens; step j's logits = what token j was drawn from
+    eng = m.engine()
+    logits = torch.empty((d.vocab,), dtype=torch.float32, device="cuda")
+    embc = emb.float().contiguous()
+    maskc = am[0].float().reshape(1, 1, 631, 631).contiguous()
+    L.call("showo_engine_prefill", eng, None, L.ptr(embc), L.ptr(maskc), 631, L.ptr(logits), L.stream())
+    last_ref = torch.from_numpy(g["last_logits"])
+    worst, errs = 0.0, []
+    for j, t in enumerate(toks_ref):
+        torch.cuda.synchronize()
+        diff = (logits[cols].cpu() - last_ref[j]).double()
+        errs.append(float(diff.abs().max()))
+        rel_max, rel_rms = errs[-1] / float(g["last_absmax"][j]), float(diff.pow(2).mean().sqrt() / last_ref[j].double().pow(2).mean().sqrt())
+        worst = max(worst, rel_max)
+        assert rel_rms <= REL_RMS and rel_max <= REL_MAX, (j, rel_max, rel_rms)
+        if j + 1 < len(toks_ref):
+            tok = torch.tensor([t], dtype=torch.int64, device="cuda")
+            L.call("showo_engine_decode_step", eng, L.ptr(tok), None, L.ptr(logits), L.stream())
+    print(f"[parity] full-size cfg4 teacher-forced decode, {len(toks_ref)} steps on the KV cache: worst rel_max={worst:.3e}")
+    toks = [int(t) for t in m.mmu_generate(input_embeddings=emb, attention_mask=am[0], max_new_tokens=len(toks_ref), top_k=1)]
+    div = next((j for j, (a, b) in enumerate(zip(toks, toks_ref)) if a != b), None)
+    print(f"[parity] full-size cfg4 free-running greedy tokens (bf16): {toks} vs reference {toks_ref}; first divergence: {div}; "
+          f"reference top-2 gaps {np.round(g['last_top2_gap'], 4).tolist()}, measured abs logit error per step {np.round(errs, 4).tolist()}")
+    for j in range(len(toks_ref)):
+        if toks[j] != toks_ref[j]:
+            assert float(g["last_top2_gap"][j]) <= 2.0 * errs[j], (j, toks, toks_ref)  # a flipped arg-max must be a near tie
+            break  # after a divergence the sequences differ legitimately
+    ivm = P.intervals_for_mmu_vit(emb, system_prompt_len=28)  # no [1,1,631,631] tensor at all: the same tokens
+    assert [int(t) for t in m.mmu_generate(input_embeddings=emb, attention_mask=ivm, max_new_tokens=len(toks_ref), top_k=1)] == toks
+    # ---- accuracy mode (projector + transformer): 1e-3 against the fp32 reference, tokens identical
+    m.set_precision(1)
+    imgp, embp = splice()
+    rp = util.relerr(imgp[0, ::64], torch.from_numpy(g["img_emb_rows"]))
+    print(f"[parity] cfg4 mm_projector rows, accuracy mode: rel_max={rp[0]:.3e} rel_rms={rp[1]:.3e}")
+    assert rp[0] <= PRECISE_TOL and rp[1] <= PRECISE_TOL
+    lgp = m(None, input_embeddings=embp, attention_mask=am)
+    _check_precise(lgp[0][torch.from_numpy(g["rows"]).cuda()][:, cols], pre_ref, "full-size cfg4 prefill logits vs the fp32 reference subset")
+    _check_precise(lgp[0, -1][cols], last_ref[0], "full-size cfg4 first-token logits")
+    del lgp
+    toks_p = [int(t) for t in m.mmu_generate(input_embeddings=embp, attention_mask=am[0], max_new_tokens=len(toks_ref), top_k=1)]
+    print(f"[parity] full-size cfg4 greedy tokens, accuracy mode (reference's no-cache algorithm): {toks_p}")
+    assert toks_p == toks_ref
+    # the grown sequence after 4 tokens, as the reference builds it (modeling_showo.py:203-217): logits token 5 was drawn from
+    neg = float(torch.finfo(torch.float32).min)
+    cur, mk = embp.float(), am[0].float().reshape(631, 631)
+    for t in toks_ref[:4]:
+        Lc = cur.shape[1]
+        grown = torch.full((Lc + 1, Lc + 1), neg, dtype=torch.float32, device="cuda")
+        grown[:Lc, :Lc] = mk
+        grown[Lc, :Lc] = mk[Lc - 1]
+        grown[Lc, Lc] = 0.0
+        mk = grown
+        cur = torch.cat([cur, tab[torch.tensor([[t]], device="cuda")].float()], dim=1)
+    lg4 = m(None, input_embeddings=cur.contiguous(), attention_mask=mk.reshape(1, 1, 635, 635).contiguous())
+    _check_precise(lg4[0, -1][cols], last_ref[4], "full-size cfg4 logits of the 5th token on the grown [1,635] sequence")
+
+
+def test_magvit_512_get_code_and_decode_code_vs_reference_golden():
+    """512x512 VQ parity (VERDICT r3 #1c; BASELINE cfg3 / cfg4 encode and decode at this size: 1 024 tokens, 32x32 latent, tile counts
+    and block maps of the conv kernels differ from 256x256): the REFERENCE's ids, latents and decoded pixels
+    (tests/golden/magvit_512.npz, oracle/make_golden.py::make_magvit_512, models/modeling_magvitv2.py:416-433)."""
+    g = util.golden("magvit_512.npz")
+    for precision, z_rms, img_rms, img_max in ((1, 2e-4, 2e-4, 1e-3), (0, 3e-2, 3e-2, 8e-2)):
+        v = util.pkg().MAGVITv2(max_batch=1, max_res=512, precision=precision)
+        v.load_state_dict(O.to_torch(Wt.make_magvit_state(seed=int(g["seed"]))), strict=True)
+        v = v.cuda().eval()
+        x = torch.from_numpy(np.random.RandomState(int(g["x_seed"])).uniform(-1, 1, size=(1, 3, 512, 512)).astype(np.float32))
+        ids, z = v.get_code_and_latents(x.cuda())
+        zr, idr = torch.from_numpy(g["z"]), torch.from_numpy(g["ids"])
+        rmax, rrms = util.relerr(z, zr)
+        agree = float((ids.cpu() == idr).float().mean())
+        print(f"[parity] magvit get_code 512x512 precision={precision}: latent rel_max={rmax:.3e} rel_rms={rrms:.3e}; token agreement {agree:.4f}")
+        assert tuple(ids.shape) == (1, 1024) and np.array_equal(ids.cpu().numpy(), O.lfq_pack_np(z.cpu().numpy()))
+        flipped = (z.cpu() > 0) != (zr > 0)
+        assert (zr.abs()[flipped] <= 4 * float((z.cpu() - zr).abs().max())).all()  # a differing bit sits on an unresolvable latent
+        assert rrms <= z_rms
+        if precision == 1:
+            assert agree >= 0.99
+        img = v.decode_code(idr.cuda()).cpu()
+        assert tuple(img.shape) == (1, 3, 512, 512)
+        dd = torch.cat([(img[:, :, ::8, ::8] - torch.from_numpy(g["image_s8"])).reshape(-1),
+                        (img[:, :, 224:288, 192:256] - torch.from_numpy(g["image_crop"])).reshape(-1)]).double()
+        rel_rms, rel_max = float(dd.pow(2).mean().sqrt() / float(g["image_rms"])), float(dd.abs().max() / float(g["image_absmax"]))
+        print(f"[parity] magvit decode_code 512x512 precision={precision} (every 8th pixel + a dense 64x64 crop): rel_max={rel_max:.3e} rel_rms={rel_rms:.3e}")
+        assert rel_rms <= img_rms and rel_max <= img_max
+        del v
 
 
 def _magvit(seed, precision=1):
