@@ -467,6 +467,7 @@ def test_full_size_cfg3_inpainting_batch_logits_vs_reference_subset():
     d = Wt.ShowoDims(num_vq_tokens=1024)
     sd = Wt.make_showo_state(d, seed=int(g["seed"]))
     m = util.build_showo(d, sd, max_batch=8, max_seq=1155)
+    sdt = O.to_torch(sd)  # kept on the host for the per-block oracle below (5.8 GB)
     del sd
     ids_cpu = torch.from_numpy(g["ids"].astype(np.int64))
     assert tuple(ids_cpu.shape) == (8, 1155)
@@ -489,7 +490,6 @@ def test_full_size_cfg3_inpainting_batch_logits_vs_reference_subset():
     assert pmax <= PRECISE_TOL and prms <= PRECISE_TOL
     del lgp
     m.set_precision(0)
-    sdt = O.to_torch(Wt.make_showo_state(d, seed=int(g["seed"])))
     # 2 of the 8 sequences (one conditional, one unconditional) keep the CPU side of the per-block gate to about a minute
     pick = torch.tensor([1, 5])
     _blockwise_bf16_points(m, d, sdt, ids_cpu[pick], mask.cpu()[pick], "full-size cfg3 rows [2,1155]", qkv_round=False, blocks=(0, 6, 12, 18, 23))
