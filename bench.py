@@ -83,7 +83,8 @@ def cpu_baseline(budget_s=30.0):
     step_s = {}
     with torch.no_grad():
         O.t2i_generate(sd_t, d, ic.clone(), iu.clone(), mask, 1.0, 1, 5.0)  # page-in + thread pool warm-up, not timed
-        for nt in sorted({threads, min(8, threads)}):  # the pick must not be slower than the 8-thread pool on a REAL oracle step
+        for nt in sorted(cands):  # every candidate runs one REAL oracle step: the GEMM microbenchmark above mis-ranks pool sizes (r4a: 64
+            # threads = 4.9x the 8-thread GEMM rate, yet a 1.55x SLOWER denoise step), so the step time decides
             torch.set_num_threads(nt)
             t0 = time.time()
             O.t2i_generate(sd_t, d, ic.clone(), iu.clone(), mask, 1.0, 1, 5.0)
@@ -503,7 +504,7 @@ def main():
         # every BASELINE config in the driver's record: cfg3 / cfg4 (and cfg1 = --batch 1) as short child runs under a ~90 s budget
         if world == 1 and not a.no_config_legs:
             others = {}
-            for key, argv in (("cfg1_t2i256_batch1", ["--batch", "1", "--steps", "2", "--warmup", "1", "--roofline-steps", "0"]),
+            for key, argv in (("cfg1_t2i256_batch1", ["--batch", "1", "--steps", "3", "--warmup", "1", "--roofline-steps", "1"]),
                               ("cfg3_t2i512_inpaint_batch4", ["--workload", "t2i512", "--steps", "1", "--warmup", "1"]),
                               ("cfg4_mmu_decode", ["--workload", "mmu", "--steps", "1", "--warmup", "1"])):
                 t1 = time.time()
@@ -523,7 +524,7 @@ def main():
                 # the CPU side of the second half of the metric, same run, same host cores (bounded sample: 3-sequence fwd + bwd)
                 import bench_train
                 try:
-                    train_step["cpu_baseline"] = bench_train.cpu_baseline(29, budget_s=25.0)
+                    train_step["cpu_baseline"] = bench_train.cpu_baseline(29, budget_s=25.0, threads=out["cpu_baseline"]["cores"])
                 except Exception as ex:  # the headline line must survive a host that cannot hold the fp32 model twice
                     train_step["cpu_baseline"] = {"error": repr(ex)}
         else:

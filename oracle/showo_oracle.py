@@ -75,14 +75,63 @@ class Bf16Points:
       * ffn = bf16(gelu_new(acc + b1)); x += [o | ffn] [Wd | W2]^T + (bd + b2) in fp32;
       * hf = bf16(final LayerNorm(x)); logits fp32."""
 
-    def __init__(self, qkv_round=False):
+    def __init__(self, qkv_round=False, attn_tiles=False):
         self.qkv_round = qkv_round
+        # attn_tiles: model the rounding SCALE of P in the LDS-tiled attention kernel as well (attention_lds_model below); without it
+        # P is rounded at the row's final maximum, which the kernel only does for rows whose maximum sits in their first key tile
+        self.attn_tiles = attn_tiles
         self._w = {}
 
     def w(self, sd, key):
         if key not in self._w:
             self._w[key] = bf16r(sd[key])
         return self._w[key]
+
+
+AT_DEFER = 8.0  # csrc/attention.hip: deferred-rescale threshold of the running maximum (natural-log units)
+_LOG2E = 1.4426950408889634
+
+
+def attention_lds_model(q, k, v, vis):
+    """The arithmetic of csrc/attention.hip::attn_lds_body with its rounding points, restated for the per-block parity gate.
+    q (pre-scaled by 1/8), k, v: bf16-rounded fp32 [B,H,L,64]; vis: bool [B,1|H,L,L] (True = key visible).
+    One wave owns 32 consecutive query rows and walks the keys in 32-key sub-tiles (multiples of 32 inside the wave's key hull); the
+    running maximum m of a row is advanced -- for EVERY row of the wave -- only when some row's sub-tile maximum exceeds its m by more
+    than AT_DEFER; P = bf16(exp2((s - m) log2 e)) multiplies bf16 V with fp32 accumulation, the denominator sums the unrounded P, both
+    are rescaled in fp32 when m moves; o = bf16(acc * (1 / l)).  The SCALE at which P is rounded (m at that sub-tile, not the row's
+    final maximum) is what this adds over rounding exp(s - rowmax): with it the remaining GPU difference is accumulation order only."""
+    B, H, L, D = q.shape
+    s_all = q @ k.transpose(2, 3)
+    vis = vis.expand(B, H, L, L) if vis.shape[1] == 1 else vis
+    out = torch.empty_like(q)
+    for g0 in range(0, L, 32):
+        g1 = min(g0 + 32, L)
+        vg = vis[:, :, g0:g1]                                   # [B,H,R,L]
+        sg = torch.where(vg, s_all[:, :, g0:g1], torch.full((), float("-inf")))
+        anyk = vg.any(dim=2)                                    # [B,H,L]: key visible to some row of the wave
+        m = torch.full((B, H, g1 - g0), float("-inf"))
+        l = torch.zeros((B, H, g1 - g0))
+        acc = torch.zeros((B, H, g1 - g0, D))
+        for ks in range(0, L, 32):
+            ke = min(ks + 32, L)
+            # hull skip is per (b, head) wave: sub-tiles outside [wmin, wmax) are not visited; inside the hull a sub-tile with no
+            # visible key contributes p = 0 and never moves m, so visiting it is equivalent -- except through the `any` rule, which
+            # such a sub-tile cannot trigger (its maxima are -inf).  Hence no explicit hull logic is needed here.
+            sv = sg[:, :, :, ks:ke]
+            mx = sv.max(dim=-1).values                          # [B,H,R]
+            upd = (mx > m + AT_DEFER).any(dim=-1, keepdim=True)  # wave-wide vote [B,H,1]
+            m_new = torch.where(upd, torch.maximum(m, mx), m)
+            alpha = torch.where(torch.isinf(m_new) | (m_new == m), torch.ones(()), torch.exp2((m - torch.where(torch.isinf(m_new), torch.zeros(()), m_new)) * _LOG2E))
+            alpha = torch.where(torch.isinf(m) & ~torch.isinf(m_new), torch.zeros(()), alpha)
+            l = l * alpha
+            acc = acc * alpha.unsqueeze(-1)
+            m = m_new
+            mb = torch.where(torch.isinf(m), torch.zeros(()), m) * _LOG2E
+            pr = torch.exp2(sv * _LOG2E - mb.unsqueeze(-1))    # exp2(fma(s, log2 e, -m log2 e)); masked keys: exp2(-inf) = 0
+            l = l + pr.sum(dim=-1)
+            acc = acc + bf16r(pr) @ v[:, :, ks:ke]
+        out[:, :, g0:g1] = bf16r(acc * (1.0 / l).unsqueeze(-1))
+    return out
 
 
 def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
@@ -112,6 +161,9 @@ def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
         # SDPA is_causal path when no mask is given (models/phi.py:713)
         causal = torch.tril(torch.ones(L, L, dtype=torch.bool))
         s = s.masked_fill(~causal, float("-inf"))
+    if pts is not None and pts.attn_tiles:
+        vis = (mask == 0) if mask is not None else torch.tril(torch.ones(L, L, dtype=torch.bool)).reshape(1, 1, L, L)
+        return attention_lds_model(q, k, v, vis).transpose(1, 2).reshape(B, L, Hd)
     if pts is not None:
         e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
         o = bf16r((bf16r(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, L, Hd)

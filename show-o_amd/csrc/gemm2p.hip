@@ -401,9 +401,10 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
 //   m-split with a 3-deep weight ring (gemm3w.hip): 2256 (8+8), 2240 (8+7), 2224 (7+7), 2208 (7+6)
 //   n-split on the ring: 3192 (6+6), 3176 (6+5), 3160 (5+5), 3144 (5+4)
 //   the same with buffer-descriptor DMAs: 4192, 4176, 4160, 4144
-constexpr int N_VARIANTS = 24;
+//   four waves x 128 x 128 wave tiles, 256-row tiles with short bodies for a ragged last tile row (gemm4h.hip): 5256
+constexpr int N_VARIANTS = 25;
 const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144,
-                                    4192, 4176, 4160, 4144};
+                                    4192, 4176, 4160, 4144, 5256};
 bool is_variant(int v) {
     for (int i = 0; i < N_VARIANTS; ++i)
         if (k_variants[i] == v) return true;
@@ -412,6 +413,7 @@ bool is_variant(int v) {
 
 template <int EPI>
 int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
+    if (h == 5256) return gemm4h_launch(g, EPI, s);
     if (h >= 2000) return gemm3w_launch(g, EPI, h - 2000, s);
     switch (h) {
         case 240: return launch2p<EPI, 8, 7, false>(g, s);

@@ -108,6 +108,17 @@ static __device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, in
     }
 }
 
+// x + (the values of the three lanes 16, 32 and 48 away): the reduction of a token's 64 head values in the QKV epilogue, where they
+// sit in the 4 lanes fr + 16 {0..3}.  gfx950's row-swap instructions (v_permlane16_swap / v_permlane32_swap: 3 VALU instructions per
+// step, no LDS round trip) in the SAME order as `x += shfl_xor(x, 16); x += shfl_xor(x, 32)` -- (own + 16-partner) + (the 32-partner's
+// pair sum), floating-point addition being commutative -- so the result has the bits of the ds_bpermute form it replaces.
+static __device__ __forceinline__ float sum4_lanes16(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 static __device__ __forceinline__ void bar_raw_fn() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
@@ -328,16 +339,14 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = sum4_lanes16(sum);
                 const float mean = sum * (1.0f / 64.0f);
                 float sq = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
+                sq = sum4_lanes16(sq);
                 const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -465,5 +474,7 @@ void gemm_count_launch(bool split);
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);
+// four-wave kernel with 128 x 128 wave tiles, accumulators in AGPRs, hand-laid instruction stream (gemm4h.hip); variant code 5256
+int gemm4h_launch(const GemmArgs& g, int epilogue, hipStream_t s);
 
 }  // namespace showo
