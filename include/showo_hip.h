@@ -26,6 +26,13 @@ int showo_abi_version(void);
 /* number of compute units / wave size of the current device; used by bench/tests for sanity. */
 int showo_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
+/* A HIP stream whose kernels never run on `reserve` of the device's CUs (every (CUs / reserve)-th CU id: spread over the XCDs); 0 = a
+ * plain non-blocking stream.  The data-parallel trainer runs its compute on such a stream while gradient buckets are being
+ * all-reduced, so that RCCL's channel kernels (training/train.py:449,612 through accelerate / DeepSpeed in the reference) find idle
+ * CUs instead of queueing behind full-chip GEMM grids.  Destroy with showo_stream_destroy. */
+int showo_stream_create_cu_mask(int reserve, void** stream_out);
+int showo_stream_destroy(void* stream);
+
 /* per-launch HIP-event timing of the hot kernels (bench.py roofline leg).  kind: 0 = GEMM, 1 = attention,
  * 2 = conv.  read() synchronises the device and returns summed elapsed ms, launch count, summed algorithmic flops. */
 int showo_prof_enable(int on);

@@ -477,32 +477,6 @@ def make_image_ops():
     print("image_ops.npz written (oracle resize == Pillow", PIL.__version__, "byte for byte)")
 
 
-def make_lr_schedules():
-    """learning-rate sequences of the reference's models/lr_schedulers.py (LambdaLR over a torch AdamW)"""
-    import importlib
-    R.load_reference()
-    ls = importlib.import_module("models.lr_schedulers")
-    out = {}
-    cases = [("constant", {}), ("constant_with_warmup", dict(num_warmup_steps=5)),
-             ("linear", dict(num_warmup_steps=5, num_training_steps=40)), ("cosine", dict(num_warmup_steps=7, num_training_steps=40)),
-             ("cosine_with_restarts", dict(num_warmup_steps=3, num_training_steps=40, num_cycles=3)),
-             ("polynomial", dict(num_warmup_steps=4, num_training_steps=30, power=2.0))]
-    for name, kw in cases:
-        p = torch.nn.Parameter(torch.zeros(1))
-        opt = torch.optim.AdamW([p], lr=3e-4)
-        sch = ls.get_scheduler(name, optimizer=opt, **kw)
-        lrs = []
-        for _ in range(50):
-            lrs.append(sch.get_last_lr()[0])
-            opt.step()
-            sch.step()
-        out[name] = np.array(lrs, dtype=np.float64)
-    import json
-    out["cases"] = np.array(json.dumps(cases))
-    np.savez_compressed(os.path.join(GOLD, "lr_schedules.npz"), **out)
-    print("lr_schedules.npz written")
-
-
 def _record_t2i(ref, d, ids_c, ids_u, mask, steps, w, seed):
     """run the REFERENCE t2i_generate with its random draws recorded (multinomial as argmax(p / Exp(1)), Gumbel uniforms) and
     every forward's input ids / logits; returns (result, final input ids, rec)"""
@@ -800,8 +774,6 @@ if __name__ == "__main__":
         make_tiny_showo()
     if a.only in ("", "magvit"):
         make_magvit()
-    if a.only in ("", "lr"):
-        make_lr_schedules()
     if a.only in ("", "image"):
         make_image_ops()
     if a.only in ("", "clip"):

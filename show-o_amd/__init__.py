@@ -19,4 +19,3 @@ from . import image_utils  # noqa: F401
 from .image_utils import image_transform  # noqa: F401
 from . import synthetic  # noqa: F401
 from . import checkpointing  # noqa: F401
-from . import lr_schedulers  # noqa: F401

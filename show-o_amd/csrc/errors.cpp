@@ -99,3 +99,36 @@ extern "C" int showo_prof_read(int kind, double* total_ms, int64_t* launches, do
     if (work) *work = w;
     return 0;
 }
+
+// ---- compute stream that leaves CUs to a concurrent collective -------------------------------------------------------------------
+// Data-parallel training overlaps the RCCL all-reduce of a finished gradient bucket with the backward of the next block.  The GEMM /
+// conv kernels launch one 512-thread block per CU on all 256 CUs; RCCL's channel kernels need CUs of their own, and on a full chip they
+// queue behind whole GEMM tiles.  A stream created with a CU mask keeps `reserve` CUs (spread evenly over the 8 XCDs: every 256/reserve-th
+// CU id) out of every kernel launched on it; RCCL's own streams are unmasked and find those CUs idle.  reserve = 0: plain stream.
+extern "C" int showo_stream_create_cu_mask(int reserve, void** out) {
+    if (!out || reserve < 0) return showo::set_error_msg(1, "stream_create_cu_mask: bad argument");
+    int cus = 0;
+    if (showo_device_info(&cus, nullptr, nullptr, 0)) return 7;
+    if (reserve >= cus) return showo::set_error_msg(1, "stream_create_cu_mask: reserve must be smaller than the CU count");
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (reserve == 0) {
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    } else {
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+        for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+        for (int k = 0; k < reserve; ++k) {
+            const int i = (int)(((int64_t)k * cus) / reserve);
+            mask[i >> 5] &= ~(1u << (i & 31));
+        }
+        e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+    }
+    if (e != hipSuccess) return showo::set_error_hip(e, "stream create (CU mask)", __FILE__, __LINE__);
+    *out = (void*)s;
+    return 0;
+}
+extern "C" int showo_stream_destroy(void* stream) {
+    if (!stream) return 0;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    return e == hipSuccess ? 0 : showo::set_error_hip(e, "hipStreamDestroy", __FILE__, __LINE__);
+}

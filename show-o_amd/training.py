@@ -61,11 +61,24 @@ class GradientExchange:
         self.world = dist.get_world_size(group)
         self.stage = [torch.empty(b.numel(), dtype=torch.bfloat16, device=b.device) for b in buckets] if wire == "bf16" else None
         self.works = []
-        self._measure, self._spans = False, []
+        self._measure, self._spans, self._bspans = False, [], []
 
     def measure(self, on=True):
-        """record the GPU time of every finish() (device events on the compute stream) from now on; exposed_ms() reads the mean"""
-        self._measure, self._spans = bool(on), []
+        """record the GPU time of every finish() (device events on the compute stream) from now on; exposed_ms() reads the mean,
+        exposed_ms_per_bucket() the same split by bucket (wait for that bucket's collective + widening its wire)"""
+        self._measure, self._spans, self._bspans = bool(on), [], []
+
+    def exposed_ms_per_bucket(self):
+        """{bucket index: mean GPU ms per step the compute stream spent waiting for / unpacking that bucket inside finish()}: buckets
+        whose all-reduce hid behind the backward show only their unpack time; None when nothing was measured"""
+        if not self._bspans:
+            return None
+        torch.cuda.synchronize()
+        acc, cnt = {}, {}
+        for b, e0, e1 in self._bspans:
+            acc[b] = acc.get(b, 0.0) + e0.elapsed_time(e1)
+            cnt[b] = cnt.get(b, 0) + 1
+        return {b: acc[b] / cnt[b] for b in sorted(acc)}
 
     def exposed_ms(self):
         """mean GPU time per step that the compute stream spent in finish(): waiting for collectives that did not hide behind the
@@ -98,13 +111,20 @@ class GradientExchange:
             self._spans.append(span)
 
     def _finish(self):
+        timed = self._measure and self.buckets and self.buckets[0].is_cuda
         for w, b in self.works:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if w is not None:
                 w.wait()
             if self.wire == "bf16":
                 self.ops.unpack(self.stage[b], self.buckets[b])
             else:
                 self.ops.scale(self.buckets[b], 1.0 / self.world)
+            if timed:
+                e1.record()
+                self._bspans.append((b, e0, e1))
         self.works = []
 
 
@@ -123,10 +143,15 @@ def train_mask(tr, attention_mask):
 
 class Trainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, coeffs=(1.0, 0.1, 1.0), group=None,
-                 wire="bf16", max_grad_norm=None, force_exchange=False):
+                 wire="bf16", max_grad_norm=None, force_exchange=False, reserve_cus=None):
         """wire: "bf16" | "fp32" gradient wire of the exchange (GradientExchange).  max_grad_norm: global-norm clipping before the
         optimizer (training/train.py:614-615; null in the shipped stage-1 YAMLs).  force_exchange: run the exchange even in a
-        process group of one rank (tests: drives the RCCL path on a single GPU)."""
+        process group of one rank (tests: drives the RCCL path on a single GPU).  reserve_cus: while an exchange is active the step's
+        kernels run on a stream that keeps this many CUs free for RCCL's channel kernels (showo_stream_create_cu_mask; None = the
+        SHOWO_RESERVE_CUS environment variable, default 0 = no mask: profiles/r4_exchange_contention.txt)."""
+        import os
+        self.reserve_cus = int(os.environ.get("SHOWO_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
+        self._masked_stream = None
         self.model, self.lr, self.betas, self.eps, self.wd, self.coeffs, self.group = model, lr, betas, eps, weight_decay, coeffs, group
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
@@ -207,8 +232,45 @@ class Trainer:
         """learning-rate schedulers (training/train.py:303-310 `get_scheduler`) call this between steps"""
         self.lr = float(lr)
 
+    def compute_stream(self):
+        """the CU-masked stream the step runs on while a gradient exchange is active (None: the caller's current stream)"""
+        if self.exchange is None or self.reserve_cus <= 0:
+            return None
+        if self._masked_stream is None:
+            h = C.c_void_p()
+            _lib.check(_lib.load().showo_stream_create_cu_mask(self.reserve_cus, C.byref(h)), "showo_stream_create_cu_mask")
+            self._masked_handle = h
+            self._masked_stream = torch.cuda.ExternalStream(h.value)
+        return self._masked_stream
+
+    def logging_means(self, losses, mask_prob=None):
+        """The reference gathers four tensors per step for logging (training/train.py:603-610: accelerator.gather of the three losses
+        and the masking rate, each repeated batch-size times, then .mean() = the mean over ranks).  Here that is ONE all-reduce of a
+        4-vector, issued next to the gradient buckets; returns a device tensor [loss_t2i, loss_lm, loss_mmu, masking_rate] averaged
+        over the ranks (no host sync).  Without a process group the inputs come back unchanged."""
+        v = torch.cat([losses.detach().float().reshape(3), (mask_prob.detach().float().mean().reshape(1) if mask_prob is not None
+                                                             else torch.zeros(1, device=losses.device))])
+        ex = self.exchange
+        if ex is None or ex.world == 1:
+            return v
+        ex.dist.all_reduce(v, op=ex.dist.ReduceOp.SUM, group=ex.group)
+        return v / ex.world
+
     def step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
         """one optimisation step; returns the three losses (fp32 device tensor [3])"""
+        ms = None
+        if getattr(self, "exchange", None) is not None and self.reserve_cus > 0:
+            ms = self.compute_stream()
+        if ms is None:
+            return self._step(input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length)
+        cur = torch.cuda.current_stream()
+        ms.wait_stream(cur)
+        with torch.cuda.stream(ms):
+            out = self._step(input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length)
+        cur.wait_stream(ms)
+        return out
+
+    def _step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
         # model.trainer() re-uploads parameters whose (data_ptr, version) changed since the last call (load_state_dict, resume,
         # manual edits); the native AdamW below updates them through raw pointers and refreshes the engine images itself
         self.tr = self.model.trainer()
