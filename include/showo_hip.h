@@ -32,6 +32,7 @@ int showo_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_n
  * CUs instead of queueing behind full-chip GEMM grids.  Destroy with showo_stream_destroy. */
 int showo_stream_create_cu_mask(int reserve, void** stream_out);
 int showo_stream_destroy(void* stream);
+int showo_cu_reserved_max(void);  /* largest `reserve` of any masked stream created so far (0 = none) */
 
 /* per-launch HIP-event timing of the hot kernels (bench.py roofline leg).  kind: 0 = GEMM, 1 = attention,
  * 2 = conv.  read() synchronises the device and returns summed elapsed ms, launch count, summed algorithmic flops. */

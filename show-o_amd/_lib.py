@@ -151,6 +151,7 @@ _PROTOS = {
     "showo_vq_get_code": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "showo_stream_create_cu_mask": [c_i, C.POINTER(c_p)],
     "showo_stream_destroy": [c_p],
+    "showo_cu_reserved_max": [],
     "showo_prof_enable": [c_i],
     "showo_prof_reset": [],
     "showo_prof_read": [c_i, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)],

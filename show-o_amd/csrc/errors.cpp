@@ -105,6 +105,10 @@ extern "C" int showo_prof_read(int kind, double* total_ms, int64_t* launches, do
 // conv kernels launch one 512-thread block per CU on all 256 CUs; RCCL's channel kernels need CUs of their own, and on a full chip they
 // queue behind whole GEMM tiles.  A stream created with a CU mask keeps `reserve` CUs (spread evenly over the 8 XCDs: every 256/reserve-th
 // CU id) out of every kernel launched on it; RCCL's own streams are unmasked and find those CUs idle.  reserve = 0: plain stream.
+static int g_cu_reserved_max = 0;
+// largest `reserve` any masked stream of this process was created with: kernels that need every block of a launch resident at once
+// (cooperative split-K reduction) size their residency check by it
+extern "C" int showo_cu_reserved_max(void) { return g_cu_reserved_max; }
 extern "C" int showo_stream_create_cu_mask(int reserve, void** out) {
     if (!out || reserve < 0) return showo::set_error_msg(1, "stream_create_cu_mask: bad argument");
     int cus = 0;
@@ -124,6 +128,7 @@ extern "C" int showo_stream_create_cu_mask(int reserve, void** out) {
         e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
     }
     if (e != hipSuccess) return showo::set_error_hip(e, "stream create (CU mask)", __FILE__, __LINE__);
+    if (reserve > g_cu_reserved_max) g_cu_reserved_max = reserve;
     *out = (void*)s;
     return 0;
 }

@@ -291,10 +291,16 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     if (MF0 == MF1 || wm == 0) {
         Q2_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
+        if constexpr (EPI != EPI_QKV) {
+            if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF0, NFS>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg); return; }
+        }
         if (g.splits > 1 && !splitk_exchange<MF0, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
         epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         Q2_RUN(MF1);
+        if constexpr (EPI != EPI_QKV) {
+            if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF1, NFS>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg); return; }
+        }
         if (g.splits > 1 && !splitk_exchange<MF1, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
         epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
@@ -349,6 +355,19 @@ bool splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
 // variant's own tile count, M = 631 gave S = 10 at 256 rows and S = 6 at 144).  The ring variants (gemm3w) do not split; they are
 // kept out of the candidate list of split shapes (launch2p_bm) for the same reason.
 int64_t g_cnt_gemm2p = 0, g_cnt_qkv_save = 0, g_cnt_splitk = 0;
+// cooperative split-K reduction (gemm_common.h splitk_coop_finish): every block of the launch must be resident at once -- one 512-thread
+// block with 128+ KiB of LDS per CU -- on the CUs that no masked stream of this process keeps free (showo_stream_create_cu_mask).
+// SHOWO_GEMM_COOP=0 restores the last-arriver reduction (A/B runs).
+bool splitk_coop_ok(int blocks) {
+    static int cus = 0, on = -1;
+    if (on < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); on = e ? atoi(e) : 1; }
+    if (!cus) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    return on && blocks <= cus - showo_cu_reserved_max();
+}
 int splitk_count(int M, int N, int K) {
     if (g_gemm_splitk < 0) { const char* e = getenv("SHOWO_GEMM_SPLITK"); g_gemm_splitk = e ? atoi(e) : 1; }
     static int min_kt = 0;  // k-tiles per split at least (SHOWO_GEMM_SPLITK_MIN, default 16)
@@ -387,6 +406,7 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
             return set_error_msg(7, "gemm2p: split-K workspace unavailable (first use of a split shape inside a stream capture, or more than 8 "
                                     "streams): run the shape once eagerly, or set SHOWO_GEMM_SPLITK=0");
         g.splits = S;
+        g.coop = (EPI != EPI_QKV && tiles <= 2048 && splitk_coop_ok(tiles * S)) ? 1 : 0;
         g_cnt_splitk++;
     }
     kfn<<<dim3(tiles * g.splits), dim3(512), SMEM3_BYTES, s>>>(g);
@@ -574,6 +594,7 @@ bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     return splitk_ws(s, need, ws, tick);
 }
 int gemm_splitk_ticks() { return SPLITK_TICKS; }
+bool gemm_splitk_coop_ok(int blocks) { return splitk_coop_ok(blocks); }
 void gemm_count_launch(bool split) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);
     g_cnt_gemm2p++;

@@ -41,6 +41,10 @@ struct GemmArgs {
     // tile's ticket sums the `splits` partials IN SPLIT ORDER (its own included, read back from ws) and runs the ordinary epilogue:
     // the result does not depend on which block arrived last.
     int splits = 1; float4* ws = nullptr; unsigned* tick = nullptr;
+    // coop != 0 (host: tiles x splits <= the CUs this stream may use, one block per CU, so every split of a tile is resident at the same
+    // time): the `splits` blocks of a tile reduce TOGETHER -- each sums and stores the fragments it owns (splitk_coop_finish) -- instead
+    // of the last arriver reading every partial alone at the cross-XCD single-block rate.  Same split order per element: same bits.
+    int coop = 0;
     // gemm_tn only (token-major operands, contraction over rows): rows k >= Klim of both operands read as zero (K = Klim rounded up to 64)
     int Klim = 0;
 };
@@ -180,6 +184,65 @@ static __device__ __forceinline__ bool splitk_exchange(const GemmArgs& g, f32x4 
             }
     }
     return true;
+}
+
+// Cooperative form of the split-K exchange (GemmArgs::coop; plain epilogues only).  All `splits` blocks of a tile are resident at once,
+// so after publishing its partial (as above) a block WAITS for the tile's other partials and then reduces the fragments it owns --
+// fragment f = i * MF + j of every thread belongs to split f % splits -- over all partials IN SPLIT ORDER (the order the last-arriver
+// form uses: identical bits) and stores them with store_frag.  Per block: one tile's worth of partial reads (splits x tile / splits)
+// instead of `splits` tiles in ONE block at 62-70 GB/s (MI355X_MICROARCH.md "handoff-payload"): at M = 516, K = 10 240 (cfg1's
+// dense|fc2 launch, 24 tiles x 10 splits) the serial read of 1.8 MB took about half of the launch.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> vmcnt(0) -> barrier -> one lane: agent release fence ->
+// arrival ticket; then ONE relaxed poll loop -> ONE agent acquire fence -> barrier -> plain loads.  tick[tile] counts arrivals,
+// tick[2048 + tile] departures; the last block to leave zeroes both for the next launch on this stream.
+template <int EPI, int MF, int NFS>
+static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int split, int n0, int wn, int mrow0,
+                                                          int fr, int fg) {
+    const int tid = threadIdx.x;
+    float4* base = g.ws + (size_t)tile * g.splits * NFS * 512;
+    float4* mine = base + (size_t)split * NFS * 512 + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) mine[(i * MF + j) * 512] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(g.tick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(g.tick + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.splits) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 26)) __builtin_trap();  // a sibling split never arrived: the host's residency condition was violated
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fg * 4;
+        float bn[4];
+        load_bias4(g, n, bn);
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            if ((i * MF + j) % g.splits != split) continue;  // block-uniform
+            f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < g.splits; ++sp) {
+                const float4 v = base[(size_t)sp * NFS * 512 + (i * MF + j) * 512 + tid];
+                sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+            }
+            store_frag<EPI>(g, sum, mrow0 + j * 16 + fr, n, bn);
+        }
+    }
+    __syncthreads();  // every partial read of this block has been issued and consumed
+    if (tid == 0) {
+        const unsigned left = __hip_atomic_fetch_add(g.tick + 2048 + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (unsigned)(g.splits - 1)) {  // every sibling has seen the full arrival count and finished reading
+            __hip_atomic_store(g.tick + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.tick + 2048 + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
@@ -470,6 +533,7 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOW
 int gemm_splitk_count(int M, int N, int K);
 bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
 int gemm_splitk_ticks();
+bool gemm_splitk_coop_ok(int blocks);  // tiles x splits blocks can all be resident (one per CU on the CUs no stream mask keeps free)
 void gemm_count_launch(bool split);
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
