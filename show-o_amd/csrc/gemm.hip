@@ -1143,6 +1143,45 @@ struct ConvRow {  // per-lane im2col state of one staged output pixel
     int oy, ox;
 };
 
+// split-K exchange of the conv kernel: gemm_common.h::splitk_exchange for its 4 x 4 fragments per thread (16 float4 = 128 KiB per block).
+// Returns true in the block that runs the epilogue, acc = sum over the splits IN SPLIT ORDER (independent of the arrival order).
+static __device__ __forceinline__ bool conv_splitk_exchange(const GemmArgs& g, f32x4 (&acc)[4][4], int tile, int split, int* s_last) {
+    const int tid = threadIdx.x;
+    float4* base = g.ws + (size_t)tile * g.splits * 16 * 512;
+    float4* mine = base + (size_t)split * 16 * 512 + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * 512] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();  // release: one L2 write-back for the whole block's partial
+        const unsigned old = atomicAdd(g.tick + tile, 1u);
+        const int last = old == (unsigned)(g.splits - 1);
+        if (last) atomicExch(g.tick + tile, 0u);  // ready for the next launch on this stream
+        *s_last = last;
+        if (last) __threadfence();  // acquire
+    }
+    __syncthreads();
+    if (!*s_last) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < g.splits; ++sp) {
+        const float4* p = base + (size_t)sp * 16 * 512 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = p[(i * 4 + j) * 512];
+                acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+            }
+    }
+    return true;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1151,13 +1190,24 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesM = (g.M + CS_AROWS - 1) / CS_AROWS, tilesN = (g.N + CS_WROWS - 1) / CS_WROWS;
     int nwg = tilesM * tilesN, bid = blockIdx.x;
+    // split-K (GemmArgs::splits > 1: the 16 x 16 / 32 x 32 levels of the VQGAN launch 32-128 tiles on 256 CUs, with K = 9 Cin up to 4 608):
+    // the grid is tiles x splits, block (tile, s) accumulates k-tiles [s per, (s + 1) per), the last block of a tile to arrive sums the
+    // partials in split order and runs the epilogue below (GroupNorm statistics included) -- conv_splitk_exchange
+    int split = 0;
+    if (g.splits > 1) { split = bid / nwg; bid -= split * nwg; }
     {
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int tn = bid / tilesM, tm = bid - tn * tilesM;  // pixels fastest: neighbouring blocks share the weight panel
     const int m0 = tm * CS_AROWS, n0 = tn * CS_WROWS;
-    const int nk = g.K / CS_BK;
+    const int nk_all = g.K / CS_BK;
+    int kt0 = 0, nk = nk_all;  // this block's k-tiles: [kt0, nk)
+    if (g.splits > 1) {
+        const int per = (nk_all + g.splits - 1) / g.splits;
+        kt0 = split * per;
+        nk = min(nk_all, kt0 + per);
+    }
     const int grp = wave >> 2, wn = wave & 1, wmg = (wave >> 1) & 1;
     const int arow0 = grp * 128 + wmg * 64;  // first tile row (pixel) of this wave
 
@@ -1297,8 +1347,8 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
         bar_raw_fn();                                                                                             \
     } while (0)
 
-    {   // prologue: all of tile 0
-        CS_TAP(0)
+    {   // prologue: all of this block's first k-tile
+        CS_TAP(kt0)
         CS_DMA_W(0, k0_);
         CS_DMA_A(0, a_lo_row, rlo, ky_, kx_, cb_);
         CS_DMA_A(0, a_lo_row + 32, rhi, ky_, kx_, cb_);
@@ -1306,13 +1356,17 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar_raw_fn();
     if (grp == 1) bar_raw_fn();
-    int t = 0;
+    int t = kt0;
     for (; t + 1 < nk; t += 2) {
         CS_TILE(0, t);
         CS_TILE(1, t + 1);
     }
     if (t < nk) CS_TILE(0, t);
     if (grp == 0) bar_raw_fn();
+    if (g.splits > 1) {
+        __shared__ int s_last;
+        if (!conv_splitk_exchange(g, acc, tn * tilesM + tm, split, &s_last)) return;
+    }
 
     if (c.gn_part == nullptr) {
 #pragma unroll
@@ -1394,7 +1448,26 @@ int launch_conv2p_split(const GemmArgs& g, const ConvArgs& c, hipStream_t s) {
         attr_set = true;
     }
     const int tilesM = (g.M + CS_AROWS - 1) / CS_AROWS, tilesN = (g.N + CS_WROWS - 1) / CS_WROWS;
-    kfn<<<dim3(tilesM * tilesN), dim3(512), CS_SMEM, s>>>(g, c);
+    const int tiles = tilesM * tilesN, nk = g.K / CS_BK;
+    // split-K policy (a function of the problem alone: run-to-run identical bits): launches that fill at most half of the 256 CUs split
+    // K until about one block per CU, every split at least 16 k-tiles (512 of the 9 Cin contraction) long.  SHOWO_CONV_SPLITK=0: off.
+    GemmArgs gs = g;
+    gs.splits = 1;
+    static int splitk_on = -1;
+    if (splitk_on < 0) { const char* e = getenv("SHOWO_CONV_SPLITK"); splitk_on = e ? atoi(e) : 1; }
+    if (splitk_on && tiles * 2 <= 256 && nk >= 32) {
+        int S = 256 / tiles;
+        if (S > nk / 16) S = nk / 16;
+        if (S > 16) S = 16;
+        if (S >= 2) {
+            const int per = (nk + S - 1) / S;
+            S = (nk + per - 1) / per;  // no empty split
+        }
+        if (S >= 2 && tiles * S <= gemm_splitk_ticks() &&
+            gemm_splitk_ws(s, (size_t)tiles * S * 16 * 512 * sizeof(float4), &gs.ws, &gs.tick))
+            gs.splits = S;  // (no workspace -- first use inside a stream capture: the unsplit launch is always valid)
+    }
+    kfn<<<dim3(tiles * gs.splits), dim3(512), CS_SMEM, s>>>(gs, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "conv2p_split launch", __FILE__, __LINE__);
     return 0;

@@ -533,10 +533,15 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     for (int ci = 0; ci < N_VARIANTS; ++ci) cand_ms[ci] = 1e30f;
     static int ring_ok = -1;  // SHOWO_GEMM_RING=0 keeps the 3-deep-ring variants (gemm3w.hip) out of the tuner (A/B runs)
     if (ring_ok < 0) { const char* e = getenv("SHOWO_GEMM_RING"); ring_ok = e ? (atoi(e) != 0) : 1; }
+    // gemm4h (variant 5256) is a candidate only on request (SHOWO_GEMM_4H=1): measured in round 4 it ties the 8-wave kernels on large
+    // cubes and loses on every pipeline shape (profiles/r4b_gemm4h_harness.txt: one wave per SIMD cannot hide its own DMA issue time)
+    static int g4h_ok = -1;
+    if (g4h_ok < 0) { const char* e = getenv("SHOWO_GEMM_4H"); g4h_ok = e ? (atoi(e) != 0) : 0; }
     for (int pass = 0; pass < 2; ++pass) {
         for (int ci = 0; ci < N_VARIANTS; ++ci) {
             const int h = k_variants[ci];
             if (h >= 2000 && (!ring_ok || split_shape)) continue;
+            if (h == 5256 && !g4h_ok) continue;
             int rc = launch2p_h<EPI>(t, h, s);  // warm-up (instruction cache, attribute set)
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, h, s);

@@ -787,3 +787,77 @@ def test_full_width_two_layer_stage1_batch_gradients_vs_oracle_autograd():
         worst = max(worst, (rrms, name))
         assert rrms < 3e-2 and rmax < 1e-1, name
     print(f"[parity] full-width worst gradient rel_rms {worst[0]:.3e} ({worst[1]})")
+
+
+def test_full_size_24_layer_training_gradients_vs_oracle_autograd():
+    """"nothing checks the 24-layer backward against anything".  The FULL model (1.45 B parameters, 24 blocks,
+    vocabulary 58 498) on a 1 t2i + 1 lm + 1 mmu batch x 387 tokens = 1 161 token rows (>= 256: the production GEMM family, the fused
+    save-form projection, the token-major weight-gradient kernel, attention backward at L = 387), every one of the 245 gradient
+    tensors against torch autograd through the fp32 CPU oracle (pinned to the reference's backward by tests/test_oracle_vs_golden.py).
+    Gates: losses 5e-3, logits rel_rms 1e-2 (the forward's bound), every gradient rel_rms <= 6e-2 / rel_max <= 2e-1 -- bf16 operand
+    rounding of a 24-block backward (the 2-layer stage-1 test measures 1.9e-2 and is gated at 3e-2; the noise grows with depth)."""
+    from stub_tokenizer import StubTokenizer
+    P = util.pkg()
+    d = Wt.ShowoDims()
+    sd_np = Wt.make_showo_state(d, seed=0)
+    bt, bl, bm = 1, 1, 1
+    m = util.build_showo(d, sd_np, max_batch=bt + bl + bm, max_seq=387).train()
+    up = P.UniversalPrompting(StubTokenizer(vocab=d.llm_vocab, bos=d.llm_vocab - 10, eos=d.llm_vocab - 10), max_text_len=d.max_text_len,
+                              cond_dropout_prob=0.1)
+    rs = np.random.RandomState(29)
+    words = [f"w{i}" for i in range(400)]
+
+    def text(n):
+        return " ".join(words[j] for j in rs.randint(0, len(words), size=n))
+
+    N = d.num_vq_tokens
+    torch.manual_seed(7)
+    import random
+    random.seed(7)
+    img_t2i = torch.randint(0, d.codebook, (bt, N), device="cuda") + d.image_offset
+    img_mmu = torch.randint(0, d.codebook, (bm, N), device="cuda") + d.image_offset
+    cfg = type("Cfg", (), {"training": type("S", (dict,), {"__getattr__": dict.__getitem__})(min_masking_rate=0.0)})
+    ids, labels, imask, _, (b1, b2, b3) = P.training_utils.build_training_batch(
+        up, cfg, d.mask_token_id, P.cosine_schedule, img_t2i, [text(17)], [text(450)], img_mmu, [text(60)])
+    assert (b1, b2, b3) == (bt, bl, bm) and tuple(ids.shape) == (3, 387)
+    kw = dict(labels=labels, batch_size_t2i=bt, batch_size_lm=bl, batch_size_mmu=bm, max_seq_length=d.max_text_len)
+    _gemm_counters(reset=True)
+    logits, l1, l2, l3 = m(ids, attention_mask=imask, **kw)
+    cnt = _gemm_counters()
+    assert cnt[1] == d.layers and cnt[0] >= 3 * d.layers + 1, cnt  # the fused save-form projection ran in every block
+    (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+    torch.cuda.synchronize()
+    c = ids.cpu()
+    dense = torch.cat([O.mask_t2i(c[:bt], d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=True),
+                       O.mask_t2i(c[bt:bt + bl], d.pad_id, d.soi_id, d.eoi_id, rm_pad_in_image=False),
+                       O.mask_mmu(c[bt + bl:], d.eoi_id)], dim=0)
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch(sd_np).items()}
+    del sd_np
+    import time
+    t0 = time.time()
+    lg, o1, o2, o3 = O.showo_forward(sd, d, c, attention_mask=dense, labels=labels.cpu(), batch_size_t2i=bt, batch_size_lm=bl,
+                                     batch_size_mmu=bm, max_seq_length=d.max_text_len)
+    (1.0 * o1 + 0.1 * o2 + 1.0 * o3).backward()
+    print(f"[parity] full-size 24-layer oracle fwd+bwd on the host: {time.time() - t0:.1f} s")
+    got, want = [float(l1), float(l2), float(l3)], [float(o1), float(o2), float(o3)]
+    print(f"[parity] full-size 24-layer losses {got} oracle {want}")
+    for a, b in zip(got, want):
+        assert abs(a - b) < 5e-3 * abs(b)
+    rmax, rrms = util.relerr(logits, lg.detach())
+    print(f"[parity] full-size 24-layer training-forward logits: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rrms < 1e-2
+    worst, worst_max, by_layer = (0.0, ""), (0.0, ""), {}
+    for name, p in m.named_parameters():
+        if name == "showo.model.embed_tokens.weight":
+            rows = torch.unique(c.reshape(-1))
+            a, b = p.grad[rows.cuda()], sd[name].grad[rows]
+        else:
+            a, b = p.grad, sd[name].grad
+        assert a is not None and b is not None, name
+        rmax, rrms = util.relerr(a, b)
+        worst, worst_max = max(worst, (rrms, name)), max(worst_max, (rmax, name))
+        key = name.split(".")[3] if ".layers." in name else name.split(".")[-2]
+        by_layer[key] = max(by_layer.get(key, 0.0), rrms)
+        assert rrms < 6e-2 and rmax < 2e-1, (name, rrms, rmax)
+    print(f"[parity] full-size 24-layer gradients: worst rel_rms {worst[0]:.3e} ({worst[1]}), worst rel_max {worst_max[0]:.3e} ({worst_max[1]}); "
+          f"worst rel_rms per block / tensor group: " + " ".join(f"{k}:{v:.1e}" for k, v in by_layer.items()))
