@@ -1521,7 +1521,12 @@ static int conv3x3_x3_impl(const uint16_t* x, const uint16_t* xlo, const uint16_
         if (g_conv_split_impl < 0) { const char* e = getenv("SHOWO_CONV_SPLIT_IMPL"); g_conv_split_impl = e ? atoi(e) : 0; }
         static int gn_fuse = -1;  // SHOWO_CONV_GN_FUSE=0: statistics by the separate two-pass reduction (A/B)
         if (gn_fuse < 0) { const char* e = getenv("SHOWO_CONV_GN_FUSE"); gn_fuse = e ? atoi(e) : 1; }
-        const bool phase_split = g_conv_split_impl == 2 || (g_conv_split_impl != 1 && g.M >= 2048);
+        // the phase-split kernel needs enough blocks: 256-pixel tiles x Cout / 128, times its split-K (launch_conv2p_split).  Round 4: with
+        // split-K it also takes the small launches (a single 256 x 256 image has 256 ... 4 096 output pixels on the 16 x 16 ... 64 x 64
+        // levels), which used to fall back to the 128^2 register-staged kernel; SHOWO_CONV_SPLIT_MINM restores a threshold (A/B)
+        static int min_m = -1;
+        if (min_m < 0) { const char* e = getenv("SHOWO_CONV_SPLIT_MINM"); min_m = e ? atoi(e) : 256; }
+        const bool phase_split = g_conv_split_impl == 2 || (g_conv_split_impl != 1 && g.M >= min_m);
         if (phase_split && (int64_t)Cout * g.ldw * 2 < ((int64_t)1 << 32)) {
             if (stats && gn_fuse && (HW % CS_AROWS) == 0 && (Cout % 128) == 0 && Cout <= 1024 && g.vec_out) {
                 c.gn_part = stats + (int64_t)B * 64;  // partials behind the [B, 32, 2] result, like showo_gn_stats

@@ -1,15 +1,28 @@
-// gemm4h: the production bf16 GEMM (C = A W^T, gemm_common.h epilogues) as a FOUR-wave kernel with 128 x 128 wave tiles.
+// gemm4h: the production bf16 GEMM (C = A W^T, gemm_common.h epilogues) as a FOUR-wave kernel with 128 x 128 wave tiles -- the structural
+// experiment of round 4.  Selectable (variant 5256: SHOWO_GEMM_BM=5256, or SHOWO_GEMM_4H=1 for the tuner), NOT the default.
 //
-// Why (profiles/r3n_lds_probe.txt, DESIGN "what comes next" of round 3): the 8-wave kernels (gemm2p / gemm3w: wave tile 64 x 96,
-// two waves per SIMD alternating MFMA and load segments) are bound by LDS read INSTRUCTIONS per MFMA -- 0.42 at their wave tile,
-// and the LDS retires about one wave-instruction per 7 cycles per CU.  A 128 x 128 wave tile needs 0.25 reads per MFMA: per 64-deep
-// k-tile a wave issues 128 MFMAs (2 048 issue cycles on its SIMD), 32 ds_read_b128 and 16 LDS-DMA pieces, so the LDS is busy about
-// 45 % of the time instead of 75 %.  The price is ONE wave per SIMD (256 accumulator registers per lane): nothing hides a stall but
-// the wave's own instruction stream, so the stream is laid out explicitly -- every ds_read and every DMA sits between MFMAs
-// (__builtin_amdgcn_sched_group_barrier pipelines; the ISA is checked by tools/check_gemm4h_isa.py), the fragments of the next
-// k-slab are read while the current slab multiplies (two register sets), and one raw s_barrier per k-tile is all the block-level
-// synchronisation there is.  (Round 3's `gemm4w` had the same tile but staged through VGPRs and left the order to the compiler:
-// 630-908 TF/s.)
+// Hypothesis (profiles/r3n_lds_probe.txt): the 8-wave kernels (gemm2p / gemm3w: wave tile 64 x 96, two waves per SIMD alternating MFMA
+// and load segments) are bound by LDS read INSTRUCTIONS per MFMA (0.42; the LDS retires about one wave-instruction per 7 cycles per
+// CU).  A 128 x 128 wave tile needs 0.25: per 64-deep k-tile a wave issues 128 MFMAs (2 048 issue cycles on its SIMD), 32 ds_read_b128
+// and 16 LDS-DMA pieces.  The price is ONE wave per SIMD (256 accumulator registers per lane): nothing hides a stall but the wave's
+// own instruction stream, so the stream is laid out explicitly -- every ds_read and every DMA sits between MFMAs, the fragments of
+// the next k-slab are read while the current slab multiplies (two register sets), one raw s_barrier per k-tile.
+//
+// How the stream is pinned.  With MFMA builtins the register allocator moved accumulator quads between VGPRs and AGPRs inside the loop
+// (1 120 v_accvgpr moves per 6 k-tiles) and __builtin_amdgcn_sched_group_barrier pipelines were only partly honoured.  Here the MFMAs
+// are `asm volatile` statements with the accumulator as a "+a" operand: the accumulators live in AGPRs for the whole kernel, volatile
+// statements keep their order and memory operations (ds_read, the DMA builtin) are not moved across them, so the SOURCE order is the
+// instruction stream; the compiler still allocates registers and inserts the counted lgkmcnt waits.  tools/check_gemm4h_isa.py audits
+// the .s: 768 MFMA / 192 ds_read / 96 DMA per 6 k-tiles in the pattern MMMR MMMR D, 0 spills, 0 v_accvgpr, only the hand-placed
+// vmcnt(8).
+//
+// Result (profiles/r4b_gemm4h_harness.txt, one MI355X, cold weights): correct -- bit-identical to the 8-wave family, 178 GEMM tests
+// green with the variant forced -- and NOT faster: 1 285 TF/s at 4096^3 (8-wave 256^2: 1 313), 1 035-1 101 on (4128, 14336, 2048) with
+// a plain epilogue (3192: 1 146), 655-670 with the fused QKV epilogue (998: 226 spilled VGPRs in an epilogue nothing overlaps), half
+// the chip idle on N = 2 048 launches (136 tiles).  A k-tile takes ~3 200 cycles against 2 048 of MFMA issue: the 16 LDS-DMA pieces
+// a wave issues per k-tile cost it ~70 cycles each (MI355X_MICROARCH.md "LDS-DMA piece issue cost"), and with one wave per SIMD that
+// time comes straight out of the MFMA stream -- the two-waves-per-SIMD kernels hide it behind the partner's MFMA segment.  LDS read
+// instructions were not the limiter; the HBM -> LDS path is.  (Round 3's `gemm4w`: same tile, VGPR staging, compiler order: 630-908.)
 //
 // Geometry: 256 threads = 4 waves as 2 (m) x 2 (n); block tile 256 (n) x 32 MJ (m), MJ = 16-row fragments per wave (8: 256 rows);
 // v_mfma_f32_16x16x32_bf16 with the weight fragment as the A operand, k order as in gemm2p (slab 0, slab 1 of every k-tile in turn):

@@ -794,8 +794,10 @@ def test_full_size_24_layer_training_gradients_vs_oracle_autograd():
     vocabulary 58 498) on a 1 t2i + 1 lm + 1 mmu batch x 387 tokens = 1 161 token rows (>= 256: the production GEMM family, the fused
     save-form projection, the token-major weight-gradient kernel, attention backward at L = 387), every one of the 245 gradient
     tensors against torch autograd through the fp32 CPU oracle (pinned to the reference's backward by tests/test_oracle_vs_golden.py).
-    Gates: losses 5e-3, logits rel_rms 1e-2 (the forward's bound), every gradient rel_rms <= 6e-2 / rel_max <= 2e-1 -- bf16 operand
-    rounding of a 24-block backward (the 2-layer stage-1 test measures 1.9e-2 and is gated at 3e-2; the noise grows with depth)."""
+    Gates: losses 5e-3, logits rel_rms 1e-2 (the forward's bound), every gradient rel_rms <= 7e-2 / rel_max <= 2e-1 -- bf16 operand
+    rounding of a 24-block backward (the 2-layer stage-1 test measures 1.9e-2 and is gated at 3e-2; the noise grows with depth).
+    Measured (r4e): worst rel_rms 5.6e-2 (layers.16.self_attn.k_layernorm.bias, a 64-element tensor), 2.2e-2 ... 5.6e-2 by block,
+    embedding 1.0e-2, lm_head 6.8e-3, worst rel_max 5.6e-2; gate = measured + 25 %.  Oracle forward + backward: 50 s on the host."""
     from stub_tokenizer import StubTokenizer
     P = util.pkg()
     d = Wt.ShowoDims()
@@ -858,6 +860,6 @@ def test_full_size_24_layer_training_gradients_vs_oracle_autograd():
         worst, worst_max = max(worst, (rrms, name)), max(worst_max, (rmax, name))
         key = name.split(".")[3] if ".layers." in name else name.split(".")[-2]
         by_layer[key] = max(by_layer.get(key, 0.0), rrms)
-        assert rrms < 6e-2 and rmax < 2e-1, (name, rrms, rmax)
+        assert rrms < 7e-2 and rmax < 2e-1, (name, rrms, rmax)
     print(f"[parity] full-size 24-layer gradients: worst rel_rms {worst[0]:.3e} ({worst[1]}), worst rel_max {worst_max[0]:.3e} ({worst_max[1]}); "
           f"worst rel_rms per block / tensor group: " + " ".join(f"{k}:{v:.1e}" for k, v in by_layer.items()))
