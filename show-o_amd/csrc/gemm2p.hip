@@ -358,6 +358,11 @@ int64_t g_cnt_gemm2p = 0, g_cnt_qkv_save = 0, g_cnt_splitk = 0;
 // cooperative split-K reduction (gemm_common.h splitk_coop_finish): every block of the launch must be resident at once -- one 512-thread
 // block with 128+ KiB of LDS per CU -- on the CUs that no masked stream of this process keeps free (showo_stream_create_cu_mask).
 // SHOWO_GEMM_COOP=0 restores the last-arriver reduction (A/B runs).
+int splitk_coop_mode() {  // SHOWO_GEMM_COOP: 1 = plain stores + release fence, 2 = write-through (sc1) partial stores, no fence
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); m = e ? atoi(e) : 1; }
+    return m == 2 ? 2 : 1;
+}
 bool splitk_coop_ok(int blocks) {
     static int cus = 0, on = -1;
     if (on < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); on = e ? atoi(e) : 1; }
@@ -406,7 +411,7 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
             return set_error_msg(7, "gemm2p: split-K workspace unavailable (first use of a split shape inside a stream capture, or more than 8 "
                                     "streams): run the shape once eagerly, or set SHOWO_GEMM_SPLITK=0");
         g.splits = S;
-        g.coop = (EPI != EPI_QKV && tiles <= 2048 && splitk_coop_ok(tiles * S)) ? 1 : 0;
+        g.coop = (EPI != EPI_QKV && tiles <= 2048 && splitk_coop_ok(tiles * S)) ? splitk_coop_mode() : 0;
         g_cnt_splitk++;
     }
     kfn<<<dim3(tiles * g.splits), dim3(512), SMEM3_BYTES, s>>>(g);

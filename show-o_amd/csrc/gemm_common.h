@@ -201,15 +201,33 @@ static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32
     const int tid = threadIdx.x;
     float4* base = g.ws + (size_t)tile * g.splits * NFS * 512;
     float4* mine = base + (size_t)split * NFS * 512 + tid;
+    if (g.coop == 2) {
+        // write-through (sc1) stores of the partial: the bytes leave the XCD's L2 as they are stored, so no release fence (an L2
+        // write-back of up to 180 KB of fresh lines per block) is needed in front of the ticket (Guideline 16 R1 / "publish-large")
+        // (wave-uniform descriptor: the slab of this split; the lane's 16 bytes are selected by the voffset)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(base + (size_t)split * NFS * 512), 0, -1, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < MF; ++j) mine[(i * MF + j) * 512] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            for (int j = 0; j < MF; ++j) {
+                u32x4 v;
+                v[0] = __float_as_uint(acc[i][j][0]); v[1] = __float_as_uint(acc[i][j][1]);
+                v[2] = __float_as_uint(acc[i][j][2]); v[3] = __float_as_uint(acc[i][j][3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, tid * 16, (i * MF + j) * 512 * 16, 16 /* sc1 */);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) mine[(i * MF + j) * 512] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g.coop != 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __hip_atomic_fetch_add(g.tick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(g.tick + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.splits) {
