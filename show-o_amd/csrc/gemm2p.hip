@@ -358,10 +358,10 @@ int64_t g_cnt_gemm2p = 0, g_cnt_qkv_save = 0, g_cnt_splitk = 0;
 // cooperative split-K reduction (gemm_common.h splitk_coop_finish): every block of the launch must be resident at once -- one 512-thread
 // block with 128+ KiB of LDS per CU -- on the CUs that no masked stream of this process keeps free (showo_stream_create_cu_mask).
 // SHOWO_GEMM_COOP=0 restores the last-arriver reduction (A/B runs).
-int splitk_coop_mode() {  // SHOWO_GEMM_COOP: 1 = plain stores + release fence, 2 = write-through (sc1) partial stores, no fence
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); m = e ? atoi(e) : 1; }
-    return m == 2 ? 2 : 1;
+int splitk_coop_mode() {  // SHOWO_GEMM_COOP: 2 (default) = write-through (sc1) partial stores, no fence; 1 = plain stores + release fence
+    static int m = -1;        // (r4g, one box: dense|fc2 at M = 631 72 -> 61 us, batch-1 t2i 66.0 -> 63.2 ms per image; same bits)
+    if (m < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); m = e ? atoi(e) : 2; }
+    return m == 1 ? 1 : 2;
 }
 bool splitk_coop_ok(int blocks) {
     static int cus = 0, on = -1;
