@@ -460,6 +460,17 @@ def main():
         # ceilings measured in THIS run (measured_ceilings above: hipBLASLt through torch.matmul on the forward's dominant shapes and the
         # library's float4 copy kernel): printed next to the spec peak the fraction is taken against
         measured_peak = ceilings
+        # MFMA busy fraction of the two per-layer GEMM launches from the PMC pass over this command (north_star: "rocprof showing ... MFMA
+        # utilisation on the transformer blocks"): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); same staleness guard
+        mfma_pmc = None
+        try:
+            mj = json.load(open(os.path.join(ROOT, "profiles", "pmc", "r4z_mfma_util.json")))
+            if mj.get("kernel_src_sha1") == gemm_src_sha1():
+                top = sorted(((k, v) for k, v in mj["kernels"].items() if k.startswith("gemm")), key=lambda kv: -kv[1]["dispatches"] * kv[1]["avg_us"])[:2]
+                mfma_pmc = {"source": "profiles/pmc/r4z_mfma_util.json (" + mj["formula"] + ")",
+                            "kernels": {k: {"mfma_busy_frac": round(v["mfma_busy_frac"], 4), "avg_us_profiled": round(v["avg_us"], 1)} for k, v in top}}
+        except (OSError, KeyError, TypeError, ValueError):
+            pass
         ach = fl_gemm.value / (ms_gemm.value * 1e-3) / 1e12 if ms_gemm.value > 0 else 0.0
         out = {
             "metric": "t2i images/sec @256x256 (18 denoise steps)", "value": value, "unit": "images/s", "n_gpus": world,
@@ -475,7 +486,7 @@ def main():
                        # utilisation -- `roofline.frac` is
                        "algorithmic_tflop_per_image": 38.4, "reference_flops_rate_tflops_skipped_work_included": value * 38.4},
             "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM; per layer ONE [Wqkv;W1] projection with the QKV / GELU split epilogue and ONE K-concatenated dense|fc2 residual GEMM; lm_head rows)",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "measured_peak": measured_peak, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "measured_peak": measured_peak, "mfma_busy_pmc": mfma_pmc, "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "launches": int(n_all.value), "timed_launches": int(n_gemm.value),
                          "avg_launch_ms": ms_gemm.value / max(1, n_gemm.value),
