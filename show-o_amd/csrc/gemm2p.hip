@@ -612,6 +612,8 @@ bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);
     return splitk_ws(s, need, ws, tick);
 }
+// the same for callers that run UNDER gemm2p_dispatch's lock (gemm3w.hip's stream-K launch): g_gemm_mu is not recursive
+bool gemm_splitk_ws_locked(hipStream_t s, size_t need, float4** ws, unsigned** tick) { return splitk_ws(s, need, ws, tick); }
 int gemm_splitk_ticks() { return SPLITK_TICKS; }
 bool gemm_splitk_coop_ok(int blocks) { return splitk_coop_ok(blocks); }
 void gemm_count_launch(bool split) {

@@ -67,7 +67,7 @@ static __device__ __forceinline__ void sk_collect(const GemmArgs& g, f32x4 (&acc
         unsigned spins = 0;
         while (__hip_atomic_load(g.tick + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nparts - 1)) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 26)) __builtin_trap();  // a publisher never ran: the host's residency condition was violated
+            if (++spins > (1u << 22)) __builtin_trap();  // (seconds) a publisher never ran: the host's residency condition was violated
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(g.tick + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every publisher of this tile has arrived
@@ -422,7 +422,8 @@ int launch3w_sk(const GemmArgs& g0, hipStream_t s) {
     }
     constexpr int NFS = 4 * 5;
     const int tiles = ((g.M + 159) / 160) * ((g.N + B2 - 1) / B2);
-    if (tiles > 2048 || !gemm_splitk_ws(s, (size_t)tiles * 2 * NFS * 512 * sizeof(float4), &g.ws, &g.tick))
+    // (called under gemm2p_dispatch's lock: the non-locking accessor)
+    if (tiles > 2048 || !gemm_splitk_ws_locked(s, (size_t)tiles * 2 * NFS * 512 * sizeof(float4), &g.ws, &g.tick))
         return set_error_msg(7, "gemm3w stream-K: partial-tile workspace unavailable (first use of the shape inside a stream capture, or more than "
                                 "8 streams): run the shape once eagerly, or set SHOWO_GEMM_SK=0");
     kfn<<<dim3(cus), dim3(512), SMEM3W_BYTES, s>>>(g);

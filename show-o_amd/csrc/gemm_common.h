@@ -550,6 +550,7 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOW
 // split-K policy and per-stream workspace of the production family (gemm2p.hip), shared with gemm_tn.hip
 int gemm_splitk_count(int M, int N, int K);
 bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
+bool gemm_splitk_ws_locked(hipStream_t s, size_t need, float4** ws, unsigned** tick);  // caller already holds the GEMM dispatch lock
 int gemm_splitk_ticks();
 bool gemm_splitk_coop_ok(int blocks);  // tiles x splits blocks can all be resident (one per CU on the CUs no stream mask keeps free)
 void gemm_count_launch(bool split);
