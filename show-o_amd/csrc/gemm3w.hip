@@ -43,9 +43,10 @@ __device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 // k = 0 end publishes its accumulators (write-through stores + arrival ticket: Guideline 16, as splitk_coop_finish); the block that
 // computed the range starting at k = 0 -- the LAST thing it does, while the others did theirs FIRST -- collects them in part order.
 template <int MF, int NFS>
-static __device__ __forceinline__ void sk_publish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int part) {
+static __device__ __forceinline__ void sk_publish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int blk) {
+    // a block publishes at most ONE partial per launch (its first segment, or its only one): the slab is indexed by the publishing block
     const int tid = threadIdx.x;
-    float4* slab = g.ws + ((size_t)tile * 2 + (part - 1)) * NFS * 512;
+    float4* slab = g.ws + (size_t)blk * NFS * 512;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slab), 0, -1, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -61,7 +62,7 @@ static __device__ __forceinline__ void sk_publish(const GemmArgs& g, f32x4 (&acc
     if (tid == 0) __hip_atomic_fetch_add(g.tick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int MF, int NFS>
-static __device__ __forceinline__ void sk_collect(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int nparts) {
+static __device__ __forceinline__ void sk_collect(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int nparts, int blk) {
     const int tid = threadIdx.x;
     if (tid == 0) {
         unsigned spins = 0;
@@ -74,7 +75,7 @@ static __device__ __forceinline__ void sk_collect(const GemmArgs& g, f32x4 (&acc
     }
     __syncthreads();
     for (int p = 1; p < nparts; ++p) {  // part order = increasing k: the fp32 sum of an element is the same chain on every run
-        const float4* slab = g.ws + ((size_t)tile * 2 + (p - 1)) * NFS * 512 + tid;
+        const float4* slab = g.ws + (size_t)(blk + p) * NFS * 512 + tid;  // part p of this tile was computed by block blk + p
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -86,9 +87,9 @@ static __device__ __forceinline__ void sk_collect(const GemmArgs& g, f32x4 (&acc
 }
 
 // one tile (or, in a stream-K launch, the k-tiles [kbeg, kend) of one tile); role 0 = whole tile, 1 = owner of a shared tile (its range
-// starts at k = 0: collects the other parts, runs the epilogue), 2 = publisher of part `part` >= 1
+// starts at k = 0: collects the parts of blocks blk + 1 .. blk + nparts - 1, runs the epilogue), 2 = publisher (blk = this block)
 template <int EPI, int MF0, int MF1, bool NS, bool BL>
-static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t* smem, int bid, int kbeg, int kend, int role, int part, int nparts) {
+static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t* smem, int bid, int kbeg, int kend, int role, int blk, int nparts) {
     static_assert(NS ? (MF0 >= MF1 && MF1 >= 3 && MF0 <= 6) : (MF0 >= 5 && MF0 <= 8 && MF1 >= 4 && MF1 <= 8),
                   "m-split: each group needs 4 lo fragments, group 0 at least one hi fragment; n-split: at most 6 fragments per group");
     constexpr int BK = GEMM_BK;
@@ -303,13 +304,13 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
     if (MF0 == MF1 || wm == 0) {
         R_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-        if (role == 2) { sk_publish<MF0, NFS>(g, acc, bid, part); return; }
-        if (role == 1) sk_collect<MF0, NFS>(g, acc, bid, nparts);
+        if (role == 2) { sk_publish<MF0, NFS>(g, acc, bid, blk); return; }
+        if (role == 1) sk_collect<MF0, NFS>(g, acc, bid, nparts, blk);
         epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         R_RUN(MF1);
-        if (role == 2) { sk_publish<MF1, NFS>(g, acc, bid, part); return; }
-        if (role == 1) sk_collect<MF1, NFS>(g, acc, bid, nparts);
+        if (role == 2) { sk_publish<MF1, NFS>(g, acc, bid, blk); return; }
+        if (role == 1) sk_collect<MF1, NFS>(g, acc, bid, nparts, blk);
         epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef R_RUN
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
             const int nparts = b_last - b_first + 1, part = bid - b_first;
             if (!first_seg) __syncthreads();  // the previous segment's epilogue staged through the LDS this segment's DMAs overwrite
             first_seg = false;
-            gemm3w_segment<EPI, MF0, MF1, NS, BL>(g, smem, tile, k0, k1, nparts == 1 ? 0 : (part == 0 ? 1 : 2), part, nparts);
+            gemm3w_segment<EPI, MF0, MF1, NS, BL>(g, smem, tile, k0, k1, nparts == 1 ? 0 : (part == 0 ? 1 : 2), bid, nparts);
             u += k1 - k0;
         }
     }
@@ -423,7 +424,7 @@ int launch3w_sk(const GemmArgs& g0, hipStream_t s) {
     constexpr int NFS = 4 * 5;
     const int tiles = ((g.M + 159) / 160) * ((g.N + B2 - 1) / B2);
     // (called under gemm2p_dispatch's lock: the non-locking accessor)
-    if (tiles > 2048 || !gemm_splitk_ws_locked(s, (size_t)tiles * 2 * NFS * 512 * sizeof(float4), &g.ws, &g.tick))
+    if (tiles > 2048 || !gemm_splitk_ws_locked(s, (size_t)cus * NFS * 512 * sizeof(float4), &g.ws, &g.tick))  // one slab per block
         return set_error_msg(7, "gemm3w stream-K: partial-tile workspace unavailable (first use of the shape inside a stream capture, or more than "
                                 "8 streams): run the shape once eagerly, or set SHOWO_GEMM_SK=0");
     kfn<<<dim3(cus), dim3(512), SMEM3W_BYTES, s>>>(g);
@@ -435,7 +436,7 @@ int launch3w_sk(const GemmArgs& g0, hipStream_t s) {
 }  // namespace
 
 // Stream-K is chosen by RULE (a function of the problem and the CU count, never of a timing race): no split-K shape, a contraction of at
-// least 48 k-tiles, 128 ... 2 048 tiles of 160 rows (so that a tile spans at most three blocks and two partial slabs per tile suffice), and
+// least 48 k-tiles, 128 ... 2 048 tiles of 160 rows (a block's range is then at least half a tile: a tile spans at most three blocks), and
 // a one-tile-per-block grid that would waste at least 8 % of its last round.  On the t2i path that is the dense|fc2 launch (M = 4 128:
 // 208 tiles on 256 CUs; M = 6 192: 312); in training the forward dense|fc2, the data gradients through W1 / Wqkv and the lm_head.
 bool gemm3w_sk_rule(int M, int N, int K) {
