@@ -98,12 +98,6 @@ int showo_gemm_tn_bf16(const uint16_t* A, int lda, const uint16_t* B, int ldb, f
  * (ceil(T / 32) + 8) * C floats.  Deterministic (per-64-row partials in row order, then a fixed two-level sum). */
 int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float* colpart, float* colsum, int accumulate, void* stream);
 
-/* 1 when the production GEMM runs the (M, N, K) problem (any epilogue but the fused QKV one) as a STREAM-K launch: one block per CU, every
- * block the same number of k-tile units, partial tiles handed over through a workspace and summed in a fixed order (gemm3w.hip).  A rule
- * of the problem and the CU count -- never of the tuner's timing race -- so the bits of a shape are the same in every process; they
- * differ from the one-tile-per-block kernels in the fp32 association at the part boundaries.  SHOWO_GEMM_SK=0 turns the rule off. */
-int showo_gemm_stream_k_rule(int M, int N, int K);
-
 /* Launch counters of the production GEMM family (gemm2p / gemm3w): out3[0] = launches, out3[1] = of those the fused [Wqkv ; W1]
  * save-for-backward form (showo_gemm_qkv_fc1_save_bf16), out3[2] = launches that split K; reset != 0 zeroes them after reading.
  * Parity tests use it to assert that a training batch ran the T >= 256 kernels that the benchmark times. */

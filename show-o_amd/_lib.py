@@ -34,7 +34,6 @@ _PROTOS = {
     "showo_gemm_set_impl": [c_i],
     "showo_gemm_tune": [c_i, c_i, c_p],
     "showo_gemm_counters": [c_p, c_i],
-    "showo_gemm_stream_k_rule": [c_i, c_i, c_i],
     "showo_attn_set_impl": [c_i],
     "showo_decode_set_impl": [c_i],
     "showo_mask_predict_next": [c_p, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_p, c_p, c_p, c_p],

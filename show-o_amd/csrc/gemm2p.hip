@@ -427,10 +427,9 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
 //   n-split on the ring: 3192 (6+6), 3176 (6+5), 3160 (5+5), 3144 (5+4)
 //   the same with buffer-descriptor DMAs: 4192, 4176, 4160, 4144
 //   four waves x 128 x 128 wave tiles, 256-row tiles with short bodies for a ragged last tile row (gemm4h.hip): 5256
-//   stream-K form of 4160 (one block per CU, gemm3w.hip): 6160 -- selected by rule (gemm3w_sk_rule), listed here for the harness only
-constexpr int N_VARIANTS = 26;
+constexpr int N_VARIANTS = 25;
 const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144,
-                                    4192, 4176, 4160, 4144, 5256, 6160};
+                                    4192, 4176, 4160, 4144, 5256};
 bool is_variant(int v) {
     for (int i = 0; i < N_VARIANTS; ++i)
         if (k_variants[i] == v) return true;
@@ -440,10 +439,6 @@ bool is_variant(int v) {
 template <int EPI>
 int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
     if (h == 5256) return gemm4h_launch(g, EPI, s);
-    if (h == 6160) {
-        if constexpr (EPI == EPI_QKV) return set_error_msg(1, "gemm: the stream-K variant has plain epilogues only");
-        else return gemm3w_sk_launch(g, EPI, s);
-    }
     if (h >= 2000) return gemm3w_launch(g, EPI, h - 2000, s);
     switch (h) {
         case 240: return launch2p<EPI, 8, 7, false>(g, s);
@@ -515,9 +510,6 @@ template <int EPI>
 int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     if (g_gemm_bm == 0) pick_bm(g.M, g.N);  // reads SHOWO_GEMM_BM
     if (g_gemm_bm > 0) return launch2p_h<EPI>(g, g_gemm_bm, s);
-    if constexpr (EPI != EPI_QKV) {
-        if (gemm3w_sk_rule(g.M, g.N, g.K)) return gemm3w_sk_launch(g, EPI, s);  // stream-K shapes bypass the tuner (reproducible bits)
-    }
     if (g_gemm_tune < 0) { const char* e = getenv("SHOWO_GEMM_TUNE"); g_gemm_tune = e ? atoi(e) : 1; }
     const auto key = std::make_tuple(g.M, g.N, g.K, EPI);
     const bool split_shape = splitk_count(g.M, g.N, g.K) >= 2;  // ring variants never split: not candidates (bit-identity, see above)
@@ -555,7 +547,6 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
             const int h = k_variants[ci];
             if (h >= 2000 && (!ring_ok || split_shape)) continue;
             if (h == 5256 && !g4h_ok) continue;
-            if (h == 6160) continue;  // stream-K is a rule, not a candidate: its bits differ from the one-tile-per-block family
             int rc = launch2p_h<EPI>(t, h, s);  // warm-up (instruction cache, attribute set)
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, h, s);
@@ -612,8 +603,6 @@ bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);
     return splitk_ws(s, need, ws, tick);
 }
-// the same for callers that run UNDER gemm2p_dispatch's lock (gemm3w.hip's stream-K launch): g_gemm_mu is not recursive
-bool gemm_splitk_ws_locked(hipStream_t s, size_t need, float4** ws, unsigned** tick) { return splitk_ws(s, need, ws, tick); }
 int gemm_splitk_ticks() { return SPLITK_TICKS; }
 bool gemm_splitk_coop_ok(int blocks) { return splitk_coop_ok(blocks); }
 void gemm_count_launch(bool split) {
@@ -642,9 +631,6 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
 }
 
 }  // namespace showo
-
-// 1 when showo_gemm_bf16 / showo_gemm_kcat_bf16 run the (M, N, K) problem as a stream-K launch (gemm3w_sk_rule: plain epilogues only)
-extern "C" int showo_gemm_stream_k_rule(int M, int N, int K) { return showo::gemm3w_sk_rule(M, N, K) ? 1 : 0; }
 
 // Launch counters of the production GEMM family (tests assert that a batch took the T >= 256 branch the bench times):
 // out[0] = launches through gemm2p_dispatch (gemm2p / gemm3w kernels), out[1] = of those, the fused [Wqkv ; W1] save-for-backward form

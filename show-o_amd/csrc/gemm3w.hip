@@ -39,57 +39,8 @@ __device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-// ---- stream-K hand-off of a partial tile (SK launches, see gemm3w_kernel).  A block that computed a k-range of a tile WITHOUT its
-// k = 0 end publishes its accumulators (write-through stores + arrival ticket: Guideline 16, as splitk_coop_finish); the block that
-// computed the range starting at k = 0 -- the LAST thing it does, while the others did theirs FIRST -- collects them in part order.
-template <int MF, int NFS>
-static __device__ __forceinline__ void sk_publish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int blk) {
-    // a block publishes at most ONE partial per launch (its first segment, or its only one): the slab is indexed by the publishing block
-    const int tid = threadIdx.x;
-    float4* slab = g.ws + (size_t)blk * NFS * 512;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slab), 0, -1, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MF; ++j) {
-            u32x4 v;
-            v[0] = __float_as_uint(acc[i][j][0]); v[1] = __float_as_uint(acc[i][j][1]);
-            v[2] = __float_as_uint(acc[i][j][2]); v[3] = __float_as_uint(acc[i][j][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, tid * 16, (i * MF + j) * 512 * 16, 16 /* sc1: write-through */);
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(g.tick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <int MF, int NFS>
-static __device__ __forceinline__ void sk_collect(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int nparts, int blk) {
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(g.tick + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(nparts - 1)) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 22)) __builtin_trap();  // (seconds) a publisher never ran: the host's residency condition was violated
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(g.tick + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every publisher of this tile has arrived
-    }
-    __syncthreads();
-    for (int p = 1; p < nparts; ++p) {  // part order = increasing k: the fp32 sum of an element is the same chain on every run
-        const float4* slab = g.ws + (size_t)(blk + p) * NFS * 512 + tid;  // part p of this tile was computed by block blk + p
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < MF; ++j) {
-                const float4 v = slab[(i * MF + j) * 512];
-                acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
-            }
-    }
-}
-
-// one tile (or, in a stream-K launch, the k-tiles [kbeg, kend) of one tile); role 0 = whole tile, 1 = owner of a shared tile (its range
-// starts at k = 0: collects the parts of blocks blk + 1 .. blk + nparts - 1, runs the epilogue), 2 = publisher (blk = this block)
 template <int EPI, int MF0, int MF1, bool NS, bool BL>
-static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t* smem, int bid, int kbeg, int kend, int role, int blk, int nparts) {
+__global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
     static_assert(NS ? (MF0 >= MF1 && MF1 >= 3 && MF0 <= 6) : (MF0 >= 5 && MF0 <= 8 && MF1 >= 4 && MF1 <= 8),
                   "m-split: each group needs 4 lo fragments, group 0 at least one hi fragment; n-split: at most 6 fragments per group");
     constexpr int BK = GEMM_BK;
@@ -98,9 +49,16 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
     constexpr int NPW = (NA + 7) / 8;
     constexpr int NAO = NS ? NPW : 4;
     constexpr int NHI = NS ? 1 : 2 * (MF0 - 4) + 2 * (MF1 - 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
     int tn, tm;
     {
         const int per = g.gn * tilesM;
@@ -111,7 +69,7 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
         tn = first + (rem - tm * gsz);
     }
     const int m0 = tm * BMT, n0 = tn * B2;
-    const int nk = kend;  // the k-tiles of this segment are [kbeg, nk)
+    const int nk = g.K / BK;
     const bool g_stage = !(g.flags & 8);  // bf16 epilogues store through LDS (full 128-B lines); flags bit 3 = direct stores (A/B)
     const int wn = wave & 3, wm = wave >> 2;
     const int gbase = wm * 16 * MF0;
@@ -268,13 +226,13 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
         bar_raw_fn();                                                                                             \
     } while (0)
 
-    // ---- prologue: all of the first k-tile and the weights of the second (the latter may still be in flight: retired by ph1's wait)
-    R_DMA_W(0, 0, kbeg * BK);
-    R_DMA_W(0, 1, kbeg * BK);
-    R_DMA_A(0, 0, NAO, kbeg * BK);
-    if (kbeg + 1 < nk) {
-        R_DMA_W(1, 0, (kbeg + 1) * BK);
-        R_DMA_W(1, 1, (kbeg + 1) * BK);
+    // ---- prologue: all of tile 0 and the weights of tile 1 (the latter may still be in flight: retired by ph1(0)'s wait)
+    R_DMA_W(0, 0, 0);
+    R_DMA_W(0, 1, 0);
+    R_DMA_A(0, 0, NAO, 0);
+    if (nk > 1) {
+        R_DMA_W(1, 0, BK);
+        R_DMA_W(1, 1, BK);
         R_WAIT(4);
     } else {
         R_WAIT(0);
@@ -285,7 +243,7 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
 #define R_ANY(WB, AB, T, MFG) do { if constexpr (NS) { RN_TILE(WB, AB, T, MFG); } else { R_TILE(WB, AB, T, MFG); } } while (0)
 #define R_RUN(MFG)                                                                                                \
     do {                                                                                                          \
-        int t = kbeg;                                                                                             \
+        int t = 0;                                                                                                \
         for (; t + 5 < nk; t += 6) {                                                                              \
             R_ANY(0, 0, t, MFG);                                                                                  \
             R_ANY(1, 1, t + 1, MFG);                                                                              \
@@ -300,17 +258,12 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
         if (t + 3 < nk) R_ANY(0, 1, t + 3, MFG);                                                                  \
         if (t + 4 < nk) R_ANY(1, 0, t + 4, MFG);                                                                  \
     } while (0)
-    constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
     if (MF0 == MF1 || wm == 0) {
         R_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-        if (role == 2) { sk_publish<MF0, NFS>(g, acc, bid, blk); return; }
-        if (role == 1) sk_collect<MF0, NFS>(g, acc, bid, nparts, blk);
         epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         R_RUN(MF1);
-        if (role == 2) { sk_publish<MF1, NFS>(g, acc, bid, blk); return; }
-        if (role == 1) sk_collect<MF1, NFS>(g, acc, bid, nparts, blk);
         epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef R_RUN
@@ -327,52 +280,12 @@ static __device__ __forceinline__ void gemm3w_segment(const GemmArgs& g, bf16_t*
 #undef R_DMA_W
 }
 
-// SK = false: one tile per block (grid = tiles).  SK = true, STREAM-K (round 4): the grid is one block per CU and block c owns the
-// k-tile units [c per, (c + 1) per) of the launch's tiles x (K / 64) units in tile order -- every CU does the same amount of MFMA work
-// whatever the tile count (a 208-tile launch no longer leaves 48 CUs idle, 4.81 rounds no longer cost 5).  A block's range is the
-// TAIL of one tile, whole tiles, and the HEAD of another; it runs them in that order, so a tile's tail parts are published early and
-// its head -- computed LAST by the block that owns the tile -- never waits for them in practice (sk_publish / sk_collect).  The
-// k-partition is a function of (M, N, K, tile height, CU count) only: identical bits on every run; they differ from the one-tile-per-
-// block kernels in the fp32 association at the part boundaries, which is why the host selects SK by RULE, not by the tuner's race.
-template <int EPI, int MF0, int MF1, bool NS, bool BL, bool SK>
-__global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-    constexpr int BMT = 16 * (MF0 + MF1);
-    const int tilesM = (g.M + BMT - 1) / BMT, tilesN = (g.N + B2 - 1) / B2;
-    const int nwg = SK ? (int)gridDim.x : tilesM * tilesN;
-    int bid = blockIdx.x;
-    {
-        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int nk = g.K / GEMM_BK;
-    if constexpr (!SK) {
-        gemm3w_segment<EPI, MF0, MF1, NS, BL>(g, smem, bid, 0, nk, 0, 0, 1);
-    } else {
-        const int total = tilesM * tilesN * nk;
-        const int per = (total + nwg - 1) / nwg;
-        const int u1 = min(total, (bid + 1) * per);
-        bool first_seg = true;
-        for (int u = bid * per; u < u1;) {
-            const int tile = u / nk, k0 = u - tile * nk;
-            const int k1 = min(nk, k0 + (u1 - u));
-            const int b_first = (tile * nk) / per, b_last = ((tile + 1) * nk - 1) / per;
-            const int nparts = b_last - b_first + 1, part = bid - b_first;
-            if (!first_seg) __syncthreads();  // the previous segment's epilogue staged through the LDS this segment's DMAs overwrite
-            first_seg = false;
-            gemm3w_segment<EPI, MF0, MF1, NS, BL>(g, smem, tile, k0, k1, nparts == 1 ? 0 : (part == 0 ? 1 : 2), bid, nparts);
-            u += k1 - k0;
-        }
-    }
-}
-
 constexpr int SMEM3W_BYTES = 5 * 256 * 64 * 2;  // 160 KiB
 
 template <int EPI, int MF0, int MF1, bool NS, bool BL = false>
 int launch3w(const GemmArgs& g, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm3w_kernel<EPI, MF0, MF1, NS, BL, false>;
+    auto kfn = gemm3w_kernel<EPI, MF0, MF1, NS, BL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3W_BYTES);
         if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm3w)", __FILE__, __LINE__);
@@ -404,60 +317,7 @@ int launch3w_h(const GemmArgs& g, int rows, hipStream_t s) {
     return launch3w<EPI, 8, 8, false>(g, s);
 }
 
-// stream-K launch: n-split 5 + 5 (160-row tiles) on the ring with buffer-descriptor DMAs, one block per CU
-template <int EPI>
-int launch3w_sk(const GemmArgs& g0, hipStream_t s) {
-    GemmArgs g = g0;
-    static bool attr_set = false;
-    auto kfn = gemm3w_kernel<EPI, 5, 5, true, true, true>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3W_BYTES);
-        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm3w stream-K)", __FILE__, __LINE__);
-        attr_set = true;
-    }
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-    }
-    constexpr int NFS = 4 * 5;
-    const int tiles = ((g.M + 159) / 160) * ((g.N + B2 - 1) / B2);
-    // (called under gemm2p_dispatch's lock: the non-locking accessor)
-    if (tiles > 2048 || !gemm_splitk_ws_locked(s, (size_t)cus * NFS * 512 * sizeof(float4), &g.ws, &g.tick))  // one slab per block
-        return set_error_msg(7, "gemm3w stream-K: partial-tile workspace unavailable (first use of the shape inside a stream capture, or more than "
-                                "8 streams): run the shape once eagerly, or set SHOWO_GEMM_SK=0");
-    kfn<<<dim3(cus), dim3(512), SMEM3W_BYTES, s>>>(g);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_error_hip(e, "gemm3w stream-K launch", __FILE__, __LINE__);
-    return 0;
-}
-
 }  // namespace
-
-// Stream-K is chosen by RULE (a function of the problem and the CU count, never of a timing race): no split-K shape, a contraction of at
-// least 48 k-tiles, 128 ... 2 048 tiles of 160 rows (a block's range is then at least half a tile: a tile spans at most three blocks), and
-// a one-tile-per-block grid that would waste at least 8 % of its last round.  On the t2i path that is the dense|fc2 launch (M = 4 128:
-// 208 tiles on 256 CUs; M = 6 192: 312); in training the forward dense|fc2, the data gradients through W1 / Wqkv and the lm_head.
-bool gemm3w_sk_rule(int M, int N, int K) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("SHOWO_GEMM_SK"); on = e ? atoi(e) : 1; }
-    const int nk = K / GEMM_BK;
-    if (!on || (K % GEMM_BK) || nk < 48 || gemm_splitk_count(M, N, K) >= 2) return false;
-    const int tiles = ((M + 159) / 160) * ((N + B2 - 1) / B2);
-    if (tiles < 128 || tiles > 2048) return false;
-    const int rounds = (tiles + 255) / 256;
-    return rounds * 256 * 100 >= tiles * 108 && gemm_splitk_coop_ok(256);
-}
-int gemm3w_sk_launch(const GemmArgs& g, int epilogue, hipStream_t s) {
-    switch (epilogue) {
-        case SHOWO_EPI_BF16: return launch3w_sk<SHOWO_EPI_BF16>(g, s);
-        case SHOWO_EPI_GELU_BF16: return launch3w_sk<SHOWO_EPI_GELU_BF16>(g, s);
-        case SHOWO_EPI_F32: return launch3w_sk<SHOWO_EPI_F32>(g, s);
-        case SHOWO_EPI_RESID_F32: return launch3w_sk<SHOWO_EPI_RESID_F32>(g, s);
-    }
-    return set_error_msg(1, "gemm3w stream-K: plain epilogues only");
-}
 
 // variant codes 2256 / 2240 / 2224 / 2208 (m-split), 3192 / 3176 / 3160 / 3144 (n-split) and 4192 / 4176 / 4160 / 4144 (n-split,
 // buffer-descriptor DMAs) of gemm2p's tile table

@@ -550,16 +550,12 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOW
 // split-K policy and per-stream workspace of the production family (gemm2p.hip), shared with gemm_tn.hip
 int gemm_splitk_count(int M, int N, int K);
 bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
-bool gemm_splitk_ws_locked(hipStream_t s, size_t need, float4** ws, unsigned** tick);  // caller already holds the GEMM dispatch lock
 int gemm_splitk_ticks();
 bool gemm_splitk_coop_ok(int blocks);  // tiles x splits blocks can all be resident (one per CU on the CUs no stream mask keeps free)
 void gemm_count_launch(bool split);
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);
-// stream-K form of the n-split 5 + 5 ring kernel (gemm3w.hip): chosen by gemm3w_sk_rule, never by the tuner; variant code 6160 (harness)
-bool gemm3w_sk_rule(int M, int N, int K);
-int gemm3w_sk_launch(const GemmArgs& g, int epilogue, hipStream_t s);
 // four-wave kernel with 128 x 128 wave tiles, accumulators in AGPRs, hand-laid instruction stream (gemm4h.hip); variant code 5256
 int gemm4h_launch(const GemmArgs& g, int epilogue, hipStream_t s);
 

@@ -763,37 +763,6 @@ def test_gemm_tn_fast_form_ignores_nan_padding_rows(M, N, T):
     assert err < 2e-5 * float(ref.abs().max()) * max(1.0, (T / 512) ** 0.5), err
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(2080, 4096, 3072, 3), (2080, 4096, 3072, 0), (4128, 2048, 10240, 3), (4100, 2048, 4096, 2),
-                                       (11223, 2048, 6144, 0)])
-def test_gemm_stream_k_rule_shapes(M, N, K, epi):
-    """Stream-K launches of the production GEMM (gemm3w.hip: one block per CU, equal k-tile units per block, partial tiles published and
-    collected in part order): the shapes the rule selects -- 208 tiles x 48 k-tiles (39 units per block: tiles shared by two or THREE blocks),
-    the t2i dense|fc2 shape, a ragged M, a training data-gradient shape -- against fp64 on the same bf16 operands (all rows for the small
-    shape, 96 sampled rows otherwise), run-to-run identical bits, and within fp32 re-association noise of the one-tile-per-block kernel."""
-    lib = util.pkg()._lib.load()
-    assert lib.showo_gemm_stream_k_rule(M, N, K) == 1
-    assert lib.showo_gemm_stream_k_rule(300, N, K) == 0 and lib.showo_gemm_stream_k_rule(M, N, 1024) == 0
-    torch.manual_seed(M + K + epi)
-    A, W, bias = torch.randn(M, K), torch.randn(N, K) * 0.05, torch.randn(N)
-    resid = torch.randn(M, N) if epi == 3 else None
-    rows = torch.arange(M) if M * K * N <= 2080 * 3072 * 4096 else torch.randperm(M)[:96]
-    ref = bf16_round(A[rows]).double() @ bf16_round(W).double().T + bias.double()
-    if epi == 3:
-        ref = ref + resid[rows].double()
-    scale = float(ref.abs().max())
-    a = _gemm(A, W, bias, epi, resid=resid)
-    b = _gemm(A, W, bias, epi, resid=resid)
-    assert torch.equal(a, b)  # the partition and the sum order are functions of the shape only
-    tol = 2 ** -8 * scale if epi == 0 else 2e-5 * scale * max(1.0, (K / 2048) ** 0.5)
-    assert float((a[rows].double() - ref).abs().max()) < tol
-    try:  # the same problem on the one-tile-per-block kernel of the same tile (variant 4160)
-        L().call("showo_gemm_tune", 8, 4160 << 8, None)
-        c = _gemm(A, W, bias, epi, resid=resid)
-    finally:
-        L().call("showo_gemm_tune", 8, 0, None)
-    assert float((a.double() - c.double()).abs().max()) < (2 ** -7 * scale if epi == 0 else 2e-5 * scale)
-
-
 SPLITK_OFF, SPLITK_ON = 64, 128  # showo_gemm_tune flag bits
 
 
