@@ -68,6 +68,18 @@ def _worker(rank, world, port, out):
         both = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(both, mine)
         ok = ok and all(torch.equal(both[0], t) for t in both)
+        # measurement hooks on CPU buckets: nothing is timed (device events only), the accessors say so instead of failing
+        ex.measure(True)
+        ok = ok and ex.exposed_ms() is None and ex.exposed_ms_per_bucket() is None
+    # Trainer.logging_means: the reference's four logging gathers (training/train.py:603-610) as ONE all-reduce of a 4-vector
+    import types
+    fake = types.SimpleNamespace(exchange=showo_amd.training.GradientExchange([torch.zeros(1)], dist, None, wire="fp32", ops=TorchWireOps))
+    losses = torch.tensor([1.0, 2.0, 3.0]) * (rank + 1)
+    means = showo_amd.Trainer.logging_means(fake, losses, torch.full((5,), 0.25 * (rank + 1)))
+    want = torch.tensor([1.0, 2.0, 3.0, 0.25]) * (sum(range(1, world + 1)) / world)
+    ok = ok and bool(torch.allclose(means, want))
+    fake1 = types.SimpleNamespace(exchange=None)
+    ok = ok and bool(torch.equal(showo_amd.Trainer.logging_means(fake1, losses)[:3], losses))
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
