@@ -24,13 +24,35 @@ __global__ void lfq_pack_nchw_kernel(const float* __restrict__ z, int64_t* __res
     ids[t] = id;
 }
 
-__global__ void lfq_pack_nhwc_kernel(const float* __restrict__ z, int64_t* __restrict__ ids, int C, int ldz, int64_t total) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const float* zp = z + t * ldz;
-    int64_t id = 0;
-    for (int c = 0; c < C; ++c) id = (id << 1) | (zp[c] > 0.0f ? 1 : 0);
-    ids[t] = id;
+// NHWC ([tokens][ldz] floats, the layout the encoder's last convolution leaves): a token's channels are ldz consecutive floats, so "one
+// thread per token" makes every load instruction of a wave touch 64 different lines (2.6 TB/s measured, profiles/pmc/r4y_vq_hbm_rocprof.txt).
+// Here a block owns 256 tokens = one contiguous run of 256 ldz floats: the threads stream it with consecutive 16-byte loads (every
+// wave-instruction reads 1 KiB of consecutive bytes), park the 0/1 sign tests as bytes in LDS, and thread t then packs the C bytes of
+// token t (MSB = channel 0, models/modeling_magvitv2.py:201-206) and stores ids[t]: consecutive 8-byte stores.
+__global__ __launch_bounds__(256) void lfq_pack_nhwc_kernel(const float* __restrict__ z, int64_t* __restrict__ ids, int C, int ldz, int64_t total) {
+    __shared__ __attribute__((aligned(16))) unsigned char bits[256 * 64];
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * 256;
+    const int nt = (int)(total - t0 < 256 ? total - t0 : 256);
+    const int nf = nt * ldz;
+    const float* zb = z + t0 * ldz;  // 256 ldz floats per block: 16-byte aligned whenever z is
+    int done = 0;
+    if ((((uintptr_t)zb) & 15) == 0) {
+        const int nv = nf >> 2;
+        for (int i = tid; i < nv; i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(zb)[i];
+            reinterpret_cast<uint32_t*>(bits)[i] = (v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 0x100u : 0u) | (v.z > 0.0f ? 0x10000u : 0u) | (v.w > 0.0f ? 0x1000000u : 0u);
+        }
+        done = nv << 2;
+    }
+    for (int i = done + tid; i < nf; i += 256) bits[i] = zb[i] > 0.0f ? 1 : 0;
+    __syncthreads();
+    if (tid < nt) {
+        const unsigned char* bp = bits + tid * ldz;
+        int64_t id = 0;
+        for (int c = 0; c < C; ++c) id = (id << 1) | bp[c];
+        ids[t0 + tid] = id;
+    }
 }
 
 __global__ void lfq_unpack_nchw_kernel(const int64_t* __restrict__ ids, float* __restrict__ zq, int C, int hw, int64_t total) {
@@ -54,7 +76,7 @@ extern "C" int showo_lfq_pack_nchw(const float* z, int64_t* ids, int B, int C, i
 extern "C" int showo_lfq_pack_nhwc(const float* z, int64_t* ids, int B, int C, int hw, int ldz, void* stream) {
     int64_t total = (int64_t)B * hw;
     if (total == 0) return 0;
-    if (C < 1 || C > 62 || ldz < C) return set_error_msg(1, "lfq: bad C/ldz");
+    if (C < 1 || C > 62 || ldz < C || ldz > 64) return set_error_msg(1, "lfq: bad C/ldz (1 <= C <= 62, C <= ldz <= 64)");
     lfq_pack_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(z, ids, C, ldz, total);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;

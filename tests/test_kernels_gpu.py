@@ -52,6 +52,13 @@ def test_lfq_pack_unpack_bit_exact():
     ids2 = torch.empty_like(ids)
     L().call("showo_lfq_pack_nhwc", L().ptr(znhwc), L().ptr(ids2), 8, 13, 1024, 13, S())
     assert torch.equal(ids, ids2)
+    # padded rows (ldz = 16: the bench's bandwidth shape) and a token count that is not a multiple of the 256-token block, NaN in the pad
+    zpad = torch.full((8 * 1024, 16), float("nan"), device="cuda")
+    zpad[:, :13] = znhwc.reshape(-1, 13)
+    for ntok in (8 * 1024, 8 * 1024 - 77, 3):
+        ids3 = torch.full((ntok,), -1, dtype=torch.int64, device="cuda")
+        L().call("showo_lfq_pack_nhwc", L().ptr(zpad), L().ptr(ids3), 1, 13, ntok, 16, S())
+        assert torch.equal(ids3, ids.reshape(-1)[:ntok])
     # property at full size: unpack(pack(z)) == sign pattern, pack(unpack(id)) == id over the whole codebook
     allids = torch.arange(8192, dtype=torch.int64, device="cuda").reshape(2, 4096)
     zq = torch.empty((2, 13, 4096), dtype=torch.float32, device="cuda")
