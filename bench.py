@@ -479,7 +479,8 @@ def main():
             "config": {"workload": (f"BASELINE cfg{2 if B == 8 else 1}{'' if B in (1, 8) else ' shape'}: configs/showo_demo.yaml t2i 256x256, batch {B} prompt{'s' if B > 1 else ''}, "
                                     f"CFG 5.0 (forward on [{2 * B},387]), 18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M"),
                        "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
-                       "launch_mode": "hipGraph replay of the denoise steps (cached on the engine)" if a.graph else "eager",
+                       "launch_mode": ("eager launches (accuracy mode does not capture graphs)" if a.precision else
+                                       "hipGraph replay of the denoise steps (cached on the engine)" if a.graph else "eager"),
                        "precision": "accuracy mode (split-bf16 GEMMs, fp32 attention)" if a.precision else "bf16 operands, fp32 accumulation",
                        # SURVEY.md §8d counts the REFERENCE's flops (38.4 TFLOP per image: text rows recomputed every step, lm_head over
                        # the full vocabulary); the path skips most of that work (prefix reuse, restricted head), so this rate is NOT MFMA
