@@ -33,6 +33,9 @@ struct ConvArgs {
     // double [M / 256][32][2] (requires Hout * Wout % 256 == 0: a 256-pixel tile never straddles two images), gn_cpg = Cout / 32
     double* gn_part = nullptr;
     int gn_cpg = 0;
+    // conv2p_split only: 3 = hi*hi + hi*lo + lo*hi (default, ~2^-17 operands); 2 drops the lo(weight) * hi(activation) product
+    // (SHOWO_CONV_PRODUCTS=2: the measurement VERDICT r3 #3c asked for -- it does not stay inside the 2e-4 gates, see DESIGN)
+    int products = 3;
 };
 
 // ---- activation-operand loaders: setup(i, m) once per staged row, load(i, k) per k-tile -> 16-B chunk
@@ -1308,9 +1311,11 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
                 acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], al[j], acc[i][(MB) + j], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
-                acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][(MB) + j], 0, 0, 0); \
+        if (c.products == 3) {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+                    acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][(MB) + j], 0, 0, 0); \
+        }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
     // tap / channel base of k-tile T (Cin % 32 == 0: a k-tile never straddles two taps)
@@ -1526,6 +1531,9 @@ static int conv3x3_x3_impl(const uint16_t* x, const uint16_t* xlo, const uint16_
         // levels), which used to fall back to the 128^2 register-staged kernel; SHOWO_CONV_SPLIT_MINM restores a threshold (A/B)
         static int min_m = -1;
         if (min_m < 0) { const char* e = getenv("SHOWO_CONV_SPLIT_MINM"); min_m = e ? atoi(e) : 256; }
+        static int products = 0;
+        if (!products) { const char* e = getenv("SHOWO_CONV_PRODUCTS"); products = (e && atoi(e) == 2) ? 2 : 3; }
+        c.products = products;
         const bool phase_split = g_conv_split_impl == 2 || (g_conv_split_impl != 1 && g.M >= min_m);
         if (phase_split && (int64_t)Cout * g.ldw * 2 < ((int64_t)1 << 32)) {
             if (stats && gn_fuse && (HW % CS_AROWS) == 0 && (Cout % 128) == 0 && Cout <= 1024 && g.vec_out) {
