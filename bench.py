@@ -136,7 +136,52 @@ def measured_ceilings(L):
     src, dst = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"), torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
     t = timed(lambda: L.call("showo_copy_b128", L.ptr(src), L.ptr(dst), src.numel(), L.stream()), 6)
     out["hbm_TBps_copy"] = 2 * src.numel() / t / 1e12
+    del src, dst
+    try:
+        out["power_wall_probe_4096x4096x8192_tflops"] = power_wall_probe(L, timed, g)
+    except Exception as ex:  # a probe, never the reason a bench line is lost
+        out["power_wall_probe_4096x4096x8192_tflops"] = {"error": repr(ex)}
     return out
+
+
+def power_wall_probe(L, timed, g):
+    """The same launches on random-normal and on all-zero bf16 operands (256 tiles of 256 x 256 = one round on 256 CUs, K = 8192, weights
+    rotated): identical instruction streams, but zero operands draw far less switching power, so the power-managed clock stays high.
+    The ratio zero / random is the share of the GEMM rate that the chip's power budget (not the kernel's stall cycles) takes on real
+    data; first measured in profiles/r4n_power_vs_bandwidth.txt (own ring kernel 1 480 -> 1 875 TF/s, +27 %).  hipBLASLt through
+    torch.matmul and the library's own kernel through its C ABI (tuner on)."""
+    M, N, K = 4096, 4096, 8192
+    fl = 2.0 * M * N * K / 1e12
+    probe = {}
+    for tag in ("random", "zero"):
+        if tag == "random":
+            a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            ws = [torch.randn(N, K, device="cuda", generator=g).to(torch.bfloat16) for _ in range(4)]
+        else:
+            a = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+            ws = [torch.zeros(N, K, device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+        o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        i = [0]
+
+        def blas():
+            i[0] = (i[0] + 1) % len(ws)
+            return torch.matmul(a, ws[i[0]].t())
+
+        def own():
+            i[0] = (i[0] + 1) % len(ws)
+            L.call("showo_gemm_bf16", L.ptr(a), K, L.ptr(ws[i[0]]), K, None, 0, L.ptr(o), N, None, 0, M, N, K, 0, L.stream())
+        probe[f"blas_{tag}_operands"] = fl / timed(blas, 12)
+        try:
+            own()  # first call of the shape: the tile tuner times its variants here, outside the timed repeats
+            probe[f"own_{tag}_operands"] = fl / timed(own, 12)
+        except Exception as ex:
+            probe[f"own_{tag}_operands"] = repr(ex)
+        del a, ws, o
+    for k in ("blas", "own"):
+        r, z = probe.get(f"{k}_random_operands"), probe.get(f"{k}_zero_operands")
+        if isinstance(r, float) and isinstance(z, float) and r > 0:
+            probe[f"{k}_zero_over_random"] = z / r
+    return probe
 
 
 def child_line(argv, timeout_s, env=None):

@@ -113,6 +113,19 @@ int main(int argc, char** argv) {
             {631, 2048, 10240, 3, "prefill dense|fc2"}, {631, 14336, 2048, 0, "prefill qkv|fc1"},
         };
     }
+    if (quick == 7) {  // row-range split of the half-empty dense|fc2 launch (DESIGN "what comes next" 2a): 4128 rows as ONE launch (208 tiles, no
+                       // split) against rows [0, 4096) (128 tiles x 2 k-halves = 256 blocks on the cooperative reduction) + the 32-row tail
+        shapes = {
+            {4128, 2048, 10240, 3, "dense|fc2 4128"}, {4096, 2048, 10240, 3, "rows 0..4095"}, {32, 2048, 10240, 3, "rows 4096..4127"},
+            {6192, 2048, 10240, 3, "dense|fc2 6192"}, {6144, 2048, 10240, 3, "rows 0..6143"}, {48, 2048, 10240, 3, "rows 6144..6191"},
+        };
+    }
+    if (quick == 8) {  // half chip vs full chip at 256-row tiles, K = 8192: with GEMM_BENCH_ZERO=1 (all-zero operands: far less switching power,
+                       // same instruction stream) this separates a clock / power bound from a shared-bandwidth bound on the k-tile time
+        shapes = {
+            {4096, 2048, 8192, 0, "128 tiles (half chip)"}, {4096, 4096, 8192, 0, "256 tiles (1 round)"}, {8192, 4096, 8192, 0, "512 tiles (2 rounds)"},
+        };
+    }
     if (quick == 3) {  // decomposition of the tile time at 192-row tiles (variant x192): exactly 256 tiles per round at N = 2048
         shapes = {
             {6144, 2048, 2048, 0, "1 round K2048"}, {6144, 2048, 4096, 0, "1 round K4096"}, {6144, 2048, 8192, 0, "1 round K8192"},
@@ -198,6 +211,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&out_ref, nO * 4)); CK(hipMalloc(&out, nO * 4));
         fill_kernel<<<1024, 256, 0, st>>>(A, nA, 1u, 1.0f);
         fill_kernel<<<1024, 256, 0, st>>>(W, nW * R, 2u, 0.02f);
+        if (getenv("GEMM_BENCH_ZERO") && atoi(getenv("GEMM_BENCH_ZERO"))) { CK(hipMemsetAsync(A, 0, nA * 2, st)); CK(hipMemsetAsync(W, 0, nW * 2 * R, st)); }
         {   // bias / resid: reuse the generator through a bf16 temp is overkill; small host fill
             std::vector<float> hb(s.N); for (int i = 0; i < s.N; ++i) hb[i] = 0.01f * ((i * 37) % 101 - 50);
             CK(hipMemcpy(bias, hb.data(), s.N * 4, hipMemcpyHostToDevice));
@@ -269,7 +283,7 @@ int main(int argc, char** argv) {
     }
 
     // ---- fused entry points: K-concatenated residual GEMM and the [Wqkv ; W1] projection, checked against the separate launches
-    if (quick != 3 && quick != 4) for (int M : {4128, 6192, 700}) {
+    if (quick != 3 && quick != 4 && quick < 7) for (int M : {4128, 6192, 700}) {
         const int H = 2048, F = 8192, nH = 32, B = M == 700 ? 2 : 16, L = M / B, Lp = ((L + 63) / 64) * 64;
         const int Mx = B * L;
         uint16_t *attn, *ffn, *Wd, *W2, *Wcat, *h, *Wq1, *Q0, *K0, *V0, *Q1, *K1, *V1, *f0, *f1;
