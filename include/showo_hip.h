@@ -175,6 +175,17 @@ int showo_gemm_qkv_fc1_save_bf16(const uint16_t* A, int lda, const uint16_t* Wqk
                                  uint16_t* raw_qkv, int ldraw, uint16_t* ffn_pre, uint16_t* ffn_out, int ldf, int F, int B, int L,
                                  int nH, int rot, float eps, int pos0, int Lcap, int Lp, int w_tiled, void* stream);
 
+/* Accuracy-mode form of showo_gemm_qkv_fc1_bf16 on the same kernels.  Operands are K-concatenated split images: A3 bf16 [M, Kcat]
+ * = [a_hi | a_lo | a_hi] (Kcat = 3 K), W3 rows [w_hi | w_hi | w_lo] ([3 nH 64 + F, Kcat], tiled when w_tiled) -- one bf16 GEMM whose
+ * fp32 accumulators receive hi*hi + lo*hi + hi*lo.  Every output is a (hi, lo) bf16 pair with hi = RNE(v), lo = RNE(v - hi):
+ * Q / Qlo, K / Klo, Vt / Vtlo (layouts of showo_qk_prep), ffn_out / ffn_lo = gelu_new(A W1^T + b1) with IEEE exp and division
+ * (both halves with leading dimension ldf).  Reference: models/phi.py:657-694, 208-212 in fp32 (inference_t2i.py:67). */
+int showo_gemm_qkv_fc1_split(const uint16_t* A3, int lda, const uint16_t* W3, int ldw, int Kcat, const float* bias,
+                             const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                             const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* Qlo, uint16_t* K, uint16_t* Klo,
+                             uint16_t* Vt, uint16_t* Vtlo, uint16_t* ffn_out, uint16_t* ffn_lo, int ldf, int F, int B, int L,
+                             int nH, int rot, float eps, int pos0, int Lcap, int Lp, int w_tiled, void* stream);
+
 /* K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias) with A0 bf16 [M,K0] (lda0), A1 bf16 [M,K1] (lda1) and
  * weight rows [W0[n,:] | W1[n,:]] bf16 [N, ldw] (ldw >= K0 + K1; K0, K1 multiples of 64).  epilogue must be SHOWO_EPI_RESID_F32
  * (out fp32 = acc + bias + resid, in place allowed).
@@ -235,6 +246,13 @@ int showo_decode_set_impl(int impl);
 int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                    void* stream);
+
+/* Accuracy-mode attention: Q, K, V^T and the output as (hi, lo) bf16 pairs (same layouts as showo_attn_fwd; O / Olo share ldo);
+ * S = Khi Qhi + Khi Qlo + Klo Qhi, fp32 soft-max, O = Vhi Phi + Vhi Plo + Vlo Phi with P split in registers: the fp32 SDPA of
+ * models/phi.py:715-722 to ~1e-5 on the MFMA.  Any Lq >= 1. */
+int showo_attn_fwd_split(const uint16_t* Q, const uint16_t* Qlo, const uint16_t* K, const uint16_t* Klo, const uint16_t* Vt,
+                         const uint16_t* Vtlo, const int32_t* iv, const int32_t* flag, const float* dense_mask, uint16_t* O,
+                         uint16_t* Olo, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo, void* stream);
 
 /* Training forward: showo_attn_fwd that also writes lse fp32 [B, nH, Lq] = log sum_k exp(score) of every (masked) row. */
 int showo_attn_fwd_lse(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
@@ -397,16 +415,24 @@ int showo_engine_t2i_captures(const showo_engine* e);
  * embedded input, slot i = output of transformer block i - 1), so that a test can check each block against the oracle evaluated on
  * the block's own input as the GPU computed it (no error amplification across blocks). */
 int showo_engine_set_collect(showo_engine* e, float* buf);
-/* Accuracy mode.  precision 0 (default, the timed path): bf16 GEMM / attention operands, fp32 accumulation.  precision 1: the
- * reference's fp32 inference (inference_t2i.py:67 keeps the model in fp32; models/phi.py:1182-1183 returns fp32 logits) to ~1e-4 end
- * to end -- every GEMM on the split-bf16 MFMA kernel (hi + lo operand pairs, see showo_gemm_bf16x3), LayerNorm / q,k-LayerNorm /
- * RoPE / attention / gelu_new in fp32 on the vector ALU.  Covers showo_engine_forward, _forward_rows and _t2i_generate (eager steps,
- * no prefix cache); the KV-cached decode entry points refuse (the Python mmu_generate runs the reference's no-cache algorithm
- * through _forward_rows instead).  The weights must be uploaded (showo_engine_load) AFTER switching to
- * precision 1 -- the loader then also keeps their low halves; showo_engine_precise_ready tells whether they are current. */
+/* Accuracy mode.  precision 0 (default): bf16 GEMM / attention operands, fp32 accumulation.  precision 1: the reference's fp32
+ * inference (inference_t2i.py:67 keeps the model in fp32; models/phi.py:1182-1183 returns fp32 logits) to ~1e-5 end to end with
+ * split-bf16 operands (x = hi + lo to 2^-17, products hi*hi + lo*hi + hi*lo accumulated in fp32).
+ * Production form (showo_engine_precise_fast() == 1: rotary_dim 32, 3 * hidden a multiple of 256 -- Phi-1.5's shape): the SAME
+ * kernels and launch structure as precision 0 on K-concatenated split images -- activations [hi | lo | hi], weight rows
+ * [hi | hi | lo], one bf16 GEMM over 3K per product (showo_gemm_qkv_fc1_split, showo_gemm_kcat_bf16), split attention
+ * (showo_attn_fwd_split) -- so every entry point works in this mode, including prefix reuse and hipGraph replay in _t2i_generate and
+ * the KV-cached prefill / decode (decode steps run eagerly).  Otherwise (tiny test shapes, SHOWO_PRECISE_FAST=0) the fp32 reference
+ * kernels of csrc/precise.hip serve forward / forward_rows / t2i_generate and the KV-cached entry points refuse.
+ * The weights must be uploaded (showo_engine_load) AFTER switching to precision 1 -- the loader then also keeps their low halves;
+ * showo_engine_precise_ready tells whether they are current. */
 int showo_engine_set_precision(showo_engine* e, int precision);
 int showo_engine_get_precision(const showo_engine* e);
 int showo_engine_precise_ready(const showo_engine* e);
+int showo_engine_precise_fast(const showo_engine* e);
+/* process-wide A/B switch of the two accuracy-mode implementations (default: SHOWO_PRECISE_FAST, on): 0 = always the fp32 reference
+ * kernels of csrc/precise.hip.  Call showo_engine_set_precision(e, 1) again after switching it on (workspaces are made there). */
+int showo_precise_set_fast(int on);
 /* Showo.forward without labels (modeling_showo.py:76-79 -> phi.py:953-1183):
  * ids int64 [B,L] or embeds fp32 [B,L,H] (exactly one non-NULL); mask fp32 [B,1,L,L] or NULL (causal);
  * logits fp32 [B,L,vocab]. */

@@ -91,6 +91,9 @@ _PROTOS = {
                                 c_f, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_qkv_fc1_save_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i,
                                      c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_qkv_fc1_split": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i,
+                                 c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "showo_attn_fwd_split": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_kcat_bf16": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_gemm_tile_weight": [c_p, c_i, c_i, c_i, c_p, c_p],
     "showo_qk_prep": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
@@ -119,6 +122,8 @@ _PROTOS = {
     "showo_engine_set_precision": [c_p, c_i],
     "showo_engine_get_precision": [c_p],
     "showo_engine_precise_ready": [c_p],
+    "showo_engine_precise_fast": [c_p],
+    "showo_precise_set_fast": [c_i],
     "showo_engine_use_intervals": [c_p, c_p, c_p],
     "showo_engine_forward": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "showo_engine_forward_rows": [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p],

@@ -163,6 +163,9 @@ struct AttnArgs {
     float* lse;  // optional (training): log-sum-exp of every score row, fp32 [B, nH, Lq]
     const int* pos_dev;  // graph replay of a decode step (Lq = 1): Lk = *pos_dev + 1 read on the device
     int nqb = 0;  // LDS-tiled form launched as a 1-D grid of nqb * nH * B blocks in the XCD-aware order below (0: 3-D grid (qb, head, b))
+    // accuracy mode (attn_lds_body<SPLIT>): low halves of the operands (same layouts) and of the output
+    const bf16_t *Qlo = nullptr, *Klo = nullptr, *Vtlo = nullptr;
+    bf16_t* Olo = nullptr;
 };
 
 // XCD-aware block order of the LDS-tiled forward.  Hardware places block `id` on XCD `id % 8`, each XCD has its own 4 MiB L2.  With
@@ -333,8 +336,12 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // WPB = waves (32-row query tiles) per block: 4, or 5 when that saves a block per (batch, head) -- at Lq = 258 (the 18-step t2i
 // loop: <soi> + 256 image tokens + <eoi>) the ninth query tile would otherwise get a block of its own that streams every K / V^T
 // tile for 2 rows.  Waves 0..3 stage the tiles; a fifth wave only consumes them.
-template <bool DENSE, int WPB>
+// SPLIT (accuracy mode, showo_attn_fwd_split): Q, K, V^T arrive as (hi, lo) bf16 pairs; S = Khi Qhi + Khi Qlo + Klo Qhi and
+// O = Vhi Phi + Vhi Plo + Vlo Phi with P split in registers (P - bf16(P) rounded to bf16): three MFMAs per fragment pair, fp32
+// softmax as before -> the fp32 SDPA of models/phi.py:715-722 to ~1e-5.  LDS holds four tiles per stage (K, V^T, Klo, V^Tlo).
+template <bool DENSE, int WPB, bool SPLIT = false>
 __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int* s_hull) {
+    constexpr int NT = SPLIT ? 4 : 2;  // tiles per stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int qb_, head, b;
     attn_block_coords(a, qb_, head, b);
@@ -345,11 +352,16 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     const int qrow = qrow_raw < a.Lq ? qrow_raw : a.Lq - 1;
     const int64_t bh = (int64_t)b * a.nH + head;
 
-    bf16x8 qf[4];
+    bf16x8 qf[4], qfl[SPLIT ? 4 : 1];
     {
         const bf16_t* Qp = a.Q + (bh * a.Lq + qrow) * 64 + 8 * hh;
 #pragma unroll
         for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const bf16x8*>(Qp + 16 * m);
+        if constexpr (SPLIT) {
+            const bf16_t* Ql = a.Qlo + (bh * a.Lq + qrow) * 64 + 8 * hh;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) qfl[m] = *reinterpret_cast<const bf16x8*>(Ql + 16 * m);
+        }
     }
     constexpr bool dense = DENSE;
     int lo1, hi1, lo2, hi2;
@@ -380,6 +392,8 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     const int prow = lane >> 3;
     const bf16_t* Kg = a.K + bh * a.Lcap * 64;
     const bf16_t* Vg = a.Vt + bh * 64 * a.Lp;
+    const bf16_t* Kgl = SPLIT ? a.Klo + bh * a.Lcap * 64 : nullptr;
+    const bf16_t* Vgl = SPLIT ? a.Vtlo + bh * 64 * a.Lp : nullptr;
     int pik[2], kch[2];
     int64_t voff[2];
 #pragma unroll
@@ -393,13 +407,17 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     }
 #define AT_STAGE(KT, BUF)                                                                              \
     if (WPB == 4 || wave < 4) {                                                                        \
-        bf16_t* sK_ = sm + (BUF) * 2 * AT_TILE;                                                        \
+        bf16_t* sK_ = sm + (BUF) * NT * AT_TILE;                                                       \
         bf16_t* sV_ = sK_ + AT_TILE;                                                                   \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
             int key_ = (KT) + pik[i];                                                                  \
             key_ = key_ < a.Lk ? key_ : a.Lk - 1; /* clamped rows are masked out below */              \
             glds16_untracked(Kg + (int64_t)key_ * 64 + kch[i], lds_addr_of(sK_ + (wave + 4 * i) * 512)); \
             glds16_untracked(Vg + voff[i] + (KT), lds_addr_of(sV_ + (wave + 4 * i) * 512));            \
+            if constexpr (SPLIT) {                                                                     \
+                glds16_untracked(Kgl + (int64_t)key_ * 64 + kch[i], lds_addr_of(sK_ + 2 * AT_TILE + (wave + 4 * i) * 512)); \
+                glds16_untracked(Vgl + voff[i] + (KT), lds_addr_of(sV_ + 2 * AT_TILE + (wave + 4 * i) * 512));             \
+            }                                                                                          \
         }                                                                                              \
     }
 
@@ -414,12 +432,13 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
     // everything loaded so far is retired HERE, with the registers named: a tracked load still pending at loop entry would make the
     // compiler wait for it inside the loop -- with a vmcnt(0) that also drains the (untracked) prefetch DMAs of every iteration
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(lo1), "+v"(hi1), "+v"(lo2), "+v"(hi2)::"memory");
+    if constexpr (SPLIT) asm volatile("" : "+v"(qfl[0]), "+v"(qfl[1]), "+v"(qfl[2]), "+v"(qfl[3]));
     __syncthreads();
     int buf = 0;
     for (int kt = kt0; kt < bmax; kt += 64, buf ^= 1) {
         const bool more = kt + 64 < bmax;
         if (more) AT_STAGE(kt + 64, buf ^ 1);  // lands under this tile's MFMAs (untracked DMA: no compiler wait in front of the reads)
-        const bf16_t* sK = sm + buf * 2 * AT_TILE;
+        const bf16_t* sK = sm + buf * NT * AT_TILE;
         const bf16_t* sV = sK + AT_TILE;
 #pragma unroll 1
         for (int sub = 0; sub < 2; ++sub) {
@@ -432,6 +451,11 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             for (int m = 0; m < 4; ++m) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * sub + qi) * 64 + (((2 * m + hh) ^ fsw) << 3));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m], s, 0, 0, 0);
+                if constexpr (SPLIT) {
+                    bf16x8 kl = *reinterpret_cast<const bf16x8*>(sK + 2 * AT_TILE + (32 * sub + qi) * 64 + (((2 * m + hh) ^ fsw) << 3));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[m], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[m], s, 0, 0, 0);
+                }
             }
             // interior sub-tile: every row of the wave sees all 32 keys -> no per-element mask work
             const bool inner = !dense && __all(((lo1 <= ks) & (ks + 32 <= hi1)) | ((lo2 <= ks) & (ks + 32 <= hi2)));
@@ -480,6 +504,18 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
                 pb0 = __builtin_bit_cast(bf16x8, u0);
                 pb1 = __builtin_bit_cast(bf16x8, u1);
             }
+            bf16x8 pl0, pl1;
+            if constexpr (SPLIT) {  // low halves of P: p - bf16(p), rounded to bf16
+                const bf16_t* h0 = reinterpret_cast<const bf16_t*>(&pb0);
+                const bf16_t* h1 = reinterpret_cast<const bf16_t*>(&pb1);
+                uint4 u0, u1;
+                u0.x = cvt_pk_bf16(p[0] - bf2f(h0[0]), p[1] - bf2f(h0[1])); u0.y = cvt_pk_bf16(p[2] - bf2f(h0[2]), p[3] - bf2f(h0[3]));
+                u0.z = cvt_pk_bf16(p[4] - bf2f(h0[4]), p[5] - bf2f(h0[5])); u0.w = cvt_pk_bf16(p[6] - bf2f(h0[6]), p[7] - bf2f(h0[7]));
+                u1.x = cvt_pk_bf16(p[8] - bf2f(h1[0]), p[9] - bf2f(h1[1])); u1.y = cvt_pk_bf16(p[10] - bf2f(h1[2]), p[11] - bf2f(h1[3]));
+                u1.z = cvt_pk_bf16(p[12] - bf2f(h1[4]), p[13] - bf2f(h1[5])); u1.w = cvt_pk_bf16(p[14] - bf2f(h1[6]), p[15] - bf2f(h1[7]));
+                pl0 = __builtin_bit_cast(bf16x8, u0);
+                pl1 = __builtin_bit_cast(bf16x8, u1);
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int c = ((4 * sub + 2 * kk + hh) ^ fsw) << 3;
@@ -487,6 +523,14 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
                 bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(sV + (32 + qi) * 64 + c);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pb1 : pb0, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pb1 : pb0, o1, 0, 0, 0);
+                if constexpr (SPLIT) {
+                    bf16x8 vl0 = *reinterpret_cast<const bf16x8*>(sV + 2 * AT_TILE + qi * 64 + c);
+                    bf16x8 vl1 = *reinterpret_cast<const bf16x8*>(sV + 2 * AT_TILE + (32 + qi) * 64 + c);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pl1 : pl0, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pl1 : pl0, o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0, kk ? pb1 : pb0, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1, kk ? pb1 : pb0, o1, 0, 0, 0);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -507,8 +551,29 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             w1.y = cvt_pk_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(op + 8 * g) = w0;
             *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
+            if constexpr (SPLIT) {
+                bf16_t* ol = a.Olo + ((int64_t)b * a.Lq + qrow_raw) * a.ldo + head * 64 + 4 * hh;
+                uint2 l0, l1;
+                l0.x = cvt_pk_bf16(o0[4 * g] * inv - bf2f((bf16_t)(w0.x & 0xffffu)), o0[4 * g + 1] * inv - bf2f((bf16_t)(w0.x >> 16)));
+                l0.y = cvt_pk_bf16(o0[4 * g + 2] * inv - bf2f((bf16_t)(w0.y & 0xffffu)), o0[4 * g + 3] * inv - bf2f((bf16_t)(w0.y >> 16)));
+                l1.x = cvt_pk_bf16(o1[4 * g] * inv - bf2f((bf16_t)(w1.x & 0xffffu)), o1[4 * g + 1] * inv - bf2f((bf16_t)(w1.x >> 16)));
+                l1.y = cvt_pk_bf16(o1[4 * g + 2] * inv - bf2f((bf16_t)(w1.y & 0xffffu)), o1[4 * g + 3] * inv - bf2f((bf16_t)(w1.y >> 16)));
+                *reinterpret_cast<uint2*>(ol + 8 * g) = l0;
+                *reinterpret_cast<uint2*>(ol + 32 + 8 * g) = l1;
+            }
         }
     }
+}
+
+// accuracy-mode launch of the LDS-tiled forward: 64 KiB of dynamic LDS (2 stages x 4 tiles)
+template <int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 2) void attn_fwd_lds_split_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char at_dyn[];
+    bf16_t* sm = reinterpret_cast<bf16_t*>(at_dyn);
+    __shared__ int s_hull[2 * WPB];
+    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);  // block-uniform
+    if (dense) attn_lds_body<true, WPB, true>(a, sm, s_hull);
+    else attn_lds_body<false, WPB, true>(a, sm, s_hull);
 }
 
 
@@ -805,6 +870,32 @@ extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16
                               const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
                               int Lcap, int Lp, int ldo, void* stream) {
     return attn_fwd_impl(Q, K, Vt, iv, flag, dense_mask, O, nullptr, B, nH, Lq, Lk, Lcap, Lp, ldo, stream);
+}
+
+// Accuracy mode (showo_engine_set_precision 1): every operand and the output as (hi, lo) bf16 pairs of identical layout; three MFMAs
+// per fragment pair, fp32 soft-max: models/phi.py:715-722 in fp32 to ~1e-5.  Any Lq >= 1 (a decode step runs one query tile).
+extern "C" int showo_attn_fwd_split(const uint16_t* Q, const uint16_t* Qlo, const uint16_t* K, const uint16_t* Klo, const uint16_t* Vt,
+                                    const uint16_t* Vtlo, const int32_t* iv, const int32_t* flag, const float* dense_mask, uint16_t* O,
+                                    uint16_t* Olo, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo, void* stream) {
+    if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+    if (!Qlo || !Klo || !Vtlo || !Olo) return set_error_msg(1, "attn_fwd_split: the low halves are required");
+    if ((Lp % 64) || Lp < Lk || Lcap < Lk || (ldo % 4)) return set_error_msg(1, "attn: bad Lp/Lcap/ldo");
+    AttnArgs a;
+    a.Q = Q; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = flag; a.dense = dense_mask; a.O = O;
+    a.B = B; a.nH = nH; a.Lq = Lq; a.Lk = Lk; a.Lcap = Lcap; a.Lp = Lp; a.ldo = ldo; a.lse = nullptr; a.pos_dev = nullptr;
+    a.Qlo = Qlo; a.Klo = Klo; a.Vtlo = Vtlo; a.Olo = Olo;
+    const int qblocks = (Lq + 31) / 32, nqb = (qblocks + 3) / 4;
+    ProfScope prof(PROF_ATTN, 3.0 * 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // executed flops: three products
+    static bool attr_set = false;
+    constexpr int SMEM = 2 * 4 * AT_TILE * 2;
+    if (!attr_set) {
+        SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lds_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    a.nqb = nqb;
+    attn_fwd_lds_split_kernel<4><<<dim3((unsigned)nqb * nH * B), dim3(256), SMEM, (hipStream_t)stream>>>(a);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // training forward: additionally writes lse fp32 [B, nH, Lq] (natural-log sum of exp of the masked score row)

@@ -20,6 +20,9 @@ struct Layer {
     // accuracy mode (showo_engine_set_precision 1): low halves of the weights, w = hi + lo to 2^-17 (same layouts as the hi images;
     // wqkv_lo and w1_lo are one allocation like wqkv / w1)
     bf16_t *wqkv_lo = nullptr, *wd_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;
+    // accuracy mode on the production kernels: K-concatenated, tiled split images (precise_sync in engine.hip)
+    //   wq1x3 rows [w_hi | w_hi | w_lo] of [Wqkv ; W1]  ([3H + F, 3H]);  wd2x3 rows [Wd_hi | W2_hi | Wd_hi | W2_hi | Wd_lo | W2_lo] ([H, 3 (H + F)])
+    bf16_t *wq1x3 = nullptr, *wd2x3 = nullptr;
 };
 }  // namespace showo
 
@@ -45,6 +48,8 @@ int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t 
 // accuracy-mode kernels (precise.hip)
 int precise_ln_split(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* hi, bf16_t* lo, int rows, int H,
                      float eps, hipStream_t s);
+int precise_ln_split3(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* out, int rows, int H, float eps,
+                      hipStream_t s);
 int precise_qk_prep(const float* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                     const float* sinT, float* Q, float* K, float* V, int B, int L, int nH, float eps, int pos0, int Lcap, hipStream_t s);
 int precise_attention(const float* Q, const float* K, const float* V, const int32_t* iv, const int32_t* flag, const float* dense, float* O,
@@ -112,7 +117,8 @@ struct showo_engine {
         int B, nseq, L, N, prefix, steps, id_offset, codebook, reuse, cfg, has_iv;
         int64_t mask_id;
         float guidance;
-        const void* p[11];
+        int prec;
+        const void* p[13];
     };
     struct T2IGraphEntry {
         T2IGraphKey key;
@@ -134,6 +140,14 @@ struct showo_engine {
     bf16_t* wlm_lo = nullptr;
     bf16_t *p_hlo = nullptr, *p_actlo = nullptr;                            // low halves of h / hf and of attn | gelu(fc1)
     float *p_qkv = nullptr, *p_f = nullptr, *p_Q = nullptr, *p_K = nullptr, *p_V = nullptr, *p_a = nullptr;  // fp32 intermediates
+    // accuracy mode on the production kernels (run_layers_precise_fast): split images of the lm_head ([V, 3H] rows [hi | hi | lo]),
+    // LayerNorm outputs [T, 3H] = [hi | lo | hi], the attention / gelu(fc1) operand of the residual GEMM act [T, 2 (H + F)] =
+    // [attn_hi | ffn_hi | attn_lo | ffn_lo], low halves of Q / K / V^T and of the KV caches
+    bool px3_valid = false;
+    bf16_t *wlm3 = nullptr, *p_h3 = nullptr, *p_hf3 = nullptr, *p_act = nullptr, *p_Qlo = nullptr, *p_Klo = nullptr, *p_Vtlo = nullptr;
+    bf16_t *kcache_lo = nullptr, *vtcache_lo = nullptr, *tk_lo = nullptr, *tvt_lo = nullptr;
+    int64_t tk_lo_cap = 0, tvt_lo_cap = 0;
+    bf16_t* wtmp3 = nullptr;
     float* collect = nullptr;  // parity hook (showo_engine_set_collect)
     int t2i_captures = 0;  // how often a denoise step was captured (tests: a second identical call must not capture again)
     int* step_dev = nullptr;

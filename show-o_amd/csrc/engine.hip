@@ -238,6 +238,7 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     if (rc == -1) return set_error_msg(3, "engine_load: unknown state-dict key");
     if (rc == 0) e->loaded.insert(k);
     e->fused_valid = false;  // the fused weight images (and with them a cached t2i graph's preconditions) are rebuilt on the next call
+    e->px3_valid = false;
     return rc;
 }
 
@@ -286,6 +287,7 @@ extern "C" int showo_engine_slot(showo_engine* e, const char* key, int64_t n, ui
 extern "C" int showo_engine_weights_touched(showo_engine* e) {
     if (!e) return set_error_msg(1, "engine: null handle");
     e->fused_valid = false;
+    e->px3_valid = false;
     e->lo_loaded.clear();  // the hi images were rewritten without their low halves: accuracy mode needs a re-upload
     return 0;
 }
@@ -348,8 +350,9 @@ struct KVDest {
     bf16_t *k, *vt;
     int64_t k_lstride, v_lstride;  // elements between consecutive layers
     int Lcap, Lp;                  // key rows per head in k, columns per row in vt
+    bf16_t *k_lo = nullptr, *vt_lo = nullptr;  // accuracy mode: low halves (same layout and strides)
 };
-static KVDest kv_workspace(showo_engine* e, int L) { return KVDest{e->K, e->Vt, 0, 0, L, ((L + 63) / 64) * 64}; }
+static KVDest kv_workspace(showo_engine* e, int L) { return KVDest{e->K, e->Vt, 0, 0, L, ((L + 63) / 64) * 64, e->p_Klo, e->p_Vtlo}; }
 namespace showo { int g_decode_impl = 0; }
 static int g_decode_chain = 0;  // 1: the fused layer as a plain three-launch chain (no co-scheduled fc2 role)
 extern "C" int showo_decode_set_impl(int impl) {
@@ -360,7 +363,8 @@ extern "C" int showo_decode_set_impl(int impl) {
 }
 
 static KVDest kv_decode_cache(showo_engine* e) {
-    return KVDest{e->kcache, e->vtcache, (int64_t)e->nH * e->cache_cap * 64, (int64_t)e->nH * 64 * e->cache_cap, e->cache_cap, e->cache_cap};
+    return KVDest{e->kcache, e->vtcache, (int64_t)e->nH * e->cache_cap * 64, (int64_t)e->nH * 64 * e->cache_cap, e->cache_cap, e->cache_cap,
+                  e->kcache_lo, e->vtcache_lo};
 }
 
 static bool layer_overlap_enabled() {
@@ -379,7 +383,22 @@ static int collect_x(showo_engine* e, int slot, int T, hipStream_t s) {
     return 0;
 }
 
-// ---- accuracy mode (precise.hip): split-bf16 GEMMs, everything between them in fp32 ---------------------------------------------
+// ---- accuracy mode ----------------------------------------------------------------------------------------------------------------
+// Two implementations.  (1) precise.hip (run_layers_precise): split-bf16 GEMMs on the 128^2 kernel, everything between them in fp32 on
+// the vector ALU: any shape, slow.  (2) run_layers_precise_fast (round 5): the PRODUCTION kernels on K-concatenated split images.  A
+// split-precision product a w = a_hi w_hi + a_lo w_hi + a_hi w_lo is ONE bf16 GEMM over K' = 3K between A' = [a_hi | a_lo | a_hi] and
+// W' = [w_hi | w_hi | w_lo] with the fp32 accumulation the MFMA does anyway, so gemm2p / gemm3w run unchanged (tile tuner, tiled
+// weights, split-K, the K-concatenated residual form); only the fused projection epilogue (epilogue_qkv_split: outputs as (hi, lo)
+// pairs, IEEE gelu) and the attention (attn_lds_body<SPLIT>: three MFMAs per fragment pair) have accuracy-mode forms.  A layer is
+// the same two GEMM launches + attention as in precision 0, so prefix reuse, hipGraph replay and the KV cache all apply.
+static int g_precise_fast = -1;  // -1: read SHOWO_PRECISE_FAST once (default on); 0 / 1: showo_precise_set_fast
+extern "C" int showo_precise_set_fast(int on) { g_precise_fast = on ? 1 : 0; return 0; }
+static bool precise_fast_shape_ok(const showo_engine* e) {
+    if (g_precise_fast < 0) { const char* env = getenv("SHOWO_PRECISE_FAST"); g_precise_fast = env ? (atoi(env) != 0) : 1; }
+    return g_precise_fast && e->cfg.rotary_dim == 32 && (3 * e->H) % 256 == 0 && e->H % 64 == 0 && e->F % 64 == 0 && e->H % 4 == 0;
+}
+// ... and its images / workspaces exist (showo_engine_set_precision(e, 1) made them)
+static bool precise_fast_ok(const showo_engine* e) { return precise_fast_shape_ok(e) && e->wlm3 != nullptr; }
 extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
     if (!e) return set_error_msg(1, "engine: null handle");
     if (precision != 0 && precision != 1) return set_error_msg(1, "engine_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class)");
@@ -398,9 +417,31 @@ extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
         rc |= e->alloc(&e->wlm_lo, V * H);
         if (rc) return rc;
     }
+    if (precision == 1 && precise_fast_shape_ok(e) && !e->wlm3) {  // K-concatenated split images + workspaces of the production-kernel path
+        const int64_t H = e->H, F = e->F, V = e->V, T = e->maxT, HF = H + F;
+        const int64_t Lp = ((e->cfg.max_seq + 63) / 64) * 64;
+        int rc = 0;
+        for (auto& l : e->layers) {
+            rc |= e->alloc(&l.wq1x3, showo_gemm_tiled_elems((int)(3 * H + F), (int)(3 * H)));
+            rc |= e->alloc(&l.wd2x3, showo_gemm_tiled_elems((int)H, (int)(3 * HF)));
+        }
+        const int64_t t1 = (3 * H + F) * 3 * H, t2 = H * 3 * HF;
+        rc |= e->alloc(&e->wtmp3, t1 > t2 ? t1 : t2);
+        rc |= e->alloc(&e->p_h3, (T + 256) * 3 * H); rc |= e->alloc(&e->p_hf3, (T + 256) * 3 * H);
+        rc |= e->alloc(&e->p_act, (T + 256) * 2 * HF);
+        rc |= e->alloc(&e->p_Qlo, T * H); rc |= e->alloc(&e->p_Klo, T * H);
+        rc |= e->alloc(&e->p_Vtlo, (int64_t)e->cfg.max_batch * H * Lp);
+        rc |= e->alloc(&e->wlm3, V * 3 * H);
+        if (rc) return rc;
+        hipMemset(e->p_Vtlo, 0, (size_t)e->cfg.max_batch * H * Lp * sizeof(bf16_t));
+        e->px3_valid = false;
+    }
     e->precision = precision;
     return 0;
 }
+// 1 when accuracy mode runs on the production kernels (K-concatenated split images): prefix reuse, hipGraph replay and the KV-cached
+// decode are then available in precision 1 as well; 0: the fp32 reference kernels of precise.hip (small / odd shapes, SHOWO_PRECISE_FAST=0)
+extern "C" int showo_engine_precise_fast(const showo_engine* e) { return e && precise_fast_ok(e) ? 1 : 0; }
 // 1 when every GEMM weight has a current low half (q, k, v, dense, fc1, fc2 per layer + lm_head), i.e. precision 1 can run
 extern "C" int showo_engine_precise_ready(const showo_engine* e) {
     return e && e->wlm_lo && (int)e->lo_loaded.size() == e->nL * 6 + 1;
@@ -444,12 +485,86 @@ static int head_rows_precise(showo_engine* e, const int32_t* rows, int nrows, in
                              logits, ncols, nullptr, 0, nrows, ncols, e->H, s);
 }
 
+static int fused_sync(showo_engine* e, hipStream_t s);
+// K-concatenated split images of every GEMM weight (see "accuracy mode" above), rebuilt after any weight load; never inside a capture
+static int precise_sync(showo_engine* e, hipStream_t s) {
+    if (e->px3_valid) return 0;
+    TRY(precise_check(e));
+    TRY(fused_sync(e, s));  // bd2 = bd + b2
+    const int64_t H = e->H, F = e->F, V = e->V, HF = H + F;
+    auto cp = [&](bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds, int64_t cols, int64_t rows) -> int {
+        SHOWO_CHECK_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * 2, src, (size_t)lds * 2, (size_t)cols * 2, (size_t)rows, hipMemcpyDeviceToDevice, s));
+        return 0;
+    };
+    for (auto& l : e->layers) {
+        bf16_t* cat = e->wtmp3;
+        // [Wqkv ; W1] rows -> [w_hi | w_hi | w_lo]  (wqkv / w1 and their low halves are one allocation each)
+        TRY(cp(cat, 3 * H, l.wqkv, H, H, 3 * H + F));
+        TRY(cp(cat + H, 3 * H, l.wqkv, H, H, 3 * H + F));
+        TRY(cp(cat + 2 * H, 3 * H, l.wqkv_lo, H, H, 3 * H + F));
+        TRY(showo_gemm_tile_weight(cat, (int)(3 * H), (int)(3 * H + F), (int)(3 * H), l.wq1x3, s));
+        // [Wd | W2] rows -> [Wd_hi | W2_hi | Wd_hi | W2_hi | Wd_lo | W2_lo] against act = [attn_hi | ffn_hi | attn_lo | ffn_lo | attn_hi | ffn_hi]
+        for (int rep = 0; rep < 3; ++rep) {
+            TRY(cp(cat + rep * HF, 3 * HF, rep == 2 ? l.wd_lo : l.wd, H, H, H));
+            TRY(cp(cat + rep * HF + H, 3 * HF, rep == 2 ? l.w2_lo : l.w2, F, F, H));
+        }
+        TRY(showo_gemm_tile_weight(cat, (int)(3 * HF), (int)H, (int)(3 * HF), l.wd2x3, s));
+    }
+    TRY(cp(e->wlm3, 3 * H, e->wlm, H, H, V));
+    TRY(cp(e->wlm3 + H, 3 * H, e->wlm, H, H, V));
+    TRY(cp(e->wlm3 + 2 * H, 3 * H, e->wlm_lo, H, H, V));
+    e->px3_valid = true;
+    return 0;
+}
+
+// One pass over the layer stack in accuracy mode on the production kernels: LayerNorm -> [hi | lo | hi]; ONE [Wqkv ; W1] projection
+// (K' = 3H) whose epilogue writes Q / K / V^T and gelu(fc1) as (hi, lo) pairs; split attention; ONE K-concatenated residual GEMM
+// (K' = 3 (H + F)) over act = [attn_hi | ffn_hi | attn_lo | ffn_lo] read as [act | act[:, :H + F]].  Any T >= 1, any KV destination.
+static int run_layers_precise_fast(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
+                                   const float* dense, hipStream_t s) {
+    const int H = e->H, F = e->F, nH = e->nH, T = B * L, HF = H + F, lda = 2 * HF;
+    if (!kv.k_lo || !kv.vt_lo) return set_error_msg(7, "engine (precision 1): the low-half K / V^T destination is missing");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cs);
+    if (!e->px3_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine (precision 1): split weight images must be built before a stream capture");
+    TRY(precise_sync(e, s));
+    TRY(collect_x(e, 0, T, s));
+    const int Lk = pos0 + L;
+    for (int li = 0; li < e->nL; ++li) {
+        showo::Layer& l = e->layers[li];
+        bf16_t* Kd = kv.k + li * kv.k_lstride;
+        bf16_t* Vd = kv.vt + li * kv.v_lstride;
+        bf16_t* Kl = kv.k_lo + li * kv.k_lstride;
+        bf16_t* Vl = kv.vt_lo + li * kv.v_lstride;
+        TRY(showo::precise_ln_split3(e->x, l.ln_w, l.ln_b, nullptr, e->p_h3, T, H, e->cfg.ln_eps, s));
+        TRY(showo_gemm_qkv_fc1_split(e->p_h3, 3 * H, l.wq1x3, 3 * H, 3 * H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT,
+                                     e->Q, e->p_Qlo, Kd, Kl, Vd, Vl, e->p_act + H, e->p_act + HF + H, lda, F, B, L, nH, e->cfg.rotary_dim,
+                                     e->cfg.ln_eps, pos0, kv.Lcap, kv.Lp, 1, s));
+        TRY(showo_attn_fwd_split(e->Q, e->p_Qlo, Kd, Kl, Vd, Vl, iv, flag, dense, e->p_act, e->p_act + HF, B, nH, L, Lk, kv.Lcap, kv.Lp, lda, s));
+        TRY(showo_gemm_kcat_bf16(e->p_act, lda, 2 * HF, e->p_act, lda, HF, l.wd2x3, 3 * HF, l.bd2, e->x, H, e->x, H, T, H,
+                                 SHOWO_EPI_RESID_F32, 1, s));
+        TRY(collect_x(e, li + 1, T, s));
+    }
+    return 0;
+}
+static int head_rows_precise_fast(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cs);
+    if (!e->px3_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine (precision 1): split weight images must be built before a stream capture");
+    TRY(precise_sync(e, s));
+    const int H = e->H;
+    TRY(showo::precise_ln_split3(e->x, e->fln_w, e->fln_b, rows, e->p_hf3, nrows, H, e->cfg.ln_eps, s));
+    return showo_gemm_bf16(e->p_hf3, 3 * H, e->wlm3 + (int64_t)col0 * 3 * H, 3 * H, e->blm + col0, 0, logits, ncols, nullptr, 0, nrows, ncols,
+                           3 * H, SHOWO_EPI_F32, s);
+}
+
 static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
                       const float* dense, hipStream_t s) {
     const int H = e->H, F = e->F, nH = e->nH;
     const int T = B * L;
     if (e->precision == 1) {
-        if (pos0 != 0 || kv.k != e->K) return set_error_msg(1, "engine (precision 1): KV-cached calls are not available in accuracy mode");
+        if (precise_fast_ok(e)) return run_layers_precise_fast(e, B, L, pos0, kv, iv, flag, dense, s);
+        if (pos0 != 0 || kv.k != e->K) return set_error_msg(1, "engine (precision 1): KV-cached calls need the production-kernel form of accuracy mode (showo_engine_precise_fast)");
         return run_layers_precise(e, B, L, iv, flag, dense, s);
     }
     TRY(collect_x(e, 0, T, s));
@@ -658,7 +773,8 @@ static int hidden(showo_engine* e, const int64_t* ids, const float* embeds, cons
 
 static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
     if (col0 < 0 || ncols <= 0 || col0 + ncols > e->V) return set_error_msg(1, "engine: bad vocabulary slice");
-    if (e->precision == 1) return head_rows_precise(e, rows, nrows, col0, ncols, logits, s);
+    if (e->precision == 1) return precise_fast_ok(e) ? head_rows_precise_fast(e, rows, nrows, col0, ncols, logits, s)
+                                                       : head_rows_precise(e, rows, nrows, col0, ncols, logits, s);
     if (nrows == 1 && !rows && showo::g_decode_impl == 0 && showo::decode_fused_shapes_ok(e->H, e->F))  // decode step: LN + lm_head in one launch
         return showo::decode_ln_gemv2(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, e->H, e->wlm + (int64_t)col0 * e->H, e->blm + col0,
                                       nullptr, logits, ncols, nullptr, nullptr, nullptr, 0, s);
@@ -721,11 +837,13 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     const int prefix = text_len + 1;
     const int La = L - prefix;
     const int LpC = ((L + 63) / 64) * 64;
-    const bool reuse_ok = e->precision == 0 && !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
+    const bool pfast = e->precision == 1 && precise_fast_ok(e);
+    const bool reuse_ok = (e->precision == 0 || pfast) && !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
     hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cs0);
     if (cs0 != hipStreamCaptureStatusNone) return set_error_msg(7, "t2i_generate: the call captures its own graph; do not call it inside a stream capture");
     TRY(fused_sync(e, s));  // weight images of the fused launches: rebuilt here (never inside a capture), so cached graphs stay valid
+    if (pfast) TRY(precise_sync(e, s));
     if (reuse_ok && !e->pfx_flag) {
         TRY(e->alloc(&e->pfx_flag, 4));
         SHOWO_CHECK_HIP(hipHostMalloc((void**)&e->pfx_host, 64, hipHostMallocDefault));
@@ -753,7 +871,13 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
         if (vn > e->tvt_cap) { TRY(e->alloc(&e->tvt, vn)); e->tvt_cap = vn; }
         SHOWO_CHECK_HIP(hipMemsetAsync(e->tvt, 0, (size_t)vn * sizeof(bf16_t), s));  // pad key columns must stay finite
         if (!e->ids_act) { TRY(e->alloc(&e->ids_act, e->maxT)); TRY(e->alloc(&e->iv_act, e->maxT * 4)); TRY(e->alloc(&e->rows_act, e->maxT)); }
-        kvc = KVDest{e->tk, e->tvt, (int64_t)nseq * e->nH * L * 64, (int64_t)nseq * e->nH * 64 * LpC, L, LpC};
+        if (pfast) {
+            if (kn > e->tk_lo_cap) { TRY(e->alloc(&e->tk_lo, kn)); e->tk_lo_cap = kn; }
+            if (vn > e->tvt_lo_cap) { TRY(e->alloc(&e->tvt_lo, vn)); e->tvt_lo_cap = vn; }
+            SHOWO_CHECK_HIP(hipMemsetAsync(e->tvt_lo, 0, (size_t)vn * sizeof(bf16_t), s));
+        }
+        kvc = KVDest{e->tk, e->tvt, (int64_t)nseq * e->nH * L * 64, (int64_t)nseq * e->nH * 64 * LpC, L, LpC, pfast ? e->tk_lo : nullptr,
+                     pfast ? e->tvt_lo : nullptr};
         if (iv) gather_iv_kernel<<<dim3((nseq * La + thr - 1) / thr), dim3(thr), 0, s>>>(iv, e->iv_act, nseq, L, prefix);
         rows_index_kernel<<<dim3((nrows + thr - 1) / thr), dim3(thr), 0, s>>>(e->rows_act, nseq, La, img_start - prefix, N);
         SHOWO_CHECK_HIP(hipGetLastError());
@@ -790,7 +914,7 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     // once (first-use attributes, GEMM tile tuning) outside the capture; step 0 always runs eagerly.  Not combined with per-launch
     // event timing.
     const int n_eager = reuse ? 2 : 1;
-    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query() && e->precision == 0;
+    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query() && (e->precision == 0 || pfast);
     if (!graph) {
         for (int step = 0; step < steps; ++step) TRY(denoise_step(step, step == 0 || !reuse));
     } else {
@@ -819,7 +943,8 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
         memset(&key, 0, sizeof(key));  // padding bytes take part in the memcmp below
         key.B = B; key.nseq = nseq; key.L = L; key.N = N; key.prefix = prefix; key.steps = steps; key.id_offset = id_offset;
         key.codebook = codebook; key.reuse = reuse ? 1 : 0; key.cfg = cfg ? 1 : 0; key.has_iv = iv ? 1 : 0;
-        key.mask_id = mask_id; key.guidance = guidance;
+        key.mask_id = mask_id; key.guidance = guidance; key.prec = e->precision;
+        key.p[11] = (reuse && pfast) ? e->tk_lo : nullptr; key.p[12] = (reuse && pfast) ? e->tvt_lo : nullptr;
         if (!reuse) { key.p[0] = iv; key.p[1] = flag; key.p[2] = mask; }  // with reuse the captured step reads e->iv_act only
         key.p[3] = exp_noise; key.p[4] = uniform; key.p[5] = e->row_logits;
         key.p[6] = reuse ? e->tk : nullptr; key.p[7] = reuse ? e->tvt : nullptr; key.p[8] = e->sched_dev; key.p[9] = e->step_dev; key.p[10] = s;
@@ -902,13 +1027,25 @@ static int ensure_cache(showo_engine* e, int need) {
     e->cache_cap = cap;
     return 0;
 }
+// accuracy mode: low halves of the decode cache (same capacity), allocated when the first precision-1 prefill arrives
+static int ensure_cache_lo(showo_engine* e) {
+    if (e->kcache_lo || e->cache_cap == 0) return 0;
+    const int64_t n = (int64_t)e->nL * e->nH * e->cache_cap * 64;
+    TRY(e->alloc(&e->kcache_lo, n));
+    TRY(e->alloc(&e->vtcache_lo, n));
+    hipMemset(e->kcache_lo, 0, (size_t)n * sizeof(bf16_t));
+    hipMemset(e->vtcache_lo, 0, (size_t)n * sizeof(bf16_t));
+    return 0;
+}
 
 extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L,
                                     float* logits_last, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     TRY(check_ready(e, 1, L));
-    if (e->precision == 1) return set_error_msg(1, "prefill: the KV-cached decode runs with bf16 operands only (showo_engine_set_precision(e, 0))");
+    if (e->precision == 1 && !precise_fast_ok(e))
+        return set_error_msg(1, "prefill: in accuracy mode the KV-cached decode needs the production-kernel form (showo_engine_precise_fast)");
     TRY(ensure_cache(e, L + 1));
+    if (e->precision == 1) TRY(ensure_cache_lo(e));
     TRY(embed_in(e, ids, embeds, L, s));
     const int32_t *iv = nullptr, *flag = nullptr;
     if (mask) {
@@ -949,6 +1086,7 @@ extern "C" int showo_engine_decode_step(showo_engine* e, const int64_t* id, cons
     else return set_error_msg(6, "decode_step: mask row needs more than two intervals");
     set_iv_kernel<<<1, 64, 0, s>>>(e->iv1, a, b, c, d);
     hipMemsetAsync(e->flag, 0, 4, s);
+    if (e->precision == 1) TRY(ensure_cache_lo(e));
     TRY(run_layers(e, 1, 1, P, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
     e->cache_len = P + 1;
     return head_rows(e, nullptr, 1, 0, e->V, logits_last, s);
@@ -986,7 +1124,12 @@ static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_
     SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv_dev, e->last_iv, 4 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     SHOWO_CHECK_HIP(hipMemsetAsync(e->flag, 0, 4, s));
     SHOWO_CHECK_HIP(hipStreamSynchronize(s));  // P0 / last_iv are host temporaries of this call
-    showo::attn_set_decode_pos(e->pos_dev, P0 + n_steps);
+    // accuracy mode: the production-kernel layers take the position from the host (no device-side position in those launches), so the
+    // steps run eagerly with pos = P0 + i; the token boundary (seam / sampler) keeps pos_dev in step with it
+    const bool prec = e->precision == 1;
+    if (prec) TRY(ensure_cache_lo(e));
+    int step_i = 0;
+    if (!prec) showo::attn_set_decode_pos(e->pos_dev, P0 + n_steps);
     // Greedy loop (top_k == 1, the reference caller's setting): the token boundary -- arg-max merge, token store, position increment, next
     // embedding row, next mask row -- is one launch (basic.hip, greedy_token_seam_kernel) at the END of a step, so a step is
     // [layers, lm_head, arg-max partials, boundary] and only the first step embeds its token up front.  SHOWO_DECODE_TOKSEAM=0: the
@@ -1003,7 +1146,8 @@ static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_
     auto one = [&]() -> int {
         if (!seam_tok) TRY(pre());
         // host-side P only sizes nothing here (grids depend on L = 1); the kernels read the position from pos_dev
-        TRY(run_layers(e, 1, 1, P0, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
+        TRY(run_layers(e, 1, 1, prec ? P0 + step_i : P0, kv_decode_cache(e), e->iv1, e->flag, nullptr, s));
+        ++step_i;
         TRY(head_rows(e, nullptr, 1, 0, e->V, logits_ws, s));
         if (seam_tok)
             return showo::greedy_token_seam(logits_ws, e->V, tok, out_tokens, e->pos_dev, P0, e->embed, e->x, e->H, e->V, e->last_iv_dev,
@@ -1017,7 +1161,7 @@ static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_
     int rc = one();  // eager first step (kernel attributes, GEMV variants)
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
-    const bool graph = use_graph && n_steps > 1 && !showo::g_prof_on_query();
+    const bool graph = use_graph && n_steps > 1 && !showo::g_prof_on_query() && !prec;
     if (!rc && graph) {
         hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
         if (he == hipSuccess) {

@@ -986,8 +986,10 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
                          const float* qln_b, const float* kln_w, const float* kln_b, const float* cos_tab, const float* sin_tab,
                          uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
                          uint16_t* ffn_out, int ldf, int F, int w_tiled, void* stream, uint16_t* raw_qkv = nullptr, int ldraw = 0,
-                         uint16_t* ffn_pre = nullptr) {
-    const int M = B * L, Nq = 3 * nH * 64, Kd = nH * 64;
+                         uint16_t* ffn_pre = nullptr, int Kcat = 0, uint16_t* Qlo = nullptr, uint16_t* Klo = nullptr, uint16_t* Vtlo = nullptr,
+                         uint16_t* ffn_lo = nullptr) {
+    const int M = B * L, Nq = 3 * nH * 64, Kd = Kcat > 0 ? Kcat : nH * 64;
+    const bool split = Qlo != nullptr;
     const int N = Nq + (ffn_out ? F : 0);
     if (M <= 0) return 0;
     if (rot != 32) return set_error_msg(1, "gemm_qkv: the fused epilogue implements rotary_dim 32 (use showo_gemm_bf16 + showo_qk_prep)");
@@ -1015,8 +1017,13 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
         g.pre = ffn_pre;
     }
     g.wtiled = w_tiled ? 1 : 0;
+    if (split) {
+        if (!Klo || !Vtlo || !ffn_lo || !ffn_out || raw_qkv || ffn_pre || (((uintptr_t)ffn_lo) & 7))
+            return set_error_msg(1, "gemm_qkv_fc1_split: Qlo, Klo, Vtlo, ffn_lo (8B aligned) and ffn_out required; no save-for-backward outputs");
+        g.Qlo = Qlo; g.Klo = Klo; g.Vtlo = Vtlo; g.out2lo = ffn_lo;
+    }
     ProfScope prof(PROF_GEMM, 2.0 * M * N * Kd, (hipStream_t)stream);
-    return gemm2p_dispatch(g, EPI_QKV, (hipStream_t)stream);
+    return gemm2p_dispatch(g, split ? EPI_QKV_SPLIT : EPI_QKV, (hipStream_t)stream);
 }
 
 extern "C" int showo_gemm_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, int ldw, const float* bias,
@@ -1035,6 +1042,23 @@ extern "C" int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_
     if (!ffn_out) return set_error_msg(1, "gemm_qkv_fc1: ffn_out required");
     return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
                          pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream);
+}
+
+// Accuracy-mode form of the same launch (showo_engine_set_precision 1 on the production kernel).  The operands are K-CONCATENATED
+// split-bf16 images: A = [a_hi | a_lo | a_hi] ([M, 3 K], lda), W rows = [w_hi | w_hi | w_lo] ([N, 3 K]) -- one bf16 GEMM over Kcat = 3 K
+// whose fp32 accumulators receive hi*hi + lo*hi + hi*lo, the three products of the split-precision scheme (the lo*lo term is below
+// 2^-34) -- and every output is written as a (hi, lo) bf16 pair: Q / Qlo, K / Klo, Vt / Vtlo, ffn_out / ffn_lo (same layouts, same
+// leading dimension ldf for both halves of the fc1 output).  LayerNorm / RoPE see the fp32 accumulators, gelu_new uses IEEE exp and
+// division.  Reference: models/phi.py:657-694, 208-212 evaluated in fp32 (inference_t2i.py:67).
+extern "C" int showo_gemm_qkv_fc1_split(const uint16_t* A3, int lda, const uint16_t* W3, int ldw, int Kcat, const float* bias,
+                                        const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                        const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* Qlo, uint16_t* K, uint16_t* Klo,
+                                        uint16_t* Vt, uint16_t* Vtlo, uint16_t* ffn_out, uint16_t* ffn_lo, int ldf, int F, int B, int L,
+                                        int nH, int rot, float eps, int pos0, int Lcap, int Lp, int w_tiled, void* stream) {
+    if (!ffn_out || !Qlo) return set_error_msg(1, "gemm_qkv_fc1_split: ffn_out and the low-half outputs are required");
+    if (Kcat <= 0 || (Kcat % 64)) return set_error_msg(1, "gemm_qkv_fc1_split: Kcat must be a positive multiple of 64");
+    return gemm_qkv_impl(A3, lda, W3, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
+                         pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream, nullptr, 0, nullptr, Kcat, Qlo, Klo, Vtlo, ffn_lo);
 }
 
 // Training forward of the same launch: additionally saves what backward needs -- raw_qkv[m][0..3 nH 64) = bf16(A Wqkv^T + b) (the values

@@ -291,18 +291,20 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     if (MF0 == MF1 || wm == 0) {
         Q2_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-        if constexpr (EPI != EPI_QKV) {
+        if constexpr (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT) {
             if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF0, NFS>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg); return; }
         }
         if (g.splits > 1 && !splitk_exchange<MF0, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
-        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        if constexpr (EPI == EPI_QKV_SPLIT) epilogue_qkv_split<MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        else epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         Q2_RUN(MF1);
-        if constexpr (EPI != EPI_QKV) {
+        if constexpr (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT) {
             if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF1, NFS>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg); return; }
         }
         if (g.splits > 1 && !splitk_exchange<MF1, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
-        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        if constexpr (EPI == EPI_QKV_SPLIT) epilogue_qkv_split<MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        else epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef Q2_RUN
     asm volatile("" ::"v"(pfreg));  // keeps the prefetch destination register reserved for the whole loop
@@ -411,7 +413,7 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
             return set_error_msg(7, "gemm2p: split-K workspace unavailable (first use of a split shape inside a stream capture, or more than 8 "
                                     "streams): run the shape once eagerly, or set SHOWO_GEMM_SPLITK=0");
         g.splits = S;
-        g.coop = (EPI != EPI_QKV && tiles <= 2048 && splitk_coop_ok(tiles * S)) ? splitk_coop_mode() : 0;
+        g.coop = (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT && tiles <= 2048 && splitk_coop_ok(tiles * S)) ? splitk_coop_mode() : 0;
         g_cnt_splitk++;
     }
     kfn<<<dim3(tiles * g.splits), dim3(512), SMEM3_BYTES, s>>>(g);
@@ -626,6 +628,7 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
         case SHOWO_EPI_F32: return launch2p_bm<SHOWO_EPI_F32>(g, s);
         case SHOWO_EPI_RESID_F32: return launch2p_bm<SHOWO_EPI_RESID_F32>(g, s);
         case EPI_QKV: return launch2p_bm<EPI_QKV>(g, s);
+        case EPI_QKV_SPLIT: return launch2p_bm<EPI_QKV_SPLIT>(g, s);
     }
     return set_error_msg(1, "gemm: unknown epilogue");
 }

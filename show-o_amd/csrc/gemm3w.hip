@@ -261,10 +261,12 @@ __global__ __launch_bounds__(512) void gemm3w_kernel(GemmArgs g) {
     if (MF0 == MF1 || wm == 0) {
         R_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
-        epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        if constexpr (EPI == EPI_QKV_SPLIT) epilogue_qkv_split<MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        else epilogue8p<EPI, MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     } else {
         R_RUN(MF1);
-        epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        if constexpr (EPI == EPI_QKV_SPLIT) epilogue_qkv_split<MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
+        else epilogue8p<EPI, MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
     }
 #undef R_RUN
 #undef R_ANY
@@ -328,6 +330,7 @@ int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s) {
         case SHOWO_EPI_F32: return launch3w_h<SHOWO_EPI_F32>(g, rows, s);
         case SHOWO_EPI_RESID_F32: return launch3w_h<SHOWO_EPI_RESID_F32>(g, rows, s);
         case EPI_QKV: return launch3w_h<EPI_QKV>(g, rows, s);
+        case EPI_QKV_SPLIT: return launch3w_h<EPI_QKV_SPLIT>(g, rows, s);
     }
     return set_error_msg(1, "gemm3w: unknown epilogue");
 }

@@ -47,9 +47,13 @@ struct GemmArgs {
     int coop = 0;
     // gemm_tn only (token-major operands, contraction over rows): rows k >= Klim of both operands read as zero (K = Klim rounded up to 64)
     int Klim = 0;
+    // EPI_QKV_SPLIT only (accuracy mode on the production kernel): every bf16 output also gets its LOW half -- value - bf16(value),
+    // rounded to bf16 -- at the same index of a second image, so that hi + lo carries the fp32 accumulator to 2^-17
+    bf16_t *Qlo = nullptr, *Klo = nullptr, *Vtlo = nullptr, *out2lo = nullptr;
 };
 
 constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
+constexpr int EPI_QKV_SPLIT = 5;  // the same projection with (hi, lo) bf16 pairs as outputs (showo_gemm_qkv_fc1_split)
 constexpr int B2 = 256;   // tile width (n) of the 256-wide kernels
 constexpr int GEMM_BK = 64;
 constexpr int P3_BUF_ELEMS = 2 * 256 * 64;  // one k-tile: W[256][64] then A[256][64] (64 KiB)
@@ -541,6 +545,185 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
             load_bias4(g, n, bn);
 #pragma unroll
             for (int j = 0; j < MF; ++j) store_frag<EPI>(g, acc[i][j], mrow0 + j * 16 + fr, n, bn);
+        }
+    }
+}
+
+// gelu_new at fp32 accuracy (x * sigmoid(2u) with IEEE exp and division; transformers NewGELUActivation, phi.py:204-212)
+static __device__ __forceinline__ float gelu_new_precise(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + expf(-2.0f * u));
+}
+// (hi, lo) bf16 halves of four values: hi = RNE(v), lo = RNE(v - hi)
+static __device__ __forceinline__ void split_pack4(const float (&v)[4], uint2& hi, uint2& lo) {
+    hi.x = pack_bf2(v[0], v[1]);
+    hi.y = pack_bf2(v[2], v[3]);
+    lo.x = pack_bf2(v[0] - bf2f((bf16_t)(hi.x & 0xffffu)), v[1] - bf2f((bf16_t)(hi.x >> 16)));
+    lo.y = pack_bf2(v[2] - bf2f((bf16_t)(hi.y & 0xffffu)), v[3] - bf2f((bf16_t)(hi.y >> 16)));
+}
+
+// Epilogue of the fused [Wqkv ; W1] projection in ACCURACY MODE (EPI_QKV_SPLIT; the operands were K-concatenated (hi, lo) images, so the
+// fp32 accumulators hold the product to ~1e-6): the arithmetic of epilogue8p<EPI_QKV> -- bias, per-head q / k LayerNorm(64), partial
+// RoPE, 1/8 folded into Q, head-major relayout of Q, K, V^T; bias + gelu_new for the fc1 columns -- with every output written as a
+// (hi, lo) bf16 pair (g.Q / g.Qlo, ...) and gelu_new evaluated with IEEE exp / division instead of the fast forms.
+// Inference only (no save-for-backward outputs).  Stores reuse the staging of the bf16 epilogue: one pass per half.
+template <int MF>
+static __device__ __forceinline__ void epilogue_qkv_split(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg,
+                                                          bf16_t* stg) {
+    const int lane_ = fg * 16 + fr;
+    constexpr int VRS = MF < 8 ? 16 * MF + 2 : 128;
+    const int rrow = lane_ >> 3, rchunk = lane_ & 7;
+    const int nbase = n0 + wn * 64;
+    if (n0 >= g.Nq) {  // fc1 columns: bias + gelu_new -> out2 / out2lo [m][n - Nq]
+        const bool staged = stg != nullptr && (g.ldo2 % 8) == 0 && ((g.N - g.Nq) % 8) == 0 && ((((uintptr_t)g.out2) & 15) == 0) &&
+                            ((((uintptr_t)g.out2lo) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float bn[4];
+            load_bias4(g, nbase + i * 16 + fg * 4, bn);
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_new_precise(acc[i][j][r] + bn[r]);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16_t* dst = half ? g.out2lo : g.out2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nbase + i * 16 + fg * 4;
+#pragma unroll
+                for (int j = 0; j < MF; ++j) {
+                    const int m = mrow0 + j * 16 + fr;
+                    const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    uint2 hi, lo;
+                    split_pack4(v, hi, lo);
+                    const uint2 pk = half ? lo : hi;
+                    if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
+                    else if (m < g.M && n < g.N) *reinterpret_cast<uint2*>(dst + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
+                }
+            }
+            if (staged) {
+#pragma unroll
+                for (int t = 0; t < 2 * MF; ++t) {
+                    const int row = t * 8 + rrow, m = mrow0 + row, n = nbase + rchunk * 8;
+                    const uint4 v = unstage_row16(stg, row, rchunk);
+                    if (m < g.M && n < g.N) *reinterpret_cast<uint4*>(dst + (int64_t)m * g.ldo2 + (n - g.Nq)) = v;
+                }
+            }
+        }
+        return;
+    }
+    if (nbase >= g.N) return;
+    const int Hq = g.nH * 64;
+    const int which = nbase / Hq;  // 0 = q, 1 = k, 2 = v (wave-uniform)
+    const int head = (nbase - which * Hq) >> 6;
+    float bn[4][4], lw[4][4], lb[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        load_bias4(g, nbase + i * 16 + fg * 4, bn[i]);
+        if (which < 2) {
+            const float4 w4 = *reinterpret_cast<const float4*>((which ? g.kw : g.qw) + i * 16 + fg * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>((which ? g.kb : g.qb) + i * 16 + fg * 4);
+            lw[i][0] = w4.x; lw[i][1] = w4.y; lw[i][2] = w4.z; lw[i][3] = w4.w;
+            lb[i][0] = b4.x; lb[i][1] = b4.y; lb[i][2] = b4.z; lb[i][3] = b4.w;
+        }
+    }
+    if (which == 2) {  // V^T[bh][d][pos], hi then lo: staged transposed in the wave's LDS slice, stored with the lanes along `pos`
+        bf16_t* vb[2];
+        bool vok[2];
+        int64_t vdelta = g.Vtlo - g.Vt;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int mt = h * 64 + lane_, m = mrow0 + mt;
+            vok[h] = mt < 16 * MF && m < g.M;
+            const int mm = vok[h] ? m : 0;
+            const int b = mm / g.L, l = mm - b * g.L;
+            vb[h] = g.Vt + ((int64_t)b * g.nH + head) * 64 * g.Lp + g.pos0 + l;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[i][j][r] + bn[i][r];
+                        const bf16_t hb = f2bf(x);
+                        const bf16_t ob = half ? f2bf(x - bf2f(hb)) : hb;
+                        if (stg) stg[(i * 16 + fg * 4 + r) * VRS + j * 16 + fr] = ob;
+                        else {
+                            const int m = mrow0 + j * 16 + fr;
+                            if (m < g.M) {
+                                const int b = m / g.L, l = m - b * g.L;
+                                (half ? g.Vtlo : g.Vt)[(((int64_t)b * g.nH + head) * 64 + i * 16 + fg * 4 + r) * g.Lp + g.pos0 + l] = ob;
+                            }
+                        }
+                    }
+            if (stg) {
+#pragma unroll 8
+                for (int dd = 0; dd < 64; ++dd) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (h * 64 < 16 * MF && vok[h]) (vb[h] + (half ? vdelta : 0))[(int64_t)dd * g.Lp] = stg[dd * VRS + h * 64 + lane_];
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < MF; ++j) {
+        const int m = mrow0 + j * 16 + fr;
+        const bool valid = m < g.M;
+        const int mm = valid ? m : g.M - 1;
+        const int b = mm / g.L, l = mm - b * g.L, pos = g.pos0 + l;
+        const int64_t bh = (int64_t)b * g.nH + head;
+        float x[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[i][r] = acc[i][j][r] + bn[i][r];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+        sum = sum4_lanes16(sum);
+        const float mean = sum * (1.0f / 64.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x[i][r] -= mean; sq += x[i][r] * x[i][r]; }
+        sq = sum4_lanes16(sq);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + g.eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[i][r] = x[i][r] * rstd * lw[i][r] + lb[i][r];
+        const float4 c0 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + fg * 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + fg * 4);
+        const float4 c1 = *reinterpret_cast<const float4*>(g.cosT + (int64_t)pos * 32 + 16 + fg * 4);
+        const float4 s1 = *reinterpret_cast<const float4*>(g.sinT + (int64_t)pos * 32 + 16 + fg * 4);
+        const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, ss0[4] = {s0.x, s0.y, s0.z, s0.w};
+        const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y0 = x[0][r], y1 = x[1][r];
+            x[0][r] = y0 * cc0[r] - y1 * ss0[r];
+            x[1][r] = y1 * cc1[r] + y0 * ss1[r];
+        }
+        if (!valid) continue;
+        const float sc = which == 0 ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (a power of two: exact for both halves)
+        const int64_t off = which == 0 ? (bh * g.L + l) * 64 : (bh * g.Lcap + pos) * 64;
+        bf16_t* dhi = (which == 0 ? g.Q : g.Kd) + off;
+        bf16_t* dlo = (which == 0 ? g.Qlo : g.Klo) + off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v[4] = {x[i][0] * sc, x[i][1] * sc, x[i][2] * sc, x[i][3] * sc};
+            uint2 hi, lo;
+            split_pack4(v, hi, lo);
+            *reinterpret_cast<uint2*>(dhi + i * 16 + fg * 4) = hi;
+            *reinterpret_cast<uint2*>(dlo + i * 16 + fg * 4) = lo;
         }
     }
 }

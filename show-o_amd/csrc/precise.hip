@@ -36,6 +36,47 @@ __global__ __launch_bounds__(256) void ln_split_kernel(const float* __restrict__
     for (int i = lane; i < H; i += 64) split_store((xr[i] - mean) * rstd * w[i] + b[i], hi, lo, (int64_t)r * H + i);
 }
 
+// The same LayerNorm with the output laid out for the K-concatenated split GEMM on the production kernel: row r of out is
+// [hi(H) | lo(H) | hi(H)] (ld = 3 H), to be multiplied with weight rows [w_hi | w_hi | w_lo] (hi*hi + lo*hi + hi*lo in ONE bf16 GEMM
+// over K = 3 H with fp32 accumulation).  One wave per row, 8 values per lane per step.
+__global__ __launch_bounds__(256) void ln_split3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                        const int32_t* __restrict__ row_index, bf16_t* __restrict__ out, int rows, int H,
+                                                        float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* xr = x + (row_index ? (int64_t)row_index[r] : (int64_t)r) * H;
+    float s = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    bf16_t* o = out + (int64_t)r * 3 * H;
+    for (int i = lane * 4; i < H; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
+        const float4 wv = *reinterpret_cast<const float4*>(w + i);
+        const float4 bv = *reinterpret_cast<const float4*>(b + i);
+        const float y[4] = {(v.x - mean) * rstd * wv.x + bv.x, (v.y - mean) * rstd * wv.y + bv.y, (v.z - mean) * rstd * wv.z + bv.z,
+                            (v.w - mean) * rstd * wv.w + bv.w};
+        uint2 hi, lo;
+        hi.x = pack_bf2(y[0], y[1]);
+        hi.y = pack_bf2(y[2], y[3]);
+        lo.x = pack_bf2(y[0] - bf2f((bf16_t)(hi.x & 0xffffu)), y[1] - bf2f((bf16_t)(hi.x >> 16)));
+        lo.y = pack_bf2(y[2] - bf2f((bf16_t)(hi.y & 0xffffu)), y[3] - bf2f((bf16_t)(hi.y >> 16)));
+        *reinterpret_cast<uint2*>(o + i) = hi;
+        *reinterpret_cast<uint2*>(o + H + i) = lo;
+        *reinterpret_cast<uint2*>(o + 2 * H + i) = hi;
+    }
+}
+
 // qkv fp32 [T, 3 nH 64] -> Q fp32 [B,nH,L,64], K / V fp32 [B,nH,Lcap,64] (rows pos0 + l): per-head LayerNorm(64) of q and k, partial
 // rotary over dims [0, 32) with rotate_half pairing d <-> d + 16 (phi.py:163-167,681-694).  One wave per (token, head, q|k|v), lane = dim.
 __global__ __launch_bounds__(256) void qk_prep_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ qb,
@@ -150,6 +191,13 @@ int precise_ln_split(const float* x, const float* w, const float* b, const int32
     if (rows <= 0) return 0;
     ln_split_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, w, b, row_index, hi, lo, rows, H, eps);
     return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "precise: ln_split launch failed");
+}
+int precise_ln_split3(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* out, int rows, int H, float eps,
+                      hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (H % 4) return set_error_msg(1, "precise: ln_split3 needs H % 4 == 0");
+    ln_split3_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(x, w, b, row_index, out, rows, H, eps);
+    return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "precise: ln_split3 launch failed");
 }
 int precise_qk_prep(const float* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                     const float* sinT, float* Q, float* K, float* V, int B, int L, int nH, float eps, int pos0, int Lcap, hipStream_t s) {

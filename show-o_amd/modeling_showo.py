@@ -374,9 +374,11 @@ class Showo(PretrainedMixin, nn.Module):
     def set_precision(self, precision):
         """0 (default): bf16 GEMM / attention operands with fp32 accumulation -- the timed path.  1: accuracy mode, the reference's
         fp32 inference (inference_t2i.py:67, models/phi.py:1182-1183) to ~1e-4 end to end: split-bf16 (hi + lo) MFMA GEMMs, fp32
-        LayerNorm / RoPE / attention / gelu_new (csrc/precise.hip).  Applies to forward() without labels, t2i_generate() and
-        mmu_generate() (which then runs the reference's own no-cache algorithm: the whole sequence per token); training keeps bf16
-        operands.  Costs a second bf16 image of the weights.  With w_clip_vit the mm_projector follows (its own accuracy mode)."""
+        LayerNorm / RoPE / attention / gelu_new.  At Phi-1.5's shape this mode runs on the PRODUCTION kernels (K-concatenated split
+        images, csrc/engine.hip run_layers_precise_fast): same launches as precision 0 with three MFMAs per product, prefix reuse,
+        hipGraph replay and the KV-cached decode included; tiny test shapes use the fp32 reference kernels of csrc/precise.hip (and
+        mmu_generate then runs the reference's own no-cache algorithm).  Applies to forward() without labels, t2i_generate() and
+        mmu_generate(); training keeps bf16 operands.  Costs 4x the bf16 weight memory.  With w_clip_vit the mm_projector follows."""
         if int(precision) not in (0, 1):
             raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
         self._precision = int(precision)
@@ -618,7 +620,10 @@ class Showo(PretrainedMixin, nn.Module):
             if noise is not None and tuple(noise.shape) != (max_new_tokens, self.vocab_size):
                 raise ValueError("_exp_noise must be [max_new_tokens, vocab_size]")
         dev = idx.device if idx is not None else input_embeddings.device
-        if int(getattr(self, "_precision", 0)) == 1:
+        # accuracy mode: KV-cached like precision 0 when the engine runs it on the production kernels (Phi-1.5's shape); otherwise -- or
+        # with `self.precise_recompute = True` -- the reference's own no-cache algorithm on the fp32-class path
+        if int(getattr(self, "_precision", 0)) == 1 and (getattr(self, "precise_recompute", False) or
+                                                         not _lib.load().showo_engine_precise_fast(eng)):
             return self._mmu_generate_recompute(idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token,
                                                 greedy, None if greedy else (k, seed, noise))
         if input_embeddings is not None:

@@ -615,9 +615,23 @@ def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
     _check_precise(lgp[0][torch.from_numpy(g["rows"]).cuda()][:, cols], pre_ref, "full-size cfg4 prefill logits vs the fp32 reference subset")
     _check_precise(lgp[0, -1][cols], last_ref[0], "full-size cfg4 first-token logits")
     del lgp
+    # accuracy mode runs on the production kernels at this shape: KV-cached prefill + decode (round 5) ...
+    assert L.load().showo_engine_precise_fast(m.engine()) == 1
     toks_p = [int(t) for t in m.mmu_generate(input_embeddings=embp, attention_mask=am[0], max_new_tokens=len(toks_ref), top_k=1)]
-    print(f"[parity] full-size cfg4 greedy tokens, accuracy mode (reference's no-cache algorithm): {toks_p}")
+    print(f"[parity] full-size cfg4 greedy tokens, accuracy mode through the KV cache: {toks_p}")
     assert toks_p == toks_ref
+    # ... teacher-forced: every cached decode step's logits within 1e-3 of what the reference drew that token from
+    L.call("showo_engine_prefill", eng, None, L.ptr(embp.float().contiguous()), L.ptr(maskc), 631, L.ptr(logits), L.stream())
+    for j, t in enumerate(toks_ref):
+        _check_precise(logits[cols], last_ref[j], f"full-size cfg4 KV-cached decode step {j}")
+        if j + 1 < len(toks_ref):
+            tok = torch.tensor([t], dtype=torch.int64, device="cuda")
+            L.call("showo_engine_decode_step", eng, L.ptr(tok), None, L.ptr(logits), L.stream())
+    # ... and the reference's own no-cache algorithm (the whole sequence per token) on the same kernels gives the same tokens
+    m.precise_recompute = True
+    toks_r = [int(t) for t in m.mmu_generate(input_embeddings=embp, attention_mask=am[0], max_new_tokens=len(toks_ref), top_k=1)]
+    m.precise_recompute = False
+    assert toks_r == toks_ref
     # the grown sequence after 4 tokens, as the reference builds it (modeling_showo.py:203-217): logits token 5 was drawn from
     neg = float(torch.finfo(torch.float32).min)
     cur, mk = embp.float(), am[0].float().reshape(631, 631)
@@ -808,6 +822,19 @@ def test_full_size_t2i_generate_is_reproducible_and_graph_equals_eager():
     agree = float((outs[0] == full).float().mean())
     print(f"[parity] full-size t2i: prefix reuse vs recompute token agreement {agree:.4f}")
     assert agree == 1.0 and caps() == 2
+    # ---- accuracy mode is a product path (round 5): prefix reuse + hipGraph replay on the production kernels, same tokens as eager /
+    # as recomputing the prefix; compared with the bf16-operand run for the record (different arithmetic: agreement is not required)
+    m.set_precision(1)
+    outs_p = []
+    for kw in (dict(), dict(use_graph=0), dict(reuse_prefix=False)):
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        outs_p.append(m.t2i_generate(input_ids=ic.clone(), uncond_input_ids=iu, attention_mask=mask, temperature=1.0, timesteps=18,
+                                     guidance_scale=5.0, generator=gen, config=P.gen_config(), **kw))
+    assert L.load().showo_engine_precise_fast(m.engine()) == 1 and caps() == 4  # two new graph keys (reuse on / off) in precision 1
+    assert torch.equal(outs_p[0], outs_p[1]) and torch.equal(outs_p[0], outs_p[2])
+    print(f"[parity] full-size t2i, accuracy mode: graph == eager == recomputed prefix; token agreement with the bf16-operand run "
+          f"{float((outs_p[0] == outs[0]).float().mean()):.4f}")
+    m.set_precision(0)
 
 
 def test_t2i_graph_cache_survives_fresh_masks_ragged_batches_and_cfg_changes():
