@@ -597,6 +597,9 @@ def main():
                     others[key] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                                    "roofline": {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")},
                                    "wall_s": round(time.time() - t1, 1)}
+                    for sub in ("batch4", "batch1"):  # cfg4: the 4 images decoded together, and one at a time
+                        if sub in d.get("config", {}):
+                            others[key][sub] = d["config"][sub]
                 log(f"{key}: {others[key]}")
             out["other_configs"] = others
         out["train_step"] = train_step

@@ -470,6 +470,21 @@ int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* em
  * use_graph: capture one step (position and mask row live in device memory) into a hipGraph and replay it. */
 int showo_engine_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws, int use_graph,
                                void* stream);
+
+/* Batched KV-cached greedy decode: nb <= 8 independent sequences (BASELINE cfg4's "batch=4 images"), nb caches, ONE weight stream per
+ * token step -- the reference's batch-1 mmu_generate (models/modeling_showo.py:183-240) serves them one after the other
+ * (inference_mmu.py:87-177) and streams the 2.66 GB of weights once per token per sequence.  Every sequence gets the bits of its own
+ * batch-1 run (same lane split / accumulation order per sequence): tokens and logits equal nb showo_engine_decode_greedy runs.
+ *   showo_engine_batch_begin(e, nb, cap_tokens): (re)sizes nb caches for cap_tokens >= max(prompt) + new tokens + 1 and clears them;
+ *   showo_engine_batch_prefill(e, b, ...): showo_engine_prefill of sequence b into its slot (own length, own mask);
+ *   showo_engine_batch_decode_greedy: tok int64 [nb] (device; in = first token to feed per sequence, out = last produced),
+ *     out_tokens int64 [nb, n_steps], logits_ws fp32 [nb, vocab]; every sequence advances n_steps tokens (the caller cuts at <eot>);
+ *     one hipGraph replay per step with the nb positions in device memory.  bf16 operands (precision 0) only. */
+int showo_engine_batch_begin(showo_engine* e, int nb, int cap_tokens);
+int showo_engine_batch_prefill(showo_engine* e, int b, const int64_t* ids, const float* embeds, const float* mask, int L,
+                               float* logits_last, void* stream);
+int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_tokens, float* logits_ws, int use_graph,
+                                     void* stream);
 /* Next-token draw of the AR decode (modeling_showo.py:220-228): x = logits / temperature; values below the top_k-th largest
  * are dropped (top_k <= 0 or >= V: none); token = multinomial(softmax(x), 1) computed as argmax_i p_i / E_i, E ~ Exp(1):
  * E = exp_noise[step * V + i] when exp_noise != NULL (parity tests inject the reference's draws), else Philox(seed; step, i). */

@@ -132,6 +132,9 @@ _PROTOS = {
     "showo_engine_prefill": [c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "showo_engine_decode_step": [c_p, c_p, c_p, c_p, c_p],
     "showo_engine_decode_greedy": [c_p, c_p, c_i, c_p, c_p, c_i, c_p],
+    "showo_engine_batch_begin": [c_p, c_i, c_i],
+    "showo_engine_batch_prefill": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
+    "showo_engine_batch_decode_greedy": [c_p, c_p, c_i, c_p, c_p, c_i, c_p],
     "showo_clip_create": [c_p, c_p],
     "showo_clip_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_clip_missing": [c_p],

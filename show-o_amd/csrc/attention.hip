@@ -638,7 +638,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
     // uninitialised bits: score() and accum() never let them reach a result
     int pos = -1;  // FUSED: index of the key that lives in LDS
     if (FUSED) {
-        pos = a.pos_dev ? *a.pos_dev : f.pos;
+        pos = a.pos_dev ? a.pos_dev[b] : f.pos;  // one position per sequence (b = 0 in the batch-1 launches)
         a.Lk = pos + 1;
     } else if (a.pos_dev) {
         a.Lk = *a.pos_dev + 1;
@@ -646,6 +646,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
     float qv[8];  // this lane's 8 query dimensions (chunk ch)
     if (FUSED) {
         const int Hq = a.nH * 64;
+        f.qkv += (int64_t)b * 3 * Hq;  // projection row of sequence b
         if (wave < 2) {
             const float* cosr = f.cosT + (int64_t)pos * f.rot;
             const float* sinr = f.sinT + (int64_t)pos * f.rot;
@@ -909,6 +910,25 @@ extern "C" int showo_attn_fwd_lse(const uint16_t* Q, const uint16_t* K, const ui
 // Engine-internal: decode-layer attention with the prep of the new token fused in (B = 1).  qkv = the new token's
 // projection row [3 * nH * 64]; K / Vt = this layer's cache (appended at pos); iv int32[4] = the token's mask row.
 namespace showo {
+// Batched decode step (decode_batch.hip): B sequences, caches [B][nH][Lcap][64] / [B][nH][64][Lp], one position per sequence in
+// pos_dev[B] (device), qkv [B, 3 nH 64], iv int32 [B, 4], O [B, nH 64].  lk_max: upper bound of every sequence's key count over the
+// replays of the captured loop (load predicate, see attn_decode_body).  Same kernel and arithmetic as the batch-1 launch per sequence.
+int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
+                            const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
+                            const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s) {
+    if ((Lp % 64) || !pos_dev || B < 1) return set_error_msg(1, "batched decode attention: bad arguments");
+    AttnArgs a;
+    a.Q = nullptr; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = nullptr; a.dense = nullptr; a.O = O;
+    a.B = B; a.nH = nH; a.Lq = 1; a.Lcap = Lcap; a.Lp = Lp; a.ldo = nH * 64; a.lse = nullptr;
+    a.pos_dev = pos_dev;
+    a.Lk = (lk_max > 0 && lk_max < Lcap) ? lk_max : Lcap;
+    DecPrep f{qkv, qw, qb, kw, kb, cosT, sinT, rot, 0, eps};
+    const size_t smem = (size_t)((Lcap + 511) & ~511) * sizeof(float);
+    if (smem > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
+    attn_decode_kernel<true><<<dim3(nH, B), dim3(1024), smem, s>>>(a, f);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s, const bf16_t* W2, const bf16_t* ffn, const float* b2, int F, int Hout, float* y2,

@@ -26,6 +26,7 @@ struct Layer {
 };
 }  // namespace showo
 
+struct showo_engine;
 namespace showo {
 void sampler_set_device_step(const int* step_dev, const float* sched, int steps);
 int sampler_step_inc(int* step_dev, hipStream_t s);
@@ -55,6 +56,7 @@ int precise_qk_prep(const float* qkv, const float* qw, const float* qb, const fl
 int precise_attention(const float* Q, const float* K, const float* V, const int32_t* iv, const int32_t* flag, const float* dense, float* O,
                       int B, int nH, int Lq, int Lk, int Lcap, int ldo, hipStream_t s);
 int precise_gelu_split(const float* f, bf16_t* hi, bf16_t* lo, int64_t n, hipStream_t s);
+void engine_batch_free(showo_engine* e);  // decode_batch.hip
 extern int g_decode_impl;  // 0 = fused decode layer (default), 1 = the seven-launch path (showo_decode_set_impl)
 extern bool g_prof_on_query();
 }  // namespace showo
@@ -148,6 +150,9 @@ struct showo_engine {
     bf16_t *kcache_lo = nullptr, *vtcache_lo = nullptr, *tk_lo = nullptr, *tvt_lo = nullptr;
     int64_t tk_lo_cap = 0, tvt_lo_cap = 0;
     bf16_t* wtmp3 = nullptr;
+    // batched AR decode (decode_batch.hip: showo_engine_batch_begin / _batch_prefill / _batch_decode_greedy)
+    struct BatchDecode;
+    BatchDecode* bd = nullptr;
     float* collect = nullptr;  // parity hook (showo_engine_set_collect)
     int t2i_captures = 0;  // how often a denoise step was captured (tests: a second identical call must not capture again)
     int* step_dev = nullptr;

@@ -165,6 +165,7 @@ extern "C" void showo_engine_destroy(showo_engine* e) {
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_fc1) hipEventDestroy(e->ev_fc1);
     if (e->side) hipStreamDestroy(e->side);
+    showo::engine_batch_free(e);
     for (void* p : e->allocs) hipFree(p);
     delete e;
 }
@@ -1038,14 +1039,12 @@ static int ensure_cache_lo(showo_engine* e) {
     return 0;
 }
 
-extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L,
-                                    float* logits_last, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    TRY(check_ready(e, 1, L));
-    if (e->precision == 1 && !precise_fast_ok(e))
-        return set_error_msg(1, "prefill: in accuracy mode the KV-cached decode needs the production-kernel form (showo_engine_precise_fast)");
-    TRY(ensure_cache(e, L + 1));
-    if (e->precision == 1) TRY(ensure_cache_lo(e));
+// prefill of ONE sequence into a given per-layer K / V^T destination (the engine's own decode cache, or a slot of a decode batch):
+// runs the prompt, leaves K / V^T of every layer there, returns the last prompt row's visibility intervals and its logits
+namespace showo {
+int engine_prefill_into(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L, bf16_t* k, bf16_t* vt,
+                        int64_t k_lstride, int64_t v_lstride, int cap, int* last_iv_out, float* logits_last, hipStream_t s,
+                        bf16_t* k_lo, bf16_t* vt_lo) {
     TRY(embed_in(e, ids, embeds, L, s));
     const int32_t *iv = nullptr, *flag = nullptr;
     if (mask) {
@@ -1054,20 +1053,35 @@ extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const f
     } else if (e->ext_iv) {  // caller-built intervals (showo_engine_use_intervals, e.g. from showo_mask_mmu_vit)
         iv = e->ext_iv; flag = e->ext_flag;
     }
-    TRY(run_layers(e, 1, L, 0, kv_decode_cache(e), iv, flag, mask, s));
-    e->prompt_len = L;
-    e->cache_len = L;
+    TRY(run_layers(e, 1, L, 0, KVDest{k, vt, k_lstride, v_lstride, cap, cap, k_lo, vt_lo}, iv, flag, mask, s));
     if (iv) {
         int32_t f = 0;
-        SHOWO_CHECK_HIP(hipMemcpyAsync(e->last_iv, iv + (int64_t)(L - 1) * 4, 16, hipMemcpyDeviceToHost, s));
+        SHOWO_CHECK_HIP(hipMemcpyAsync(last_iv_out, iv + (int64_t)(L - 1) * 4, 16, hipMemcpyDeviceToHost, s));
         if (flag) SHOWO_CHECK_HIP(hipMemcpyAsync(&f, flag, 4, hipMemcpyDeviceToHost, s));
         SHOWO_CHECK_HIP(hipStreamSynchronize(s));
         if (f) return set_error_msg(6, "decode: prompt mask is not interval-representable; KV-cached decode unsupported");
     } else {
-        e->last_iv[0] = 0; e->last_iv[1] = L; e->last_iv[2] = 0; e->last_iv[3] = 0;
+        last_iv_out[0] = 0; last_iv_out[1] = L; last_iv_out[2] = 0; last_iv_out[3] = 0;
     }
     set_iv_kernel<<<1, 64, 0, s>>>(e->rows, L - 1, 0, 0, 0);  // rows[0] = L-1
     return head_rows(e, e->rows, 1, 0, e->V, logits_last, s);
+}
+}  // namespace showo
+
+extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const float* embeds, const float* mask, int L,
+                                    float* logits_last, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TRY(check_ready(e, 1, L));
+    if (e->precision == 1 && !precise_fast_ok(e))
+        return set_error_msg(1, "prefill: in accuracy mode the KV-cached decode needs the production-kernel form (showo_engine_precise_fast)");
+    TRY(ensure_cache(e, L + 1));
+    if (e->precision == 1) TRY(ensure_cache_lo(e));
+    const KVDest kv = kv_decode_cache(e);
+    TRY(showo::engine_prefill_into(e, ids, embeds, mask, L, kv.k, kv.vt, kv.k_lstride, kv.v_lstride, kv.Lcap, e->last_iv, logits_last, s,
+                                   kv.k_lo, kv.vt_lo));
+    e->prompt_len = L;
+    e->cache_len = L;
+    return 0;
 }
 
 extern "C" int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* embed, float* logits_last, void* stream) {

@@ -688,6 +688,77 @@ class Showo(PretrainedMixin, nn.Module):
         return result
 
 
+@torch.no_grad()
+def mmu_generate_batch(self, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, temperature=1.0, top_k=None,
+                       eot_token=None):
+    """n independent `mmu_generate` calls served together (BASELINE cfg4: "batch=4 images"; the reference's mmu_generate is batch-1 and
+    inference_mmu.py:87-177 walks the images one by one).  `idx` / `input_embeddings` / `attention_mask` are LISTS (one entry per
+    sequence, each what a single `mmu_generate` call takes: [1, L_b] ids or [1, L_b, H] embeddings, its own mask or IntervalMask);
+    returns a list of n token lists -- exactly what n separate calls return.  Greedy (`top_k=1`, the reference caller's setting,
+    inference_mmu.py:81) with bf16 operands runs on the batched engine path (csrc/decode_batch.hip: n KV caches, ONE weight stream per
+    token step, every sequence bit-identical to its batch-1 run); anything else falls back to n sequential calls."""
+    seqs = idx if idx is not None else input_embeddings
+    n = len(seqs)
+    masks = attention_mask if isinstance(attention_mask, (list, tuple)) else [attention_mask] * n
+    if top_k != 1 or int(getattr(self, "_precision", 0)) != 0 or n > 8 or n < 2:
+        return [self.mmu_generate(idx=None if idx is None else idx[b], input_embeddings=None if input_embeddings is None else input_embeddings[b],
+                                  attention_mask=masks[b], max_new_tokens=max_new_tokens, temperature=temperature, top_k=top_k,
+                                  eot_token=eot_token) for b in range(n)]
+    from .prompting_utils import IntervalMask
+    eng = self.engine()
+    dev = seqs[0].device
+    lens = [int(t.shape[1]) for t in seqs]
+    _lib.call("showo_engine_batch_begin", eng, n, max(lens) + max_new_tokens + 1)
+    logits = torch.empty((n, self.vocab_size), dtype=torch.float32, device=dev)
+    tok = torch.empty((n,), dtype=torch.int64, device=dev)
+    for b in range(n):
+        if seqs[b].shape[0] != 1:
+            raise ValueError("every sequence of mmu_generate_batch is one batch-1 mmu_generate call (reference modeling_showo.py:204,229)")
+        ids = emb = None
+        if idx is not None:
+            ids = idx[b].to(torch.int64).contiguous()
+        else:
+            emb = input_embeddings[b].detach().float().contiguous()
+        am = masks[b]
+        if isinstance(am, IntervalMask):
+            mask = self._use_mask(eng, am)
+        else:
+            mask = None if am is None else am.detach().float().reshape(1, 1, lens[b], lens[b]).contiguous()
+        try:
+            _lib.call("showo_engine_batch_prefill", eng, b, _lib.ptr(ids), _lib.ptr(emb), _lib.ptr(mask), lens[b], _lib.ptr(logits[b]), _lib.stream())
+        finally:
+            _lib.call("showo_engine_use_intervals", eng, None, None)
+        _lib.call("showo_argmax_f32", _lib.ptr(logits[b]), self.vocab_size, _lib.ptr(tok[b:b + 1]), _lib.stream())
+    first = tok.tolist()
+    results = [[torch.tensor(t, device=dev)] for t in first]
+    done = [(eot_token is not None and t == eot_token) or max_new_tokens <= 1 for t in first]
+    use_graph, chunk = int(getattr(self, "decode_graph", 1)), 16
+    if getattr(self, "_graph_stream", None) is None:
+        self._graph_stream = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    remaining = max_new_tokens - 1
+    while remaining > 0 and not all(done):
+        m = min(chunk, remaining)
+        outc = torch.empty((n, m), dtype=torch.int64, device=dev)
+        self._graph_stream.wait_stream(cur)
+        with torch.cuda.stream(self._graph_stream):
+            _lib.call("showo_engine_batch_decode_greedy", eng, _lib.ptr(tok), m, _lib.ptr(outc), _lib.ptr(logits), use_graph, _lib.stream())
+        cur.wait_stream(self._graph_stream)
+        rows = outc.tolist()
+        for b in range(n):
+            for t in rows[b]:
+                if done[b]:
+                    break
+                results[b].append(torch.tensor(t, device=dev))
+                if (eot_token is not None and t == eot_token) or len(results[b]) >= max_new_tokens:
+                    done[b] = True
+        remaining -= m
+    return [r[:max_new_tokens] for r in results]
+
+
+Showo.mmu_generate_batch = mmu_generate_batch
+
+
 def _dense_mask_of(attention_mask, L, device):
     """[1,1,L,L] additive fp32 mask from whatever mmu_generate accepts (dense tensor, IntervalMask, None = causal)"""
     from .prompting_utils import IntervalMask

@@ -605,6 +605,14 @@ def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
             break  # after a divergence the sequences differ legitimately
     ivm = P.intervals_for_mmu_vit(emb, system_prompt_len=28)  # no [1,1,631,631] tensor at all: the same tokens
     assert [int(t) for t in m.mmu_generate(input_embeddings=emb, attention_mask=ivm, max_new_tokens=len(toks_ref), top_k=1)] == toks
+    # ---- BASELINE cfg4 "batch=4 images": four prompts of different lengths decoded TOGETHER (csrc/decode_batch.hip: 4 KV caches, one
+    # weight stream per token step) give exactly the tokens of four batch-1 calls; sequence 0 is the reference's own prompt
+    embs = [emb, emb[:, :620].contiguous(), torch.cat([emb, emb[:, 600:612]], dim=1).contiguous(), emb[:, :600].contiguous()]
+    ams = [P.create_attention_mask_for_mmu_vit(e_, system_prompt_len=28)[0] for e_ in embs]
+    single = [[int(t) for t in m.mmu_generate(input_embeddings=e_, attention_mask=k_, max_new_tokens=24, top_k=1)] for e_, k_ in zip(embs, ams)]
+    got4 = [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=embs, attention_mask=ams, max_new_tokens=24, top_k=1)]
+    print(f"[parity] full-size cfg4, 4 sequences (631 / 620 / 643 / 600 embeddings) decoded together == 4 batch-1 calls: {got4 == single}")
+    assert got4 == single and got4[0][:len(toks)] == toks
     # ---- accuracy mode (projector + transformer): 1e-3 against the fp32 reference, tokens identical
     m.set_precision(1)
     imgp, embp = splice()
