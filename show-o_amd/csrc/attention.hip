@@ -326,11 +326,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 constexpr int AT_TILE = 64 * 64;  // bf16 elements of one K (or V^T) tile
 constexpr float AT_DEFER = 8.0f;   // deferred-rescale threshold (natural-log units of the score)
 
-// hardware RNE f32 -> packed bf16 (same rounding as f2bf on finite values)
+// hardware RNE f32 -> packed bf16 (same rounding as f2bf on finite values).  Through the compiler's own conversion (it selects
+// v_cvt_pk_bf16_f32 on gfx950), NOT inline assembly: the results feed MFMA operands, and the hazard recognizer does not look inside an
+// asm block -- in the split + dense-mask variant an asm-written P fragment was consumed by the next-but-one MFMA and the products
+// came out at bf16 accuracy (round 5: tools/diag_split_attn.py, 4e-3 instead of 3e-5 against the fp64 SDPA).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // WPB = waves (32-row query tiles) per block: 4, or 5 when that saves a block per (batch, head) -- at Lq = 258 (the 18-step t2i
@@ -497,24 +501,22 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             }
             l_run += ps;
             bf16x8 pb0, pb1;
+            uint4 u0, u1;
             {
-                uint4 u0, u1;
                 u0.x = cvt_pk_bf16(p[0], p[1]); u0.y = cvt_pk_bf16(p[2], p[3]); u0.z = cvt_pk_bf16(p[4], p[5]); u0.w = cvt_pk_bf16(p[6], p[7]);
                 u1.x = cvt_pk_bf16(p[8], p[9]); u1.y = cvt_pk_bf16(p[10], p[11]); u1.z = cvt_pk_bf16(p[12], p[13]); u1.w = cvt_pk_bf16(p[14], p[15]);
                 pb0 = __builtin_bit_cast(bf16x8, u0);
                 pb1 = __builtin_bit_cast(bf16x8, u1);
             }
             bf16x8 pl0, pl1;
-            if constexpr (SPLIT) {  // low halves of P: p - bf16(p), rounded to bf16
-                const bf16_t* h0 = reinterpret_cast<const bf16_t*>(&pb0);
-                const bf16_t* h1 = reinterpret_cast<const bf16_t*>(&pb1);
-                uint4 u0, u1;
-                u0.x = cvt_pk_bf16(p[0] - bf2f(h0[0]), p[1] - bf2f(h0[1])); u0.y = cvt_pk_bf16(p[2] - bf2f(h0[2]), p[3] - bf2f(h0[3]));
-                u0.z = cvt_pk_bf16(p[4] - bf2f(h0[4]), p[5] - bf2f(h0[5])); u0.w = cvt_pk_bf16(p[6] - bf2f(h0[6]), p[7] - bf2f(h0[7]));
-                u1.x = cvt_pk_bf16(p[8] - bf2f(h1[0]), p[9] - bf2f(h1[1])); u1.y = cvt_pk_bf16(p[10] - bf2f(h1[2]), p[11] - bf2f(h1[3]));
-                u1.z = cvt_pk_bf16(p[12] - bf2f(h1[4]), p[13] - bf2f(h1[5])); u1.w = cvt_pk_bf16(p[14] - bf2f(h1[6]), p[15] - bf2f(h1[7]));
-                pl0 = __builtin_bit_cast(bf16x8, u0);
-                pl1 = __builtin_bit_cast(bf16x8, u1);
+            if constexpr (SPLIT) {  // low halves of P: p - bf16(p), rounded to bf16 (the high halves are taken from the packed words)
+                const uint32_t hw[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                uint32_t lw[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    lw[i] = cvt_pk_bf16(p[2 * i] - __uint_as_float(hw[i] << 16), p[2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u));
+                pl0 = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+                pl1 = __builtin_bit_cast(bf16x8, make_uint4(lw[4], lw[5], lw[6], lw[7]));
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -783,6 +785,19 @@ __global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPre
     attn_decode_body<true>(a, f, blockIdx.x, 0);
 }
 
+// Batched form of the co-scheduled launch (decode_batch.hip): blocks [0, nH * B) = the (sequence, head) attention blocks, the rest
+// stream the fc2 weights ONCE for all NB sequences (fc2_columns_roleB: activations as fp32 in LDS).
+template <int NB>
+__global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPrep f, showo::OutGemvBArgs g) {
+    const int nab = a.nH * a.B;
+    if ((int)blockIdx.x >= nab) {
+        extern __shared__ float sp[];
+        showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, gridDim.x - nab, 16, sp);
+        return;
+    }
+    attn_decode_body<true>(a, f, blockIdx.x % a.nH, blockIdx.x / a.nH);
+}
+
 // decode-step graph replay (engine-internal): when set, single-token qk_prep / attention launches take the position from
 // device memory, so the captured launch sequence is the same for every token
 static const int* g_decode_pos_dev = nullptr;
@@ -926,6 +941,37 @@ int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb,
     const size_t smem = (size_t)((Lcap + 511) & ~511) * sizeof(float);
     if (smem > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
     attn_decode_kernel<true><<<dim3(nH, B), dim3(1024), smem, s>>>(a, f);
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
+                         const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
+                         const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s) {
+    if ((Lp % 64) || !pos_dev || B < 2 || B > 4 || fc2.K1 != 8192 || !fc2.y2 || co_blocks < 1)
+        return set_error_msg(1, "batched co-scheduled decode attention: 2..4 sequences, fc2 with K = 8192 and y2 required");
+    AttnArgs a;
+    a.Q = nullptr; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = nullptr; a.dense = nullptr; a.O = O;
+    a.B = B; a.nH = nH; a.Lq = 1; a.Lcap = Lcap; a.Lp = Lp; a.ldo = nH * 64; a.lse = nullptr;
+    a.pos_dev = pos_dev;
+    a.Lk = (lk_max > 0 && lk_max < Lcap) ? lk_max : Lcap;
+    DecPrep f{qkv, qw, qb, kw, kb, cosT, sinT, rot, 0, eps};
+    const size_t smem_a = (size_t)((Lcap + 511) & ~511) * sizeof(float);
+    if (smem_a > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
+    const size_t smem_f = (size_t)B * fc2.K1 * sizeof(float);
+    const size_t smem = smem_a > smem_f ? smem_a : smem_f;
+    const dim3 grid(nH * B + co_blocks);
+    static bool attr[5] = {false, false, false, false, false};
+    auto launch = [&](auto kfn) -> int {
+        if (!attr[B]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(attn_decode_coB)", __FILE__, __LINE__);
+            attr[B] = true;
+        }
+        kfn<<<grid, dim3(1024), smem, s>>>(a, f, fc2);
+        return 0;
+    };
+    int rc = B == 2 ? launch(attn_decode_coB_kernel<2>) : B == 3 ? launch(attn_decode_coB_kernel<3>) : launch(attn_decode_coB_kernel<4>);
+    if (rc) return rc;
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -16,10 +16,14 @@
 // The whole step replays as a hipGraph with the NB positions in device memory.
 #include "engine.h"
 #include "decode_common.h"
+#include <cstdlib>
 
 using namespace showo;
 
 namespace showo {
+int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
+                         const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
+                         const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s);
 int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                             const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
                             const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s);
@@ -51,17 +55,22 @@ struct LnGemvBArgs {
     int N1, ld1;
 };
 
-template <int NB>
-__global__ __launch_bounds__(256) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048
+// REG (NB <= 4): after the LayerNorm every lane keeps ITS 32 activation values of each sequence in registers as fp32 (the k positions
+// lane * 8 + u * 512 + j are the same for every weight row), so a weight row costs 32 conversions + 32 NB FMAs per lane and no LDS
+// read -- with the activations re-read from LDS as bf16 per row (the batch-1 form, !REG) four sequences made the step VALU-bound
+// (1.61 ms per 4-token step against 0.96 ms per batch-1 token).  Fewer, longer-lived waves (2 blocks per CU) amortise the register
+// fill.  Same products and the same accumulation order per sequence either way.
+template <int NB, bool REG, int R = 2>
+__global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048; R = weight rows in flight per wave
     extern __shared__ bf16_t sh[];  // [NB][H] normalised rows (bf16, like showo_layernorm_f32_bf16's output)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H = g.H, Ntot = g.N0 + g.N1;
     const int stride = gridDim.x * 4;
     int n = blockIdx.x * 4 + wave;
     auto rowp = [&](int c) { return c < g.N0 ? g.W0 + (int64_t)c * H : g.W1 + (int64_t)(c - g.N0) * H; };
-    uint4 br[2][4];
+    uint4 br[R][4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < R; ++r)
         if (n + r * stride < Ntot) load4(rowp(n + r * stride), lane * 8, H, br[r]);
     // LayerNorm: wave w normalises rows w, w + 4, ... with ln_gemv2_kernel's lane split and expressions (same bits per row)
     for (int b = wave; b < NB; b += 4) {
@@ -100,15 +109,35 @@ __global__ __launch_bounds__(256) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <=
         }
     }
     __syncthreads();
+    float act[REG ? NB : 1][32];
+    if constexpr (REG) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = lane * 8 + u * 512;
+                uint4 av = make_uint4(0, 0, 0, 0);
+                if (k < H) av = *reinterpret_cast<const uint4*>(sh + b * H + k);
+                const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) act[b][u * 8 + j] = bf2f(ea[j]);
+            }
+    }
     while (n < Ntot) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             const int c = n + r * stride;
             if (c < Ntot) {
                 float acc[NB];
+                if constexpr (REG) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = fma4(br[r], sh + b * H, lane * 8, H, 0.f);
-                if (c + 2 * stride < Ntot) load4(rowp(c + 2 * stride), lane * 8, H, br[r]);
+                    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+                    fma4_regs<NB>(br[r], act, lane * 8, H, acc);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[b] = fma4(br[r], sh + b * H, lane * 8, H, 0.f);
+                }
+                if (c + R * stride < Ntot) load4(rowp(c + R * stride), lane * 8, H, br[r]);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[b] = wave_sum(acc[b]);
                 if (lane == 0) {
@@ -128,22 +157,9 @@ __global__ __launch_bounds__(256) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <=
                 }
             }
         }
-        n += 2 * stride;
+        n += R * stride;
     }
 }
-
-struct OutGemvBArgs {
-    float* x;  // [NB, N] fp32 residual rows (ldx = N), updated in place
-    const bf16_t* W0;  // [N, K0] dense;  a0 [NB, K0] (lda0)
-    const bf16_t* a0;
-    const float* b0;
-    int K0, lda0;
-    const bf16_t* W1;  // [N, K1] fc2;    a1 [NB, K1] (lda1)
-    const bf16_t* a1;
-    const float* b1;
-    int K1, lda1;
-    int N;
-};
 
 // C = 2048-element chunks per output column (dense chunks first, then fc2 chunks), all in flight per wave (out_gemv2_kernel<C, 0>)
 template <int C, int NB>
@@ -191,6 +207,52 @@ __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
                 float v = acc0[b] + bd;  // x1 = x + (dense + bd)       (out_gemv2_kernel's order and parenthesisation)
                 v += g.x[(int64_t)b * g.N + n];
                 float v2 = acc1[b] + b2;  // x2 = x1 + (fc2 + b2)
+                v2 += v;
+                g.x[(int64_t)b * g.N + n] = v2;
+            }
+        }
+        n = nn;
+    }
+}
+
+// Third launch of the co-scheduled batched layer: x[b][n] = (x[b][n] + (dense(attn[b]) + bd)) + y2[b][n]  (out_gemv2_kernel<1, 2>'s
+// expression; y2 = fc2 + b2 from the fc2 role of the attention launch).  K0 <= 2048: the lane's 32 attention values per sequence stay
+// in registers.
+template <int NB>
+__global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stride = gridDim.x * 8;
+    int n = blockIdx.x * 8 + wave;
+    uint4 buf[4];
+    if (n < g.N) load4(g.W0 + (int64_t)n * g.K0, lane * 8, g.K0, buf);
+    float act[NB][32];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane * 8 + u * 512;
+            uint4 av = make_uint4(0, 0, 0, 0);
+            if (k < g.K0) av = *reinterpret_cast<const uint4*>(g.a0 + (int64_t)b * g.lda0 + k);
+            const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) act[b][u * 8 + j] = bf2f(ea[j]);
+        }
+    while (n < g.N) {
+        const int nn = n + stride;
+        float acc0[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc0[b] = 0.f;
+        fma4_regs<NB>(buf, act, lane * 8, g.K0, acc0);
+        if (nn < g.N) load4(g.W0 + (int64_t)nn * g.K0, lane * 8, g.K0, buf);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc0[b] = wave_sum(acc0[b]);
+        if (lane == 0) {
+            const float bd = g.b0[n];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float v = acc0[b] + bd;
+                v += g.x[(int64_t)b * g.N + n];
+                float v2 = g.y2[(int64_t)b * g.N + n];
                 v2 += v;
                 g.x[(int64_t)b * g.N + n] = v2;
             }
@@ -260,12 +322,24 @@ __global__ __launch_bounds__(1024) void greedy_seam_rows_kernel(const float* __r
     for (int i = tid; i < H; i += 1024) xr[i] = src[i];
 }
 
+int g_batch_reg = -1;  // SHOWO_DECODE_BATCH_REG=0: activations re-read from LDS per weight row (A/B; the form NB > 4 uses)
 template <int NB>
 int launch_ln_gemvB(const LnGemvBArgs& g, hipStream_t s) {
     const int Ntot = g.N0 + g.N1;
-    int blocks = (Ntot + 11) / 12;
-    if (blocks > 1280) blocks = 1280;
-    ln_gemvB_kernel<NB><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+    if (g_batch_reg < 0) { const char* e = getenv("SHOWO_DECODE_BATCH_REG"); g_batch_reg = e ? (atoi(e) != 0) : 1; }
+    static int rows_fl = 0, cap = 0;  // A/B knobs: SHOWO_DECODE_BATCH_R = 2 | 4 rows in flight per wave, SHOWO_DECODE_BATCH_LNBLOCKS = grid cap
+    if (!rows_fl) { const char* e = getenv("SHOWO_DECODE_BATCH_R"); rows_fl = (e && atoi(e) == 4) ? 4 : 2; }
+    if (!cap) { const char* e = getenv("SHOWO_DECODE_BATCH_LNBLOCKS"); cap = (e && atoi(e) > 0) ? atoi(e) : 512; }
+    if (NB <= 4 && g_batch_reg) {
+        int blocks = (Ntot + 4 * rows_fl - 1) / (4 * rows_fl);  // >= R rows per wave; at most 2 blocks per CU: every wave is resident from the start
+        if (blocks > cap) blocks = cap;
+        if (rows_fl == 4) ln_gemvB_kernel<NB, (NB <= 4), 4><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+        else ln_gemvB_kernel<NB, (NB <= 4), 2><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+    } else {
+        int blocks = (Ntot + 11) / 12;
+        if (blocks > 1280) blocks = 1280;
+        ln_gemvB_kernel<NB, false><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+    }
     return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "ln_gemvB launch failed");
 }
 int ln_gemvB(int nb, const LnGemvBArgs& g, hipStream_t s) {
@@ -309,6 +383,17 @@ int out_gemvB_c(const OutGemvBArgs& g, hipStream_t s) {
     }
     return set_error_msg(1, "batched decode: unsupported K0 / K1 (decode_fused_shapes_ok)");
 }
+int out_dense_y2B(int nb, const OutGemvBArgs& g, hipStream_t s) {
+    int blocks = (g.N + 7) / 8;
+    if (blocks > 256) blocks = 256;
+    switch (nb) {
+        case 2: out_dense_y2B_kernel<2><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 3: out_dense_y2B_kernel<3><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 4: out_dense_y2B_kernel<4><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        default: return set_error_msg(1, "batched decode: the co-scheduled layer serves 2..4 sequences");
+    }
+    return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "out_dense_y2B launch failed");
+}
 int out_gemvB(int nb, const OutGemvBArgs& g, hipStream_t s) {
     switch (nb) {
         case 1: return out_gemvB_c<1>(g, s);
@@ -336,6 +421,7 @@ struct showo_engine::BatchDecode {
     int last_iv[MAXB][4] = {{0}};
     int *pos_dev = nullptr, *L0_dev = nullptr, *base_dev = nullptr;
     int32_t *last_iv_dev = nullptr, *iv_dev = nullptr;
+    float* y2 = nullptr;  // [nb, H] fc2 + b2 of the current layer (co-scheduled form)
 };
 
 namespace showo {
@@ -425,16 +511,37 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
     batch_iv_kernel<<<1, 64, 0, s>>>(d->last_iv_dev, d->L0_dev, d->pos_dev, d->iv_dev, nb);
     SHOWO_CHECK_HIP(hipGetLastError());
     const int64_t per_seq = (int64_t)nH * d->cap * 64, lstride = (int64_t)nb * per_seq;
+    // co-scheduled layer (fc2 streams next to the latency-bound attention blocks): Phi-1.5's shape, 2..4 sequences (the fc2 role
+    // keeps nb x 8192 fp32 activations in LDS); SHOWO_DECODE_BATCH_CO=0 / other shapes: three plain launches per layer
+    static int co_on = -1, co_blocks = 96;
+    if (co_on < 0) {
+        const char* env = getenv("SHOWO_DECODE_BATCH_CO");
+        co_on = env ? (atoi(env) != 0) : 1;
+        const char* cb = getenv("SHOWO_DECODE_BATCH_CO_BLOCKS");
+        if (cb && atoi(cb) > 0) co_blocks = atoi(cb);
+    }
+    const bool co = co_on && F == 8192 && H <= 2048 && nb >= 2 && nb <= 4 && (size_t)nb * F * 4 <= 128 * 1024;
+    if (co && !d->y2) TRY(e->alloc(&d->y2, (int64_t)MAXB * H));
     auto one = [&]() -> int {
         for (int li = 0; li < e->nL; ++li) {
             showo::Layer& l = e->layers[li];
             LnGemvBArgs a{e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, 3 * H, l.w1, l.b1, e->ffn, F, F};
             TRY(ln_gemvB(nb, a, s));
-            TRY(showo::attn_decode_fused_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,
-                                               d->vt + li * lstride, d->iv_dev, e->attn, nb, nH, e->cfg.rotary_dim, e->cfg.ln_eps,
-                                               d->pos_dev, lk_max, d->cap, d->cap, s));
-            OutGemvBArgs o{e->x, l.wd, e->attn, l.bd, H, H, l.w2, e->ffn, l.b2, F, F, H};
-            TRY(out_gemvB(nb, o, s));
+            OutGemvBArgs o{e->x, l.wd, e->attn, l.bd, H, H, l.w2, e->ffn, l.b2, F, F, H, d->y2};
+            if (co) {
+                // [ attention of the nb x heads (sequence, head) pairs || fc2 of all nb sequences -> y2 ] -> dense + both residual adds
+                // (Phi's block is parallel-residual, models/phi.py:806-835: fc2 does not depend on the attention; decode.hip's batch-1 layer
+                // co-schedules the same way)
+                TRY(showo::attn_decode_co_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,
+                                                d->vt + li * lstride, d->iv_dev, e->attn, nb, nH, e->cfg.rotary_dim, e->cfg.ln_eps,
+                                                d->pos_dev, lk_max, d->cap, d->cap, o, co_blocks, s));
+                TRY(out_dense_y2B(nb, o, s));
+            } else {
+                TRY(showo::attn_decode_fused_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,
+                                                   d->vt + li * lstride, d->iv_dev, e->attn, nb, nH, e->cfg.rotary_dim, e->cfg.ln_eps,
+                                                   d->pos_dev, lk_max, d->cap, d->cap, s));
+                TRY(out_gemvB(nb, o, s));
+            }
         }
         LnGemvBArgs h{e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, H, e->wlm, e->blm, nullptr, logits_ws, V, V, nullptr, nullptr, nullptr, 0, 0};
         TRY(ln_gemvB(nb, h, s));

@@ -71,4 +71,99 @@ static __device__ __forceinline__ void fc2_columns_role(const OutGemvArgs& g, in
     }
 }
 
+// ---- batched decode (decode_batch.hip): NB sequences share one weight stream --------------------------------------------------
+struct OutGemvBArgs {
+    float* x;          // [NB, N] fp32 residual rows (ld = N), updated in place
+    const bf16_t* W0;  // [N, K0] dense;  a0 [NB, K0] (lda0)
+    const bf16_t* a0;
+    const float* b0;
+    int K0, lda0;
+    const bf16_t* W1;  // [N, K1] fc2;    a1 [NB, K1] (lda1)
+    const bf16_t* a1;
+    const float* b1;
+    int K1, lda1;
+    int N;
+    float* y2;         // [NB, N] fp32: fc2 + b2 per sequence (written by the co-scheduled role, added by out_gemvB_kernel<.., 2>)
+};
+
+// acc[b] += sum over the 4 loaded 8-element groups of w * act[b], in fma4's order (u ascending, j ascending) with the weight
+// converted ONCE for all NB sequences.  act: this lane's 32 activation values per sequence (registers).
+template <int NB>
+static __device__ __forceinline__ void fma4_regs(const uint4 (&wv)[4], const float (&act)[NB][32], int k0, int K, float (&acc)[NB]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (k0 + u * 512 >= K) break;
+        const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = bf2f(ew[j]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = fmaf(act[b][u * 8 + j], w, acc[b]);
+        }
+    }
+}
+// the same with the activations in LDS as fp32 (sa: row b at sa + b * ld): one conversion per weight element, none per activation
+template <int NB>
+static __device__ __forceinline__ void fma4_lds32(const uint4 (&wv)[4], const float* sa, int ld, int k0, int K, float (&acc)[NB]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * 512;
+        if (k >= K) break;
+        const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u]);
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = bf2f(ew[j]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {  // one sequence at a time: 8 activation registers live, the chain of acc[b] stays j-ascending
+            const float4 lo = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + k);
+            const float4 hi = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + k + 4);
+            acc[b] = fmaf(lo.x, w[0], acc[b]); acc[b] = fmaf(lo.y, w[1], acc[b]); acc[b] = fmaf(lo.z, w[2], acc[b]); acc[b] = fmaf(lo.w, w[3], acc[b]);
+            acc[b] = fmaf(hi.x, w[4], acc[b]); acc[b] = fmaf(hi.y, w[5], acc[b]); acc[b] = fmaf(hi.z, w[6], acc[b]); acc[b] = fmaf(hi.w, w[7], acc[b]);
+        }
+    }
+}
+
+// fc2 role of the co-scheduled BATCHED decode launch (attention.hip, attn_decode_coB_kernel): y2[b][n] = W1[n, :] a1[b] + b1[n] for
+// the columns of role-block rb of nrb, nw waves per block.  fc2_columns_role's lane split and accumulation order per sequence (chunks
+// t ascending into ONE accumulator chain, then the wave reduction): the bits of the batch-1 launch.  sa: NB * K1 floats of LDS.
+template <int C, int NB>
+static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, int rb, int nrb, int nw, float* sa) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stride = nrb * nw;
+    int n = wave * nrb + rb;
+    uint4 buf[C][4];
+    if (n < g.N) {
+#pragma unroll
+        for (int t = 0; t < C; ++t) load4(g.W1 + (int64_t)n * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
+    }
+    for (int b = 0; b < NB; ++b)
+        for (int i = threadIdx.x * 8; i < g.K1; i += nw * 64 * 8) {
+            const uint4 av = *reinterpret_cast<const uint4*>(g.a1 + (int64_t)b * g.lda1 + i);
+            const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
+            float* d = sa + (size_t)b * g.K1 + i;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = bf2f(ea[j]);
+        }
+    __syncthreads();
+    while (n < g.N) {
+        const int nn = n + stride;
+        float acc1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc1[b] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            fma4_lds32<NB>(buf[t], sa, g.K1, t * 2048 + lane * 8, g.K1, acc1);
+            if (nn < g.N) load4(g.W1 + (int64_t)nn * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc1[b] = wave_sum(acc1[b]);
+        if (lane == 0) {
+            const float b2 = g.b1[n];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) g.y2[(int64_t)b * g.N + n] = acc1[b] + b2;
+        }
+        n = nn;
+    }
+}
+
 }  // namespace showo

@@ -21,7 +21,7 @@ def _prompts(d, g, n):
     out = []
     for b in range(n):
         extra = rs.randint(5, 200, size=3 * b + (b % 2)).tolist()
-        row = base[:len(base) - (2 * b if b % 2 else 0)] + extra
+        row = base[:len(base) - (b % 4 if b % 2 else 0)] + extra  # the text tail behind <eoi> is 6 tokens long
         out.append(torch.tensor([row], dtype=torch.int64))
     return out
 
@@ -101,7 +101,8 @@ def test_batch_decode_logits_are_the_bits_of_the_batch1_run():
     assert out.tolist() == ref_tokens
     for b in range(n):
         assert torch.equal(lgs[b], ref_logits[b]), (b, float((lgs[b] - ref_logits[b]).abs().max()))
-    with pytest.raises(RuntimeError):  # the caches are full: one more chunk does not fit
-        L.call("showo_engine_batch_decode_greedy", eng, L.ptr(tok), steps, L.ptr(out), L.ptr(lgs), 0, L.stream())
+    big = torch.empty((n, 4096), dtype=torch.int64, device="cuda")
+    with pytest.raises(RuntimeError):  # more steps than the caches hold
+        L.call("showo_engine_batch_decode_greedy", eng, L.ptr(tok), 4096, L.ptr(big), L.ptr(lgs), 0, L.stream())
     with pytest.raises(RuntimeError):
         L.call("showo_engine_batch_begin", eng, 9, 64)
