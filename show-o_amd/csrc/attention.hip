@@ -330,12 +330,7 @@ constexpr float AT_DEFER = 8.0f;   // deferred-rescale threshold (natural-log un
 // v_cvt_pk_bf16_f32 on gfx950), NOT inline assembly: the results feed MFMA operands, and the hazard recognizer does not look inside an
 // asm block -- in the split + dense-mask variant an asm-written P fragment was consumed by the next-but-one MFMA and the products
 // came out at bf16 accuracy (round 5: tools/diag_split_attn.py, 4e-3 instead of 3e-5 against the fp64 SDPA).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }
 
 // WPB = waves (32-row query tiles) per block: 4, or 5 when that saves a block per (batch, head) -- at Lq = 258 (the 18-step t2i
 // loop: <soi> + 256 image tokens + <eoi>) the ninth query tile would otherwise get a block of its own that streams every K / V^T

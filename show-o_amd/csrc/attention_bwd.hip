@@ -27,11 +27,7 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int BT = 64 * 64;  // bf16 elements of one 64 x 64 tile
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }  // compiler-visible conversion: see common.h
 __device__ __forceinline__ bf16x8 pack8v(const float* p) {
     uint4 u;
     u.x = cvt_pk_bf16(p[0], p[1]); u.y = cvt_pk_bf16(p[2], p[3]); u.z = cvt_pk_bf16(p[4], p[5]); u.w = cvt_pk_bf16(p[6], p[7]);

@@ -23,11 +23,15 @@ __host__ __device__ inline float bf2f(bf16_t v) {
 // ~7 VALU instructions per value for the integer form; bit-identical on every finite value and on infinities, NaN stays NaN with
 // the hardware's quiet pattern) -- the integer form was 25-45 % of the VALU work of every bf16-producing GEMM epilogue
 // (profiles/r2_gemm_harness.txt, r3e).  The host keeps the integer form (NaN preserved as quiet NaN).
+// The conversion is written as the COMPILER's fptrunc (selected to v_cvt_pk_bf16_f32 on gfx950), not as inline assembly: converted
+// values feed MFMA operands in the attention kernels, and the hazard recognizer cannot see a VALU write inside an asm block (round 5:
+// an asm-written P fragment consumed by the next-but-one MFMA gave bf16-level errors in one variant of the split attention).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __host__ __device__ inline bf16_t f2bf(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(f));
-    return (bf16_t)(r & 0xffffu);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
 #else
     union { uint32_t u; float f; } c;
     c.f = f;
@@ -39,9 +43,8 @@ __host__ __device__ inline bf16_t f2bf(float f) {
 }
 
 __device__ inline uint32_t pack_bf2(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ inline float wave_sum(float v) {

@@ -138,21 +138,35 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
                     for (int b = 0; b < NB; ++b) acc[b] = fma4(br[r], sh + b * H, lane * 8, H, 0.f);
                 }
                 if (c + R * stride < Ntot) load4(rowp(c + R * stride), lane * 8, H, br[r]);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = wave_sum(acc[b]);
-                if (lane == 0) {
-                    if (c < g.N0) {
-                        const float bias = g.b0[c];
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const float v = acc[b] + bias;
+                if constexpr (NB <= 4) {  // lane 16 b finishes sequence b (wave_sum's order of additions per sequence: decode_common.h)
+                    const float tot = wave_sum_groups<NB>(acc);
+                    const int b = lane >> 4;
+                    if ((lane & 15) == 0 && b < NB) {
+                        if (c < g.N0) {
+                            const float v = tot + g.b0[c];
                             if (g.outf) g.outf[(int64_t)b * g.ld0 + c] = v;
                             else g.out0[(int64_t)b * g.ld0 + c] = f2bf(v);
+                        } else {
+                            g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = f2bf(gelu_new_fast(tot + g.b1[c - g.N0]));
                         }
-                    } else {
-                        const float bias = g.b1[c - g.N0];
+                    }
+                } else {
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = f2bf(gelu_new_fast(acc[b] + bias));
+                    for (int b = 0; b < NB; ++b) acc[b] = wave_sum(acc[b]);
+                    if (lane == 0) {
+                        if (c < g.N0) {
+                            const float bias = g.b0[c];
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) {
+                                const float v = acc[b] + bias;
+                                if (g.outf) g.outf[(int64_t)b * g.ld0 + c] = v;
+                                else g.out0[(int64_t)b * g.ld0 + c] = f2bf(v);
+                            }
+                        } else {
+                            const float bias = g.b1[c - g.N0];
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = f2bf(gelu_new_fast(acc[b] + bias));
+                        }
                     }
                 }
             }
@@ -198,17 +212,29 @@ __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
             }
             if (nn < g.N) issue(nn, t, buf[t]);
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { acc0[b] = wave_sum(acc0[b]); acc1[b] = wave_sum(acc1[b]); }
-        if (lane == 0) {
-            const float bd = g.b0[n], b2 = g.b1[n];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float v = acc0[b] + bd;  // x1 = x + (dense + bd)       (out_gemv2_kernel's order and parenthesisation)
-                v += g.x[(int64_t)b * g.N + n];
-                float v2 = acc1[b] + b2;  // x2 = x1 + (fc2 + b2)
+        if constexpr (NB <= 4) {
+            const float t0 = wave_sum_groups<NB>(acc0), t1 = wave_sum_groups<NB>(acc1);
+            if ((lane & 15) == 0 && (lane >> 4) < NB) {
+                const int64_t i = (int64_t)(lane >> 4) * g.N + n;
+                float v = t0 + g.b0[n];  // x1 = x + (dense + bd)       (out_gemv2_kernel's order and parenthesisation)
+                v += g.x[i];
+                float v2 = t1 + g.b1[n];  // x2 = x1 + (fc2 + b2)
                 v2 += v;
-                g.x[(int64_t)b * g.N + n] = v2;
+                g.x[i] = v2;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { acc0[b] = wave_sum(acc0[b]); acc1[b] = wave_sum(acc1[b]); }
+            if (lane == 0) {
+                const float bd = g.b0[n], b2 = g.b1[n];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float v = acc0[b] + bd;
+                    v += g.x[(int64_t)b * g.N + n];
+                    float v2 = acc1[b] + b2;
+                    v2 += v;
+                    g.x[(int64_t)b * g.N + n] = v2;
+                }
             }
         }
         n = nn;
@@ -244,18 +270,14 @@ __global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
         for (int b = 0; b < NB; ++b) acc0[b] = 0.f;
         fma4_regs<NB>(buf, act, lane * 8, g.K0, acc0);
         if (nn < g.N) load4(g.W0 + (int64_t)nn * g.K0, lane * 8, g.K0, buf);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc0[b] = wave_sum(acc0[b]);
-        if (lane == 0) {
-            const float bd = g.b0[n];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float v = acc0[b] + bd;
-                v += g.x[(int64_t)b * g.N + n];
-                float v2 = g.y2[(int64_t)b * g.N + n];
-                v2 += v;
-                g.x[(int64_t)b * g.N + n] = v2;
-            }
+        const float tot = wave_sum_groups<NB>(acc0);
+        if ((lane & 15) == 0 && (lane >> 4) < NB) {
+            const int64_t i = (int64_t)(lane >> 4) * g.N + n;
+            float v = tot + g.b0[n];
+            v += g.x[i];
+            float v2 = g.y2[i];
+            v2 += v;
+            g.x[i] = v2;
         }
         n = nn;
     }

@@ -86,6 +86,29 @@ struct OutGemvBArgs {
     float* y2;         // [NB, N] fp32: fc2 + b2 per sequence (written by the co-scheduled role, added by out_gemvB_kernel<.., 2>)
 };
 
+// wave_sum of up to four accumulators at once, each with wave_sum's own order of additions (partners 32, 16, 8, 4, 2, 1 away: the same
+// bits).  The 32 / 16 steps run on every accumulator with gfx950's row-swap instructions (VALU only); after them a lane holds, for
+// each b, the sum over its 4-lane group {l, l^16, l^32, l^48}, so lane group g = lane >> 4 continues with accumulator g alone: ONE
+// register takes the remaining four steps.  4 LDS-crossbar permutes per weight row instead of 6 per sequence.  Returns, in the lanes
+// 16 b .. 16 b + 15, the wave-wide sum of acc[b] (b < NB <= 4).
+template <int NB>
+static __device__ __forceinline__ float wave_sum_groups(const float (&acc)[NB]) {
+    static_assert(NB >= 1 && NB <= 4, "one 16-lane group per accumulator");
+    const int g = (threadIdx.x >> 4) & 3;
+    float r = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[b]), __float_as_uint(acc[b]), false, false);
+        const float v = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const float w = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        r = g == b ? w : r;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+    return r;
+}
+
 // acc[b] += sum over the 4 loaded 8-element groups of w * act[b], in fma4's order (u ascending, j ascending) with the weight
 // converted ONCE for all NB sequences.  act: this lane's 32 activation values per sequence (registers).
 template <int NB>
@@ -155,13 +178,8 @@ static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, 
             fma4_lds32<NB>(buf[t], sa, g.K1, t * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) load4(g.W1 + (int64_t)nn * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc1[b] = wave_sum(acc1[b]);
-        if (lane == 0) {
-            const float b2 = g.b1[n];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) g.y2[(int64_t)b * g.N + n] = acc1[b] + b2;
-        }
+        const float tot = wave_sum_groups<NB>(acc1);
+        if ((lane & 15) == 0 && (lane >> 4) < NB) g.y2[(int64_t)(lane >> 4) * g.N + n] = tot + g.b1[n];
         n = nn;
     }
 }
