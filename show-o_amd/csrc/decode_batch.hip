@@ -63,7 +63,7 @@ struct LnGemvBArgs {
 template <int NB, bool REG, int R = 2>
 __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048; R = weight rows in flight per wave
     extern __shared__ bf16_t sh[];  // [NB][H] normalised rows (bf16, like showo_layernorm_f32_bf16's output)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
     const int H = g.H, Ntot = g.N0 + g.N1;
     const int stride = gridDim.x * 4;
     int n = blockIdx.x * 4 + wave;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
 template <int C, int NB>
 __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
     extern __shared__ bf16_t sa[];  // [NB][K0 + K1]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
     const int stride = gridDim.x * 8;
     const int c0 = (g.K0 + 2047) / 2048;
     const int KK = g.K0 + g.K1;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
 // in registers.
 template <int NB>
 __global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
     const int stride = gridDim.x * 8;
     int n = blockIdx.x * 8 + wave;
     uint4 buf[4];
@@ -265,17 +265,21 @@ __global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
         }
     while (n < g.N) {
         const int nn = n + stride;
+        // epilogue operands of this column requested up front (they do not depend on the products): no dependent round trip at the tail
+        const bool writer = (lane & 15) == 0 && (lane >> 4) < NB;
+        const int64_t i = (int64_t)(lane >> 4) * g.N + n;
+        float xv = 0.f, yv = 0.f, bd = 0.f;
+        if (writer) { xv = g.x[i]; yv = g.y2[i]; bd = g.b0[n]; }
         float acc0[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc0[b] = 0.f;
         fma4_regs<NB>(buf, act, lane * 8, g.K0, acc0);
         if (nn < g.N) load4(g.W0 + (int64_t)nn * g.K0, lane * 8, g.K0, buf);
         const float tot = wave_sum_groups<NB>(acc0);
-        if ((lane & 15) == 0 && (lane >> 4) < NB) {
-            const int64_t i = (int64_t)(lane >> 4) * g.N + n;
-            float v = tot + g.b0[n];
-            v += g.x[i];
-            float v2 = g.y2[i];
+        if (writer) {
+            float v = tot + bd;
+            v += xv;
+            float v2 = yv;
             v2 += v;
             g.x[i] = v2;
         }
@@ -535,7 +539,7 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
     const int64_t per_seq = (int64_t)nH * d->cap * 64, lstride = (int64_t)nb * per_seq;
     // co-scheduled layer (fc2 streams next to the latency-bound attention blocks): Phi-1.5's shape, 2..4 sequences (the fc2 role
     // keeps nb x 8192 fp32 activations in LDS); SHOWO_DECODE_BATCH_CO=0 / other shapes: three plain launches per layer
-    static int co_on = -1, co_blocks = 96;
+    static int co_on = -1, co_blocks = 128;  // 128 role blocks + 32 nb attention blocks = one block per CU at nb = 4 (r5e sweep: 64 / 96 / 128 -> 1.64 / 1.53 / 1.49 ms per step)
     if (co_on < 0) {
         const char* env = getenv("SHOWO_DECODE_BATCH_CO");
         co_on = env ? (atoi(env) != 0) : 1;
