@@ -26,13 +26,19 @@ int showo_abi_version(void);
 /* number of compute units / wave size of the current device; used by bench/tests for sanity. */
 int showo_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
-/* A HIP stream whose kernels never run on `reserve` of the device's CUs (every (CUs / reserve)-th CU id: spread over the XCDs); 0 = a
- * plain non-blocking stream.  The data-parallel trainer runs its compute on such a stream while gradient buckets are being
+/* A HIP stream whose kernels never run on `reserve` of the device's CUs (a multiple of 8: reserve / 8 CUs of EVERY XCD, since blocks
+ * are dealt to the XCDs round-robin); 0 = a plain non-blocking stream.  The data-parallel trainer runs its compute on such a stream while gradient buckets are being
  * all-reduced, so that RCCL's channel kernels (training/train.py:449,612 through accelerate / DeepSpeed in the reference) find idle
  * CUs instead of queueing behind full-chip GEMM grids.  Destroy with showo_stream_destroy. */
 int showo_stream_create_cu_mask(int reserve, void** stream_out);
 int showo_stream_destroy(void* stream);
-int showo_cu_reserved_max(void);  /* largest `reserve` of any masked stream created so far (0 = none) */
+int showo_cu_reserved_max(void);  /* largest `reserve` among the LIVE masked streams (0 = none) */
+/* CUs a launch on `stream` may use (device CUs minus the stream's reserve): the one number every grid-sizing rule reads (split-K
+ * targets, tile-height model, cooperative-residency test), so launches on a masked stream are sized for what they can occupy */
+int showo_cu_usable(void* stream);
+/* which CUs does a launch on `stream` run on?  Launches `blocks` one-wave blocks and records per block (xcc_id << 16) | hw_id bits
+ * (se, sh, cu) into ids int32 [blocks] (device): tests count the distinct CUs per XCD under a mask. */
+int showo_cu_census(int32_t* ids, int blocks, int spin, void* stream);
 
 /* per-launch HIP-event timing of the hot kernels (bench.py roofline leg).  kind: 0 = GEMM, 1 = attention,
  * 2 = conv.  read() synchronises the device and returns summed elapsed ms, launch count, summed algorithmic flops. */
@@ -572,6 +578,11 @@ int showo_train_losses(showo_trainer* t, float* out3, void* stream);
 int showo_train_bind_param(showo_trainer* t, const char* key, float* param, float* exp_avg, float* exp_avg_sq, int64_t n);
 int showo_train_adamw_step(showo_trainer* t, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                            void* stream);
+/* torch.nn.utils.clip_grad_norm_ on a flat fp32 gradient buffer (reference training/train.py:614-615): g *= min(max_norm /
+ * (||g||_2 + 1e-6), 1).  Fixed-order reduction (block partials in double, one block sums them in index order), the coefficient stays in
+ * device memory: out2 (device, 2 floats) = {total norm, coefficient}; ws = showo_grad_clip_ws_doubles() doubles of scratch. */
+int showo_grad_clip_norm(float* g, int64_t n, float max_norm, double* ws, float* out2, void* stream);
+int showo_grad_clip_ws_doubles(void);
 int showo_gelu_bf16(const uint16_t* f, uint16_t* a, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -160,6 +160,10 @@ _PROTOS = {
     "showo_stream_create_cu_mask": [c_i, C.POINTER(c_p)],
     "showo_stream_destroy": [c_p],
     "showo_cu_reserved_max": [],
+    "showo_cu_usable": [c_p],
+    "showo_grad_clip_norm": [c_p, c_i64, c_f, c_p, c_p, c_p],
+    "showo_grad_clip_ws_doubles": [],
+    "showo_cu_census": [c_p, c_i, c_i, c_p],
     "showo_prof_enable": [c_i],
     "showo_prof_reset": [],
     "showo_prof_read": [c_i, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)],

@@ -526,3 +526,24 @@ int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t 
     return 0;
 }
 }  // namespace showo
+
+
+// ---- CU census (tests of showo_stream_create_cu_mask): where do the blocks of a launch on this stream run?
+namespace {
+__global__ __launch_bounds__(64) void cu_census_kernel(int32_t* __restrict__ ids, int spin) {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    // keep the block alive for a while so that the launch spreads over every CU it is allowed on
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (long long)spin) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) ids[blockIdx.x] = (int32_t)(((xcc & 0xf) << 16) | (hw & 0xff00u));  // HW_ID: cu [11:8], sh [12], se [15:13]
+}
+}  // namespace
+extern "C" int showo_cu_census(int32_t* ids, int blocks, int spin, void* stream) {
+    if (!ids || blocks < 1) return showo::set_error_msg(1, "cu_census: bad argument");
+    cu_census_kernel<<<dim3(blocks), dim3(64), 0, (hipStream_t)stream>>>(ids, spin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return showo::set_error_hip(e, "cu_census launch", __FILE__, __LINE__);
+    return 0;
+}

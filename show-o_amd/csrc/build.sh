@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-r
 OBJS=""
 PIDS=""
 mkdir -p _build
-for f in basic gemm gemm2p gemm3w gemm4h gemm_tn attention attention_bwd train_kernels decode decode_batch prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops precise; do
+for f in basic gemm gemm2p gemm3w gemm_tn attention attention_bwd train_kernels decode decode_batch prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops precise; do
   if [ ! -f _build/$f.o ] || [ $f.hip -nt _build/$f.o ] || [ common.h -nt _build/$f.o ] || [ engine.h -nt _build/$f.o ] || [ gemm_common.h -nt _build/$f.o ] || [ decode_common.h -nt _build/$f.o ] || [ prof.h -nt _build/$f.o ] || [ ../../include/showo_hip.h -nt _build/$f.o ]; then
     rm -f _build/$f.o
     hipcc $FLAGS -c $f.hip -o _build/$f.o &

@@ -105,35 +105,68 @@ extern "C" int showo_prof_read(int kind, double* total_ms, int64_t* launches, do
 // conv kernels launch one 512-thread block per CU on all 256 CUs; RCCL's channel kernels need CUs of their own, and on a full chip they
 // queue behind whole GEMM tiles.  A stream created with a CU mask keeps `reserve` CUs (spread evenly over the 8 XCDs: every 256/reserve-th
 // CU id) out of every kernel launched on it; RCCL's own streams are unmasked and find those CUs idle.  reserve = 0: plain stream.
-static int g_cu_reserved_max = 0;
-// largest `reserve` any masked stream of this process was created with: kernels that need every block of a launch resident at once
-// (cooperative split-K reduction) size their residency check by it
-extern "C" int showo_cu_reserved_max(void) { return g_cu_reserved_max; }
+// Live masked streams of this process (stream -> reserve).  Everything that sizes a grid from the CU count asks showo_cu_usable(stream):
+// split-K targets of gemm2p / gemm_tn / the split-precision conv, the tile-height model, the residency test of the cooperative split-K
+// reduction -- ONE place, so a launch on a masked stream is sized for the CUs it may actually use (grids sized to 256
+// CUs fell into a second round on 240 and cost 20-45 %).
+#include <map>
+#include <mutex>
+static std::mutex g_mask_mu;
+static std::map<hipStream_t, int> g_masked;
+extern "C" int showo_cu_reserved_max(void) {
+    std::lock_guard<std::mutex> lock(g_mask_mu);
+    int m = 0;
+    for (auto& kv : g_masked) m = kv.second > m ? kv.second : m;
+    return m;
+}
+static int device_cus() {
+    static int cus = 0;
+    if (!cus && showo_device_info(&cus, nullptr, nullptr, 0)) cus = 256;
+    return cus;
+}
+extern "C" int showo_cu_usable(void* stream) {
+    std::lock_guard<std::mutex> lock(g_mask_mu);
+    auto it = g_masked.find((hipStream_t)stream);
+    return device_cus() - (it == g_masked.end() ? 0 : it->second);
+}
 extern "C" int showo_stream_create_cu_mask(int reserve, void** out) {
     if (!out || reserve < 0) return showo::set_error_msg(1, "stream_create_cu_mask: bad argument");
-    int cus = 0;
-    if (showo_device_info(&cus, nullptr, nullptr, 0)) return 7;
+    const int cus = device_cus();
     if (reserve >= cus) return showo::set_error_msg(1, "stream_create_cu_mask: reserve must be smaller than the CU count");
+    constexpr int XCC = 8;  // MI355X: 8 XCDs x 32 CUs; kernels are dealt to the XCDs round-robin, so every XCD must lose the same number
+    if (reserve % XCC || cus % XCC) return showo::set_error_msg(1, "stream_create_cu_mask: reserve must be a multiple of 8 (the same number of CUs per XCD)");
     hipStream_t s = nullptr;
     hipError_t e;
     if (reserve == 0) {
         e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     } else {
+        // KFD interleaves the mask bits across the XCCs: bit i is CU (i / 8) of XCC (i % 8).  Each XCC loses reserve / 8 CUs, spread
+        // over its 32 (clearing every (256 / reserve)-th bit took them all from XCC 0).
         std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
         for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-        for (int k = 0; k < reserve; ++k) {
-            const int i = (int)(((int64_t)k * cus) / reserve);
-            mask[i >> 5] &= ~(1u << (i & 31));
-        }
+        const int per = reserve / XCC, cpx = cus / XCC;
+        for (int x = 0; x < XCC; ++x)
+            for (int j = 0; j < per; ++j) {
+                const int i = x + XCC * (int)(((int64_t)j * cpx) / per + cpx / (2 * per));
+                mask[i >> 5] &= ~(1u << (i & 31));
+            }
+        // (a stream created this way is a BLOCKING stream: it synchronises with the legacy null stream, unlike the reserve = 0 form)
         e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
     }
     if (e != hipSuccess) return showo::set_error_hip(e, "stream create (CU mask)", __FILE__, __LINE__);
-    if (reserve > g_cu_reserved_max) g_cu_reserved_max = reserve;
+    if (reserve > 0) {
+        std::lock_guard<std::mutex> lock(g_mask_mu);
+        g_masked[s] = reserve;
+    }
     *out = (void*)s;
     return 0;
 }
 extern "C" int showo_stream_destroy(void* stream) {
     if (!stream) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_mask_mu);
+        g_masked.erase((hipStream_t)stream);
+    }
     hipError_t e = hipStreamDestroy((hipStream_t)stream);
     return e == hipSuccess ? 0 : showo::set_error_hip(e, "hipStreamDestroy", __FILE__, __LINE__);
 }

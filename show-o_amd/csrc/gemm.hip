@@ -465,323 +465,8 @@ int dispatch2(const GemmArgs& g, const Loader& ld, int epilogue, hipStream_t s) 
     return set_error_msg(1, "gemm: unknown epilogue");
 }
 
-// =====================================================================================================
-// v3: 256 x 256 x 64 tile, 8 waves, "phase-split" schedule (CDNA4 playbook T3+T4+T5), linear operands only.
-//   * waves 0-3 (group 0, wm = 0) and waves 4-7 (group 1, wm = 1) run the same phase program ONE BARRIER APART:
-//     while one group is in its MFMA segment the other is in its LDS-read / DMA-issue segment, so each SIMD's
-//     matrix pipe alternates between its two resident waves and never waits for a staging step.
-//   * a k-tile is 4 phases of 16 MFMAs (one quadrant 2(n) x 4(m) fragments x K=64 of the 64(n) x 128(m) wave tile):
-//       ph0: ds_read W[n0..3] + A[m0..3] (16 x b128), DMA A-half0 of tile t+1     MFMA (n01, m0-3)
-//       ph1:                                          DMA A-half1 of tile t+1     MFMA (n23, m0-3)
-//       ph2: ds_read A[m4..7] (8 x b128),             DMA W-half0 of tile t+2     MFMA (n23, m4-7)
-//       ph3:                                          DMA W-half1 of tile t+2     MFMA (n01, m4-7)
-//            then s_waitcnt vmcnt(4): everything but the two W halves just issued has landed (= all of tile t+1)
-//   * HBM -> LDS by global_load_lds (16 B/lane); the DMA queue is never drained inside the loop (counted vmcnt),
-//     raw s_barrier (a __syncthreads() would emit vmcnt(0)).
-//   * WAR: a region is re-staged >= 2 phases after the phase that issued its last ds_read (the reads are retired by
-//     the lgkmcnt wait at the head of that phase's MFMA segment, one barrier before the earliest re-stage).
-//     RAW: every wave waits for its own DMA pieces (vmcnt) in ph3, the reads start in the next phase, i.e. after a
-//     barrier that all 8 waves passed after their wait.
-// =====================================================================================================
-
-// ABL (timing ablations, results are garbage): bit0 = no ds_read in the loop, bit1 = no DMA in the loop, bit2 = no barriers
-template <int EPI, int PH, bool DBG, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tilesM = (g.M + B2 - 1) / B2, tilesN = (g.N + B2 - 1) / B2;
-    int nwg = tilesM * tilesN, bid = blockIdx.x;
-    {
-        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    // grouped order: gn n-panels wide, m fastest inside a group -> the ~32 tiles an XCD runs at once share
-    // gn weight panels and ~32/gn activation panels (instead of 1 and 32)
-    int tn, tm;
-    {
-        const int per = g.gn * tilesM;
-        const int grp = bid / per, rem = bid - grp * per;
-        const int first = grp * g.gn;
-        const int gsz = min(tilesN - first, g.gn);
-        tm = rem / gsz;
-        tn = first + (rem - tm * gsz);
-    }
-    const int m0 = tm * B2, n0 = tn * B2;
-    const int nk = g.K / BK;
-    const int wn = wave & 3, wm = wave >> 2;
-#define bar_raw() do { if (!(ABL & 4)) bar_raw_fn(); } while (0)
-    unsigned long long* dbgl = reinterpret_cast<unsigned long long*>(smem_raw + SMEM3_BYTES) + wave * 64;
-    int dslot = 0;
-    (void)dbgl; (void)dslot;
-#define P3_TS(T)                                                                                                  \
-    if (DBG) {                                                                                                    \
-        if ((T) >= 8 && (T) < (PH == 2 ? 12 : 10)) {                                                                            \
-            unsigned long long ts_ = __builtin_readcyclecounter();                                                \
-            if (lane == 0) dbgl[dslot] = ts_;                                                                     \
-            ++dslot;                                                                                              \
-        }                                                                                                         \
-    }
-
-    // ---- DMA roles.  A piece = 8 rows x 128 B = one wave-instruction (16 B/lane); its LDS image is lane-linear, so the
-    // (row & 7) chunk swizzle is applied to the SOURCE address.  Source = wave-uniform base (SGPR pair, advanced by the
-    // k offset) + per-lane 32-bit byte offset: a DMA costs no vector ALU and the thread keeps 8 offsets, not 8 pointers.
-    //   W half-tile h (128 rows): pieces wave, wave+8                       -> woff[h][0..1]
-    //   A quarter (q, h) = rows h*128 + q*64 .. +63 (q=0: the m0-3 fragments of group h, q=1: m4-7): piece wave -> aoff[q][h]
-    const int srow = lane >> 3;
-    const int coff = ((lane & 7) ^ srow) << 3;
-    uint32_t woff[2][2], aoff[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = h * 128 + i * 64 + wave * 8 + srow;
-            int n = n0 + row, m = m0 + row;
-            n = n < g.N ? n : g.N - 1;
-            m = m < g.M ? m : g.M - 1;
-            woff[h][i] = (uint32_t)(((int64_t)n * g.ldw + coff) * 2);
-            aoff[i][h] = (uint32_t)(((int64_t)m * g.lda + coff) * 2);
-        }
-    const char* wbase = reinterpret_cast<const char*>(g.W);
-    const char* abase = reinterpret_cast<const char*>(g.A);
-    // LDS (elements): W[buf][256][64] at 0, A[buf][256][64] at 2*256*64 -- both buffers of an operand sit within the
-    // 64 KiB immediate range of one base address register.
-#define P3_DMA_W(BUF, H, I, K0)                                                                                   \
-    if (!(ABL & 2) || first_read) glds16(reinterpret_cast<const bf16_t*>(wbase + (size_t)(K0) * 2 + (size_t)woff[H][I]),                         \
-           smem + (BUF) * 256 * 64 + ((H) * 128 + (I) * 64 + wave * 8) * 64)
-#define P3_DMA_A(BUF, Q, H, K0)                                                                                   \
-    if (!(ABL & 2) || first_read) glds16(reinterpret_cast<const bf16_t*>(abase + (size_t)(K0) * 2 + (size_t)aoff[Q][H]),                         \
-           smem + 2 * 256 * 64 + (BUF) * 256 * 64 + ((H) * 128 + (Q) * 64 + wave * 8) * 64)
-#define P3_STAGE_W(BUF, H, K0) do { P3_DMA_W(BUF, H, 0, K0); P3_DMA_W(BUF, H, 1, K0); } while (0)
-#define P3_STAGE_A(BUF, H, K0) do { P3_DMA_A(BUF, 0, H, K0); P3_DMA_A(BUF, 1, H, K0); } while (0)
-#define P3_STAGE_AQ(BUF, Q, K0) do { P3_DMA_A(BUF, Q, 0, K0); P3_DMA_A(BUF, Q, 1, K0); } while (0)
-
-    // ---- fragment read addresses (elements).  row & 7 == fr & 7 for every fragment row of this lane.
-    const int fr = lane & 15, fg = lane >> 4;
-    const int lsw0 = fr * 64 + ((fg ^ (fr & 7)) << 3);  // k-step 0 chunk; k-step 1 = chunk ^ 4
-    const int lsw1 = fr * 64 + (((fg + 4) ^ (fr & 7)) << 3);
-    const bf16_t* ldsW = smem + (wn * 64) * 64;
-    const bf16_t* ldsA = smem + 2 * 256 * 64 + (wm * 128) * 64;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[2][4], af[2][4];
-    bool first_read = true;  // ablation builds read the fragments once
-    (void)first_read;
-
-#define P3_READ_W(BUF)                                                                                            \
-    if (!(ABL & 1) || first_read) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-        wf[0][i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * 256 * 64 + i * 16 * 64 + lsw0);            \
-        wf[1][i] = *reinterpret_cast<const bf16x8*>(ldsW + (BUF) * 256 * 64 + i * 16 * 64 + lsw1);            \
-    }
-#define P3_READ_A(BUF, MB)                                                                                        \
-    if (!(ABL & 1) || first_read) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
-        af[0][j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * 256 * 64 + ((MB) + j) * 16 * 64 + lsw0);   \
-        af[1][j] = *reinterpret_cast<const bf16x8*>(ldsA + (BUF) * 256 * 64 + ((MB) + j) * 16 * 64 + lsw1);   \
-    }
-#define P3_MFMA(NB, MB)                                                                                           \
-    do {                                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-                    acc[(NB) + i][(MB) + j] =                                                                     \
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][(NB) + i], af[kk][j], acc[(NB) + i][(MB) + j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                            \
-    } while (0)
-
-    // one k-tile (4 phases).  BUF is a literal so every LDS address is base + immediate.
-#define P3_TILE(BUF, T)                                                                                           \
-    do {                                                                                                          \
-        const int kA = ((T) + 1) * BK, kW = ((T) + 2) * BK;                                                       \
-        const bool hasA = (T) + 1 < nk, hasW = (T) + 2 < nk;                                                      \
-        /* ph0 */                                                                                                 \
-        P3_READ_W(BUF)                                                                                            \
-        P3_READ_A(BUF, 0)                                                                                         \
-        if (hasA) P3_STAGE_A((BUF) ^ 1, 0, kA);                                                                   \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        P3_MFMA(0, 0);                                                                                            \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        /* ph1 */                                                                                                 \
-        if (hasA) P3_STAGE_A((BUF) ^ 1, 1, kA);                                                                   \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        P3_MFMA(2, 0);                                                                                            \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        /* ph2 */                                                                                                 \
-        P3_READ_A(BUF, 4)                                                                                         \
-        if (hasW) P3_STAGE_W(BUF, 0, kW);                                                                         \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        P3_MFMA(2, 4);                                                                                            \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        /* ph3 */                                                                                                 \
-        if (hasW) {                                                                                               \
-            P3_STAGE_W(BUF, 1, kW);                                                                               \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                      \
-        } else {                                                                                                  \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-        }                                                                                                         \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        P3_MFMA(0, 4);                                                                                            \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-    } while (0)
-
-    // 2-phase form: a k-tile is 2 phases of 32 MFMAs (all 4 n fragments x 4 m fragments x K=64); half the barriers.
-    //   ph0: ds_read W[n0..3] + A[m0..3]; DMA W + A-lo quarters of tile t+1 (6 pieces); vmcnt(6) retires A-hi of tile t
-    //   ph1: ds_read A[m4..7];            DMA A-hi quarters of tile t+1 (2 pieces);     vmcnt(2) retires W + A-lo of t+1
-    //   every DMA has one full phase (two barrier intervals) between issue and its wait; regions are re-staged exactly
-    //   2 phases after the phase that read them last.
-#define P3_MFMA32(MB)                                                                                             \
-    do {                                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                            \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-                    acc[i][(MB) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], af[kk][j], acc[i][(MB) + j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                            \
-    } while (0)
-#define P2_TILE(BUF, T)                                                                                           \
-    do {                                                                                                          \
-        const int kN = ((T) + 1) * BK;                                                                            \
-        const bool has1 = (T) + 1 < nk;                                                                           \
-        /* ph0 */                                                                                                 \
-        P3_READ_W(BUF)                                                                                            \
-        P3_READ_A(BUF, 0)                                                                                         \
-        if (has1) {                                                                                               \
-            P3_STAGE_W((BUF) ^ 1, 0, kN);                                                                         \
-            P3_STAGE_W((BUF) ^ 1, 1, kN);                                                                         \
-            P3_STAGE_AQ((BUF) ^ 1, 0, kN);                                                                        \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                      \
-        } else {                                                                                                  \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-        }                                                                                                         \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        P3_MFMA32(0);                                                                                             \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        /* ph1 */                                                                                                 \
-        P3_READ_A(BUF, 4)                                                                                         \
-        if (has1) {                                                                                               \
-            P3_STAGE_AQ((BUF) ^ 1, 1, kN);                                                                        \
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                      \
-        } else {                                                                                                  \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-        }                                                                                                         \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-        P3_MFMA32(4);                                                                                             \
-        bar_raw();                                                                                                \
-        P3_TS(T)                                                                                                  \
-    } while (0)
-
-    // ---- prologue: all of tile 0 (4-phase form: plus the W halves of tile 1)
-    P3_STAGE_W(0, 0, 0);
-    P3_STAGE_W(0, 1, 0);
-    P3_STAGE_A(0, 0, 0);
-    P3_STAGE_A(0, 1, 0);
-    if (PH == 4 && nk > 1) {
-        P3_STAGE_W(1, 0, BK);
-        P3_STAGE_W(1, 1, BK);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    bar_raw();
-    const bool stagger = !(g.flags & 1);
-    if (wm == 1 && stagger) bar_raw();  // group 1 runs one barrier behind group 0
-
-    int t = 0;
-    if (PH == 4) {
-        for (; t + 1 < nk; t += 2) {
-            P3_TILE(0, t);
-            P3_TILE(1, t + 1);
-        }
-        if (t < nk) P3_TILE(0, t);
-    } else {
-        for (; t + 1 < nk; t += 2) {
-            P2_TILE(0, t);
-            if (ABL) first_read = false;
-            P2_TILE(1, t + 1);
-        }
-        if (t < nk) P2_TILE(0, t);
-    }
-    if (wm == 0 && stagger) bar_raw();  // re-align the barrier counts of the two groups
-    if (DBG) {
-        __syncthreads();
-        if (blockIdx.x == 0 && g.dbg) g.dbg[tid] = dbgl[lane];
-    }
-
-    epilogue8p<EPI, 8>(g, acc, n0, wn, m0 + wm * 128, fr, fg, nullptr);
-#undef bar_raw
-#undef P3_TILE
-#undef P2_TILE
-#undef P3_MFMA32
-#undef P3_TS
-#undef P3_STAGE_AQ
-#undef P3_DMA_A
-#undef P3_DMA_W
-#undef P3_MFMA
-#undef P3_READ_A
-#undef P3_READ_W
-#undef P3_STAGE_A
-#undef P3_STAGE_W
-}
-
-template <int EPI, int PH, bool DBG = false, int ABL = 0>
-int launch3(const GemmArgs& g, hipStream_t s) {
-    static bool attr_set = false;
-    auto kfn = gemm8p_kernel<EPI, PH, DBG, ABL>;
-    const int smem = SMEM3_BYTES + (DBG ? 4096 : 0);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(gemm8p)", __FILE__, __LINE__);
-        attr_set = true;
-    }
-    int tilesM = (g.M + B2 - 1) / B2, tilesN = (g.N + B2 - 1) / B2;
-    kfn<<<dim3(tilesM * tilesN), dim3(512), smem, s>>>(g);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_error_hip(e, "gemm8p launch", __FILE__, __LINE__);
-    return 0;
-}
-
-int g_gemm_flags = 0;  // (g_gemm_gn lives in gemm2p.hip) 4 n-panels per XCD tile group: same-process sweep on the bench workload 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s
+int g_gemm_flags = 0;  // experiment flags of showo_gemm_tune (bits 0..7)
 unsigned long long* g_gemm_dbg = nullptr;
-
-template <int PH>
-int dispatch3(GemmArgs g, int epilogue, hipStream_t s) {
-    g.gn = g_gemm_gn > 0 ? g_gemm_gn : 1;
-    g.flags = g_gemm_flags;
-    g.dbg = g_gemm_dbg;
-    if (g_gemm_dbg && epilogue == SHOWO_EPI_BF16) return launch3<SHOWO_EPI_BF16, PH, true>(g, s);
-    if (PH == 2 && epilogue == SHOWO_EPI_BF16 && (g.flags >> 4)) {  // timing ablations (tools/gemm_bench.cpp)
-        switch (g.flags >> 4) {
-            case 1: return launch3<SHOWO_EPI_BF16, PH, false, 1>(g, s);
-            case 2: return launch3<SHOWO_EPI_BF16, PH, false, 2>(g, s);
-            case 3: return launch3<SHOWO_EPI_BF16, PH, false, 3>(g, s);
-            case 7: return launch3<SHOWO_EPI_BF16, PH, false, 7>(g, s);
-        }
-    }
-    switch (epilogue) {
-        case SHOWO_EPI_BF16: return launch3<SHOWO_EPI_BF16, PH>(g, s);
-        case SHOWO_EPI_GELU_BF16: return launch3<SHOWO_EPI_GELU_BF16, PH>(g, s);
-        case SHOWO_EPI_F32: return launch3<SHOWO_EPI_F32, PH>(g, s);
-        case SHOWO_EPI_RESID_F32: return launch3<SHOWO_EPI_RESID_F32, PH>(g, s);
-    }
-    return set_error_msg(1, "gemm: unknown epilogue");
-}
-
 
 // =====================================================================================================
 // GEMV form for decode steps (M <= 8 token rows): the weight matrix is streamed ONCE straight into VGPRs (no LDS round
@@ -883,7 +568,7 @@ int gemm_impl_choice(int M, int N) {
         const char* e = getenv("SHOWO_GEMM_IMPL");
         g_gemm_forced = e ? atoi(e) : 0;
     }
-    if (g_gemm_forced >= 1 && g_gemm_forced <= 6) return g_gemm_forced;
+    if (g_gemm_forced == 1 || g_gemm_forced == 2 || g_gemm_forced == 5 || g_gemm_forced == 6) return g_gemm_forced;
     if (M <= 8) return 6;  // decode step: weight-streaming GEMV
     // phase-split 256-wide kernel from 256 rows up: measured on the prefill (tools/prefill_sweep.py) 631 rows 11.3 -> 9.3 ms,
     // 387 rows 10.3 -> 9.6 ms against the 128x128 kernel
@@ -894,7 +579,7 @@ int gemm_impl_choice(int M, int N) {
 
 // 0 = choose by shape (default), 1 = 128^2 register-staged kernel, 2 = 256^2 global_load_lds kernel
 extern "C" int showo_gemm_set_impl(int impl) {
-    g_gemm_forced = (impl >= 1 && impl <= 6) ? impl : 0;
+    g_gemm_forced = (impl == 1 || impl == 2 || impl == 5 || impl == 6) ? impl : 0;  // (3 / 4 = the 4-phase rung of round 1, removed from the library in round 5)
     return 0;
 }
 
@@ -934,8 +619,6 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     int impl = gemm_impl_choice(M, N);
     // the phase-split kernels address both operands as base + 32-bit byte offset
     if (impl >= 3 && ((int64_t)M * lda * 2 >= ((int64_t)1 << 32) || (int64_t)N * ldw * 2 >= ((int64_t)1 << 32))) impl = 2;
-    if (impl == 3) return dispatch3<4>(g, epilogue, (hipStream_t)stream);
-    if (impl == 4) return dispatch3<2>(g, epilogue, (hipStream_t)stream);
     if (impl == 6 && M <= 8 && (K % 8) == 0) return dispatch_gemv(g, epilogue, (hipStream_t)stream);
     if (impl == 6) impl = 1;
     if (impl == 5) return gemm2p_dispatch(g, epilogue, (hipStream_t)stream);
@@ -1484,8 +1167,9 @@ int launch_conv2p_split(const GemmArgs& g, const ConvArgs& c, hipStream_t s) {
     gs.splits = 1;
     static int splitk_on = -1;
     if (splitk_on < 0) { const char* e = getenv("SHOWO_CONV_SPLITK"); splitk_on = e ? atoi(e) : 1; }
-    if (splitk_on && tiles * 2 <= 256 && nk >= 32) {
-        int S = 256 / tiles;
+    const int cus = showo_cu_usable((void*)s);  // the CUs this stream may use (256 unless it is a masked stream)
+    if (splitk_on && tiles * 2 <= cus && nk >= 32) {
+        int S = cus / tiles;
         if (S > nk / 16) S = nk / 16;
         if (S > 16) S = 16;
         if (S >= 2) {

@@ -365,23 +365,54 @@ int splitk_coop_mode() {  // SHOWO_GEMM_COOP: 2 (default) = write-through (sc1) 
     if (m < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); m = e ? atoi(e) : 2; }
     return m == 1 ? 1 : 2;
 }
-bool splitk_coop_ok(int blocks) {
-    static int cus = 0, on = -1;
-    if (on < 0) { const char* e = getenv("SHOWO_GEMM_COOP"); on = e ? atoi(e) : 1; }
-    if (!cus) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+// Residency: blocks are dealt to the 8 XCDs round-robin, so the test is per XCD -- ceil(blocks / 8) blocks on the usable(stream) / 8 CUs
+// of one XCD (a global count admits launches whose XCD share does not fit under an uneven mask).
+// Ownership: the spin-wait of splitk_coop_finish is only safe when NOTHING else can take CUs away from a half-resident launch.  Two
+// cooperative launches on different streams could each be partly resident and wait for each other until the trap, so ONE
+// stream at a time owns the cooperative form: the first stream that asks; another stream takes over only when the owner's last
+// cooperative launch has completed (event), and a stream that CAPTURED cooperative launches into a hipGraph keeps the ownership (the
+// graph may replay at any time).  Everybody else gets the last-arriver reduction: the same bits, no waiting.  Disabled altogether while
+// the opt-in side-stream experiments (SHOWO_LAYER_OVERLAP / SHOWO_MALL_PF) are on.  Work of ANOTHER PROCESS on the same GPU is outside
+// this gate: SHOWO_GEMM_COOP=0 there.
+struct CoopOwner { hipStream_t s = nullptr; hipEvent_t ev = nullptr; bool sticky = false, used = false; };
+CoopOwner g_coop_owner;
+bool splitk_coop_ok(int blocks, hipStream_t s) {  // caller holds g_gemm_mu
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("SHOWO_GEMM_COOP");
+        on = e ? atoi(e) : 1;
+        const char* o1 = getenv("SHOWO_LAYER_OVERLAP");
+        const char* o2 = getenv("SHOWO_MALL_PF");
+        if (!e && ((o1 && atoi(o1)) || (o2 && atoi(o2)))) on = 0;
     }
-    return on && blocks <= cus - showo_cu_reserved_max();
+    if (!on || (blocks + 7) / 8 > showo_cu_usable((void*)s) / 8) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    CoopOwner& o = g_coop_owner;
+    if (o.used && o.s != s) {
+        if (o.sticky) return false;
+        if (o.ev && hipEventQuery(o.ev) != hipSuccess) { (void)hipGetLastError(); return false; }  // the owner's cooperative work is still in flight
+    }
+    if (!o.ev && !capturing && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    o.s = s; o.used = true;
+    if (capturing) o.sticky = true;
+    return true;
 }
-int splitk_count(int M, int N, int K) {
+void splitk_coop_launched(hipStream_t s) {  // after a cooperative launch outside a capture: marks the end of the owner's cooperative work
+    CoopOwner& o = g_coop_owner;
+    if (o.sticky || !o.ev) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)hipEventRecord(o.ev, s);
+}
+// split count for a launch that may use `cus` CUs (showo_cu_usable(stream): 256 on a plain stream).  A function of the problem and of
+// that number alone -- never of the tile variant -- so every variant produces the same bits under a given CU budget.
+int splitk_count(int M, int N, int K, int cus) {
     if (g_gemm_splitk < 0) { const char* e = getenv("SHOWO_GEMM_SPLITK"); g_gemm_splitk = e ? atoi(e) : 1; }
     static int min_kt = 0;  // k-tiles per split at least (SHOWO_GEMM_SPLITK_MIN, default 16)
     if (!min_kt) { const char* e = getenv("SHOWO_GEMM_SPLITK_MIN"); min_kt = (e && atoi(e) >= 2) ? atoi(e) : 16; }
     const int tiles = ((M + 255) / 256) * ((N + B2 - 1) / B2), nk = K / GEMM_BK;
-    if (!g_gemm_splitk || tiles * 2 > 256 || nk < 2 * min_kt) return 1;
-    int S = 256 / tiles;
+    if (!g_gemm_splitk || tiles * 2 > cus || nk < 2 * min_kt) return 1;
+    int S = cus / tiles;
     if (S > nk / min_kt) S = nk / min_kt;
     if (S > 16) S = 16;
     if (S < 2) return 1;
@@ -406,19 +437,20 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
     // split-K: the split count S (hence the k-partition and the fp32 summation order) is a function of (M, N, K) ALONE
     // (splitk_count below): every split-capable tile variant produces the same bits, whichever one the tuner picks.
     g.splits = 1;
-    const int S = splitk_count(g.M, g.N, g.K);
+    const int S = splitk_count(g.M, g.N, g.K, showo_cu_usable((void*)s));
     if (S >= 2) {
         constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
         if (tiles * S > SPLITK_TICKS || !splitk_ws(s, (size_t)tiles * S * NFS * 512 * sizeof(float4), &g.ws, &g.tick))
             return set_error_msg(7, "gemm2p: split-K workspace unavailable (first use of a split shape inside a stream capture, or more than 8 "
                                     "streams): run the shape once eagerly, or set SHOWO_GEMM_SPLITK=0");
         g.splits = S;
-        g.coop = (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT && tiles <= 2048 && splitk_coop_ok(tiles * S)) ? splitk_coop_mode() : 0;
+        g.coop = (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT && tiles <= 2048 && splitk_coop_ok(tiles * S, s)) ? splitk_coop_mode() : 0;
         g_cnt_splitk++;
     }
     kfn<<<dim3(tiles * g.splits), dim3(512), SMEM3_BYTES, s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "gemm2p launch", __FILE__, __LINE__);
+    if (g.coop) splitk_coop_launched(s);
     return 0;
 }
 
@@ -428,10 +460,10 @@ int launch2p(const GemmArgs& g0, hipStream_t s) {
 //   m-split with a 3-deep weight ring (gemm3w.hip): 2256 (8+8), 2240 (8+7), 2224 (7+7), 2208 (7+6)
 //   n-split on the ring: 3192 (6+6), 3176 (6+5), 3160 (5+5), 3144 (5+4)
 //   the same with buffer-descriptor DMAs: 4192, 4176, 4160, 4144
-//   four waves x 128 x 128 wave tiles, 256-row tiles with short bodies for a ragged last tile row (gemm4h.hip): 5256
-constexpr int N_VARIANTS = 25;
+//   (5256, the four-wave 128 x 128-wave-tile kernel of round 4, lives in tools/experiments/gemm4h.hip: a measured negative, not shipped)
+constexpr int N_VARIANTS = 24;
 const int k_variants[N_VARIANTS] = {256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144,
-                                    4192, 4176, 4160, 4144, 5256};
+                                    4192, 4176, 4160, 4144};
 bool is_variant(int v) {
     for (int i = 0; i < N_VARIANTS; ++i)
         if (k_variants[i] == v) return true;
@@ -440,7 +472,6 @@ bool is_variant(int v) {
 
 template <int EPI>
 int launch2p_h(const GemmArgs& g, int h, hipStream_t s) {
-    if (h == 5256) return gemm4h_launch(g, EPI, s);
     if (h >= 2000) return gemm3w_launch(g, EPI, h - 2000, s);
     switch (h) {
         case 240: return launch2p<EPI, 8, 7, false>(g, s);
@@ -471,18 +502,12 @@ namespace {
 
 // model used when a shape cannot be timed (stream capture, SHOWO_GEMM_TUNE=0, small problems): rounds x (rows + fixed cost),
 // rounds = ceil(tiles / CUs); short tiles use the n-split program
-int pick_bm(int M, int N) {
+int pick_bm(int M, int N, int cus) {
     if (g_gemm_bm == 0) {  // SHOWO_GEMM_BM=<variant code> forces a tile (A/B runs of bench.py)
         const char* e = getenv("SHOWO_GEMM_BM");
         g_gemm_bm = e ? atoi(e) : -1;
     }
     if (is_variant(g_gemm_bm)) return g_gemm_bm;
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-    }
     const int tilesN = (N + B2 - 1) / B2;
     const int cand[8] = {256, 240, 224, 208, 1192, 1176, 1160, 1144};  // (the ring variants are only chosen by measurement)
     long best_cost = -1;
@@ -510,11 +535,12 @@ int g_gemm_tune = -1;
 
 template <int EPI>
 int launch2p_bm(const GemmArgs& g, hipStream_t s) {
-    if (g_gemm_bm == 0) pick_bm(g.M, g.N);  // reads SHOWO_GEMM_BM
+    const int cus = showo_cu_usable((void*)s);
+    if (g_gemm_bm == 0) pick_bm(g.M, g.N, cus);  // reads SHOWO_GEMM_BM
     if (g_gemm_bm > 0) return launch2p_h<EPI>(g, g_gemm_bm, s);
     if (g_gemm_tune < 0) { const char* e = getenv("SHOWO_GEMM_TUNE"); g_gemm_tune = e ? atoi(e) : 1; }
-    const auto key = std::make_tuple(g.M, g.N, g.K, EPI);
-    const bool split_shape = splitk_count(g.M, g.N, g.K) >= 2;  // ring variants never split: not candidates (bit-identity, see above)
+    const auto key = std::make_tuple(g.M, g.N, g.K, EPI | (cus << 8));  // the CU budget of the stream is part of the shape: other split counts, other rounds
+    const bool split_shape = splitk_count(g.M, g.N, g.K, cus) >= 2;  // ring variants never split: not candidates (bit-identity, see above)
     auto it = g_bm_cache.find(key);
     if (it != g_bm_cache.end()) {
         GemmArgs c = g;
@@ -523,16 +549,16 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    if (!g_gemm_tune || capturing || (int64_t)g.M * g.N < ((int64_t)1 << 20)) return launch2p_h<EPI>(g, pick_bm(g.M, g.N), s);
+    if (!g_gemm_tune || capturing || (int64_t)g.M * g.N < ((int64_t)1 << 20)) return launch2p_h<EPI>(g, pick_bm(g.M, g.N, cus), s);
     GemmArgs t = g;
     void* scratch = nullptr;
     if (EPI == SHOWO_EPI_RESID_F32) {  // accumulates in place: time it on a scratch output
-        if (hipMalloc(&scratch, (size_t)g.M * g.ldo * sizeof(float)) != hipSuccess) return launch2p_h<EPI>(g, pick_bm(g.M, g.N), s);
+        if (hipMalloc(&scratch, (size_t)g.M * g.ldo * sizeof(float)) != hipSuccess) return launch2p_h<EPI>(g, pick_bm(g.M, g.N, cus), s);
         t.out = scratch; t.resid = (const float*)scratch; t.ldr = g.ldo;
     }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    int best = pick_bm(g.M, g.N);
+    int best = pick_bm(g.M, g.N, cus);
     float best_ms = 1e30f;
     // interleaved passes over the candidates, 3 timed launches each, minimum per candidate: the first measurements of a process
     // run on a GPU that is still ramping its clocks, and a single sample mis-ranks tiles that differ by ~10 %
@@ -540,15 +566,10 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
     for (int ci = 0; ci < N_VARIANTS; ++ci) cand_ms[ci] = 1e30f;
     static int ring_ok = -1;  // SHOWO_GEMM_RING=0 keeps the 3-deep-ring variants (gemm3w.hip) out of the tuner (A/B runs)
     if (ring_ok < 0) { const char* e = getenv("SHOWO_GEMM_RING"); ring_ok = e ? (atoi(e) != 0) : 1; }
-    // gemm4h (variant 5256) is a candidate only on request (SHOWO_GEMM_4H=1): measured in round 4 it ties the 8-wave kernels on large
-    // cubes and loses on every pipeline shape (profiles/r4b_gemm4h_harness.txt: one wave per SIMD cannot hide its own DMA issue time)
-    static int g4h_ok = -1;
-    if (g4h_ok < 0) { const char* e = getenv("SHOWO_GEMM_4H"); g4h_ok = e ? (atoi(e) != 0) : 0; }
     for (int pass = 0; pass < 2; ++pass) {
         for (int ci = 0; ci < N_VARIANTS; ++ci) {
             const int h = k_variants[ci];
             if (h >= 2000 && (!ring_ok || split_shape)) continue;
-            if (h == 5256 && !g4h_ok) continue;
             int rc = launch2p_h<EPI>(t, h, s);  // warm-up (instruction cache, attribute set)
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch2p_h<EPI>(t, h, s);
@@ -600,13 +621,20 @@ int launch2p_bm(const GemmArgs& g, hipStream_t s) {
 }  // namespace
 
 // split-K policy / workspace / launch counters shared with gemm_tn.hip (the caller holds no lock; the workspace table is guarded here)
-int gemm_splitk_count(int M, int N, int K) { return splitk_count(M, N, K); }
+int gemm_splitk_count(int M, int N, int K, int cus) { return splitk_count(M, N, K, cus); }
 bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);
     return splitk_ws(s, need, ws, tick);
 }
 int gemm_splitk_ticks() { return SPLITK_TICKS; }
-bool gemm_splitk_coop_ok(int blocks) { return splitk_coop_ok(blocks); }
+bool gemm_splitk_coop_ok(int blocks, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_gemm_mu);
+    return splitk_coop_ok(blocks, s);
+}
+void gemm_splitk_coop_launched(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_gemm_mu);
+    splitk_coop_launched(s);
+}
 void gemm_count_launch(bool split) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);
     g_cnt_gemm2p++;

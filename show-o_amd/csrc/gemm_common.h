@@ -731,15 +731,14 @@ static __device__ __forceinline__ void epilogue_qkv_split(const GemmArgs& g, f32
 // production kernel (gemm2p.hip)
 int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOWO_EPI_* or EPI_QKV
 // split-K policy and per-stream workspace of the production family (gemm2p.hip), shared with gemm_tn.hip
-int gemm_splitk_count(int M, int N, int K);
+int gemm_splitk_count(int M, int N, int K, int cus);  // cus = showo_cu_usable(stream)
 bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
 int gemm_splitk_ticks();
-bool gemm_splitk_coop_ok(int blocks);  // tiles x splits blocks can all be resident (one per CU on the CUs no stream mask keeps free)
+bool gemm_splitk_coop_ok(int blocks, hipStream_t s);  // tiles x splits blocks can all be resident on the CUs `s` may use AND `s` owns the cooperative form
+void gemm_splitk_coop_launched(hipStream_t s);
 void gemm_count_launch(bool split);
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208
 int gemm3w_launch(const GemmArgs& g, int epilogue, int rows, hipStream_t s);
-// four-wave kernel with 128 x 128 wave tiles, accumulators in AGPRs, hand-laid instruction stream (gemm4h.hip); variant code 5256
-int gemm4h_launch(const GemmArgs& g, int epilogue, hipStream_t s);
 
 }  // namespace showo

@@ -334,7 +334,7 @@ int launch_tn(GemmArgs g, hipStream_t s) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + B2 - 1) / B2);
     // split-K: the same rule as the production kernel (a function of (M, N, K) alone -> run-to-run identical summation order)
     g.splits = 1;
-    const int S = gemm_splitk_count(g.M, g.N, g.K);
+    const int S = gemm_splitk_count(g.M, g.N, g.K, showo_cu_usable((void*)s));
     if (S >= 2) {
         if (tiles * S > gemm_splitk_ticks() || !gemm_splitk_ws(s, (size_t)tiles * S * 32 * 512 * sizeof(float4), &g.ws, &g.tick))
             return set_error_msg(7, "gemm_tn: split-K workspace unavailable (first use of a split shape inside a stream capture): run the "

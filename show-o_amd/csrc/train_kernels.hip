@@ -624,6 +624,61 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const showo::AdamSeg* 
     }
 }
 
+// ---- global-norm clipping of the flat gradient buffer (reference training/train.py:614-615 accelerator.clip_grad_norm_) ------------
+// Fixed-order reduction: block b sums the squares of its contiguous slice (per-thread fp32 chains over a fixed stride, then a fixed
+// tree in double), ONE block sums the partials in index order -> total norm and the clip coefficient in device memory; the scale
+// pass reads the coefficient there and leaves the buffer untouched when it is >= 1.  Two runs give identical bits.
+constexpr int CLIP_PARTS = 2048;
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
+    __shared__ double sh[256];
+    const int64_t chunk = ((n + CLIP_PARTS - 1) / CLIP_PARTS + 3) & ~(int64_t)3;
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    if (i0 >= n) {  // slices beyond the end (the chunk is rounded up to a multiple of 4)
+        if (threadIdx.x == 0) part[blockIdx.x] = 0.0;
+        return;
+    }
+    float a = 0.f;
+    for (int64_t i = i0 + threadIdx.x * 4; i + 3 < i1; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(g + i);
+        a += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (threadIdx.x == 0) for (int64_t i = i0 + ((i1 - i0) & ~(int64_t)3); i < i1; ++i) a += g[i] * g[i];  // tail of the last slice
+    sh[threadIdx.x] = (double)a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ part, float max_norm, float* __restrict__ out2) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < CLIP_PARTS; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(sh[0]);
+        out2[0] = total;
+        out2[1] = fminf(max_norm / (total + 1e-6f), 1.0f);  // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max = 1)
+    }
+}
+__global__ __launch_bounds__(256) void scale_by_dev_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ coef) {
+    const float c = *coef;
+    if (c >= 1.0f) return;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
+        float4 v = *reinterpret_cast<float4*>(g + i);
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        *reinterpret_cast<float4*>(g + i) = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int64_t i = n & ~(int64_t)3; i < n; ++i) g[i] *= c;
+}
+
 __global__ void scale_f32_kernel(float* __restrict__ x, int64_t n, float s) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -928,3 +983,21 @@ extern "C" int showo_gelu_bf16(const uint16_t* f, uint16_t* a, int64_t n, void* 
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+
+// g fp32 [n] (16-byte aligned): g *= min(max_norm / (||g||_2 + 1e-6), 1); ws = CLIP_PARTS doubles of scratch; out2 (device, 2 floats)
+// receives the total norm and the coefficient.  No host synchronisation.
+extern "C" int showo_grad_clip_norm(float* g, int64_t n, float max_norm, double* ws, float* out2, void* stream) {
+    if (!g || !ws || !out2 || n <= 0 || (((uintptr_t)g) & 15)) return showo::set_error_msg(1, "grad_clip_norm: bad argument (g 16-byte aligned)");
+    hipStream_t s = (hipStream_t)stream;
+    sumsq_part_kernel<<<dim3(CLIP_PARTS), dim3(256), 0, s>>>(g, n, ws);
+    clip_coef_kernel<<<dim3(1), dim3(256), 0, s>>>(ws, max_norm, out2);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    scale_by_dev_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g, n, out2 + 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return showo::set_error_hip(e, "grad_clip_norm launch", __FILE__, __LINE__);
+    return 0;
+}
+extern "C" int showo_grad_clip_ws_doubles(void) { return CLIP_PARTS; }

@@ -256,6 +256,23 @@ class Trainer:
         ex.dist.all_reduce(v, op=ex.dist.ReduceOp.SUM, group=ex.group)
         return v / ex.world
 
+    def close(self):
+        """release the CU-masked compute stream (one HIP stream per Trainer that ran with reserve_cus > 0)"""
+        h = getattr(self, "_masked_handle", None)
+        if h is not None:
+            self._masked_stream = None
+            self._masked_handle = None
+            try:
+                _lib.call("showo_stream_destroy", h)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
         """one optimisation step; returns the three losses (fp32 device tensor [3])"""
         ms = None
@@ -268,6 +285,7 @@ class Trainer:
         with torch.cuda.stream(ms):
             out = self._step(input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length)
         cur.wait_stream(ms)
+        out.record_stream(cur)  # allocated on the masked stream's pool, consumed on the caller's stream
         return out
 
     def _step(self, input_ids, attention_mask, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length):
@@ -286,17 +304,17 @@ class Trainer:
         losses = torch.empty(3, dtype=torch.float32, device=ids.device)
         # the weights of the three losses are known up front here (training/train.py:600): the forward's cross-entropy pass also
         # writes d(loss)/d(logits), so the backward does not read the [B*L, V] logits again
-        _lib.call("showo_train_set_loss_weights", tr, self.coeffs[0], self.coeffs[1], self.coeffs[2], 1)
-        try:
-            _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
-                      batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
-        finally:
-            _lib.call("showo_trainer_use_intervals", tr, None, None)
         ex = self.exchange
         nL = m.arch["num_hidden_layers"]
-        # `lab` is this step's own contiguous copy / view and is not written between the forward above and this call: the d(logits) of
-        # the forward's cross-entropy pass is reused only for the SAME forward (every forward invalidates it), pointer, split and weights.
-        try:
+        _lib.call("showo_train_set_loss_weights", tr, self.coeffs[0], self.coeffs[1], self.coeffs[2], 1)
+        try:  # ONE scope for the announcement: a forward that raises must withdraw it too
+            try:
+                _lib.call("showo_train_forward", tr, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(lab), B, L, batch_size_t2i, batch_size_lm,
+                          batch_size_mmu, max_seq_length, None, _lib.ptr(losses), s())
+            finally:
+                _lib.call("showo_trainer_use_intervals", tr, None, None)
+            # `lab` is this step's own contiguous copy / view and is not written between the forward above and this call: the d(logits)
+            # of the forward's cross-entropy pass is reused only for the SAME forward (every forward invalidates it), pointer, split and weights.
             _lib.call("showo_train_backward_head", tr, _lib.ptr(lab), batch_size_t2i, batch_size_lm, batch_size_mmu, max_seq_length,
                       self.coeffs[0], self.coeffs[1], self.coeffs[2], s())
         finally:
@@ -322,12 +340,15 @@ class Trainer:
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ over the flat gradient buffer (reference training/train.py:614-615
         `accelerator.clip_grad_norm_(model.parameters(), max_grad_norm)`): g *= max_norm / (||g||_2 + 1e-6) when that is < 1.
-        Returns the total norm (device scalar); the clip coefficient never visits the host."""
-        sq = torch.zeros((), dtype=torch.float32, device=self.buckets[0].device)
-        for b in self.buckets:
-            sq = sq + torch.linalg.vector_norm(b, 2.0, dtype=torch.float32) ** 2
-        total = sq.sqrt()
-        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        for b in self.buckets:
-            b.mul_(coef)
-        return total
+        ONE fixed-order HIP reduction over the library's flat gradient buffer + a scale pass that reads the coefficient from device
+        memory (csrc/train_kernels.hip showo_grad_clip_norm): no ATen arithmetic, no host synchronisation, bit-reproducible.
+        Returns the total norm (device scalar)."""
+        b0, bl = self.buckets[0], self.buckets[-1]
+        n = (bl.data_ptr() + bl.numel() * 4 - b0.data_ptr()) // 4
+        if sum(b.numel() for b in self.buckets) != n:
+            raise RuntimeError("gradient buckets are not one contiguous range")
+        if getattr(self, "_clip_ws", None) is None:
+            self._clip_ws = torch.empty(_lib.load().showo_grad_clip_ws_doubles(), dtype=torch.float64, device=b0.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=b0.device)
+        _lib.call("showo_grad_clip_norm", b0.data_ptr(), n, float(max_norm), _lib.ptr(self._clip_ws), _lib.ptr(out2), _lib.stream())
+        return out2[0]

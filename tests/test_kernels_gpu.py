@@ -542,7 +542,7 @@ def test_softmax_rows_and_small_conv():
     assert (out.cpu() - ref).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("impl", [1, 2, 3, 4, 5] + [5 + (v << 16) for v in (256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144, 4192, 4176, 4160, 4144)])
+@pytest.mark.parametrize("impl", [1, 2, 5] + [5 + (v << 16) for v in (256, 240, 224, 208, 176, 160, 144, 1192, 1176, 1160, 1144, 1128, 2256, 2240, 2224, 2208, 3192, 3176, 3160, 3144, 4192, 4176, 4160, 4144)])
 def test_gemm_both_tile_kernels(impl):
     """the 128^2 register-staged kernel and the 256^2 global_load_lds kernel give the same result on shapes
     with ragged M/N edges (rows/cols beyond the edge are clamped on load and predicated on store)"""
@@ -1021,3 +1021,94 @@ def test_argmax_first_maximal_index(n):
     L().call("showo_argmax_f32", L().ptr(dev(x)), n, L().ptr(out), S())
     sync()
     assert int(out) == int(torch.nonzero(x == x.max())[0])
+
+
+# ------------------------------------------------------------------------------------- CU masks, grid budgets, cooperative ownership
+def test_cu_masked_stream_takes_the_same_number_of_cus_from_every_xcd():
+    """showo_stream_create_cu_mask(r): a census kernel on the stream must find (32 - r / 8) distinct CUs on EVERY one of the 8 XCDs
+    (the round-4 mask took all of them from XCC 0), showo_cu_usable reports 256 - r for that stream only, and destroying the
+    stream withdraws the reservation"""
+    lib = L()
+    import ctypes as C2
+    cus = C2.c_int()
+    lib.call("showo_device_info", C2.byref(cus), None, None, 0)
+    total = cus.value
+    assert total % 8 == 0
+
+    def census(stream_ptr, torch_stream):
+        ids = torch.zeros(16 * total, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch_stream):
+            lib.call("showo_cu_census", lib.ptr(ids), ids.numel(), 200000, stream_ptr)
+        torch.cuda.synchronize()
+        per = {}
+        for v in ids.cpu().tolist():
+            per.setdefault(v >> 16, set()).add(v & 0xffff)
+        return {x: len(s) for x, s in per.items()}
+
+    cur = torch.cuda.current_stream()
+    full = census(cur.cuda_stream, cur)
+    assert len(full) == 8 and all(n == total // 8 for n in full.values()), full
+    assert lib.load().showo_cu_usable(C2.c_void_p(cur.cuda_stream)) == total
+    with pytest.raises(RuntimeError):  # not a multiple of 8: the XCDs would lose different numbers of CUs
+        h = C2.c_void_p()
+        lib.check(lib.load().showo_stream_create_cu_mask(12, C2.byref(h)), "showo_stream_create_cu_mask")
+    for r in (8, 16):
+        h = C2.c_void_p()
+        lib.check(lib.load().showo_stream_create_cu_mask(r, C2.byref(h)), "showo_stream_create_cu_mask")
+        ext = torch.cuda.ExternalStream(h.value)
+        got = census(h.value, ext)
+        assert len(got) == 8 and all(n == total // 8 - r // 8 for n in got.values()), (r, got)
+        assert lib.load().showo_cu_usable(h) == total - r and lib.load().showo_cu_usable(C2.c_void_p(cur.cuda_stream)) == total
+        assert lib.load().showo_cu_reserved_max() == r
+        lib.call("showo_stream_destroy", h)
+        assert lib.load().showo_cu_reserved_max() == 0
+
+
+def test_split_k_launches_on_two_streams_at_once_share_the_gpu_without_waiting_for_each_other():
+    """two cooperative split-K launches on different streams could each be partly resident and spin until the trap.  One
+    stream at a time owns the cooperative reduction, the other gets the last-arriver form -- same bits either way.  Many interleaved
+    launches of the M = 631 prefill shapes on two streams: every result equals the single-stream result bit for bit, nothing hangs."""
+    torch.manual_seed(3)
+    M, N, K = 631, 2048, 4096
+    A, W, b = torch.randn(M, K), torch.randn(N, K) * 0.02, torch.randn(N)
+    Ad, Wd, bd = dev(to_bf16_bits(A)), dev(to_bf16_bits(W)), dev(b)
+    ref = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    L().call("showo_gemm_bf16", L().ptr(Ad), K, L().ptr(Wd), K, L().ptr(bd), 0, L().ptr(ref), N, None, 0, M, N, K, 2, S())
+    sync()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.empty_like(ref) for _ in range(16)]
+    for i, o in enumerate(outs):
+        st = s1 if i % 2 == 0 else s2
+        with torch.cuda.stream(st):
+            L().call("showo_gemm_bf16", L().ptr(Ad), K, L().ptr(Wd), K, L().ptr(bd), 0, L().ptr(o), N, None, 0, M, N, K, 2, st.cuda_stream)
+    sync()
+    for o in outs:
+        assert torch.equal(o, ref)
+
+
+def test_grad_clip_norm_kernel_matches_torch_and_is_reproducible():
+    """showo_grad_clip_norm = torch.nn.utils.clip_grad_norm_ on a flat buffer (reference training/train.py:614-615): total norm to fp32
+    accuracy of a double-precision sum, g scaled by min(max / (norm + 1e-6), 1), untouched when the coefficient is 1, same bits twice"""
+    lib = L()
+    torch.manual_seed(1)
+    n = (1 << 22) + 7
+    ws = torch.empty(lib.load().showo_grad_clip_ws_doubles(), dtype=torch.float64, device="cuda")
+    for max_norm, clipped in ((5.0, True), (1e9, False)):
+        g0 = torch.randn(n + 4, device="cuda")[:n] * 0.3
+        runs = []
+        for _ in range(2):
+            g = g0.clone()
+            out2 = torch.empty(2, device="cuda")
+            lib.call("showo_grad_clip_norm", g.data_ptr(), n, max_norm, lib.ptr(ws), lib.ptr(out2), S())
+            sync()
+            runs.append((g, out2.clone()))
+        total = float(g0.double().pow(2).sum().sqrt())
+        assert abs(float(runs[0][1][0]) - total) <= 2e-7 * total
+        coef = min(max_norm / (total + 1e-6), 1.0)
+        assert abs(float(runs[0][1][1]) - coef) <= 1e-6 * coef
+        if clipped:
+            assert torch.allclose(runs[0][0], g0 * runs[0][1][1], rtol=0, atol=0)  # one fp32 multiply per element by the stored coefficient
+        else:
+            assert torch.equal(runs[0][0], g0)
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])

@@ -3,10 +3,10 @@
 Runs the stage-1 training step (bench_train.py's batch: 15 t2i + 4 lm + 10 mmu x 387 tokens, VQ encode included) with the gradient
 exchange forced on in a one-rank RCCL group (26 all-reduces of ~100 MB bf16 per step through torch.distributed; with one rank RCCL's
 kernels move no data over xGMI, so this measures launch / stream / CU-occupancy interaction, not link time) and the compute stream
-masked to 256 - r CUs (Trainer(reserve_cus=r), showo_stream_create_cu_mask) for r in {0, 8, 16, 32}; baseline = no exchange, no mask.
+masked to 256 - r CUs (Trainer(reserve_cus=r), showo_stream_create_cu_mask) for r in {0, 8, 16}; baseline = no exchange, no mask.
 Prints one table: step ms, GPU ms the compute stream spent in finish() (total and the five most exposed buckets).
 
-    python tools/exchange_contention.py > profiles/r4_exchange_contention.txt"""
+    python tools/exchange_contention.py > profiles/r5_exchange_contention.txt"""
 import os
 import random
 import sys
@@ -69,8 +69,10 @@ def main():
     ms, _, _ = run(make(False, 0))
     print(f"no exchange, no mask        : {ms:7.2f} ms/step")
     for rep in range(2):
-        for r in (0, 8, 16, 32):
-            ms, exp, per = run(make(True, r))
+        for r in (0, 8, 16):  # multiples of 8: the same number of CUs from every XCD (round 5)
+            tr_ = make(True, r)
+            ms, exp, per = run(tr_)
+            tr_.close()
             top = sorted(per.items(), key=lambda kv: -kv[1])[:5] if per else []
             print(f"exchange on, reserve {r:3d} CUs: {ms:7.2f} ms/step   exposed {exp:6.2f} ms   most exposed buckets (index: ms) "
                   + " ".join(f"{b}:{v:.2f}" for b, v in top) + f"   [pass {rep}]", flush=True)
