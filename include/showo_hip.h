@@ -610,6 +610,9 @@ int showo_clip_features(showo_clip* c, const float* images, int B, float* featur
  * by the first call with precision 1. */
 int showo_clip_set_precision(showo_clip* c, int precision);
 int showo_clip_get_precision(const showo_clip* c);
+/* 1 when every GEMM weight of the tower has a current low half: they are allocated by the FIRST showo_clip_set_precision(c, 1) (a
+ * precision-0 user never pays the 0.6 GB), so weights loaded before that call must be uploaded again. */
+int showo_clip_precise_ready(const showo_clip* c);
 /* mm_projector: Linear(in,out) -> exact GELU -> Linear(out,out).  Keys "0.weight", "0.bias", "2.weight", "2.bias" (optionally
  * prefixed "mm_projector."); x fp32 [T,in] -> out fp32 [T,out], T <= max_rows. */
 typedef struct showo_projector showo_projector;
@@ -619,6 +622,7 @@ int showo_projector_load(showo_projector* p, const char* key, const float* src, 
 int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream);
 /* 0: bf16 operands (default, also what showo_projector_backward differentiates); 1: split-bf16 GEMMs + fp32 exact GELU (inference) */
 int showo_projector_set_precision(showo_projector* p, int precision);
+int showo_projector_precise_ready(const showo_projector* p);  /* as showo_clip_precise_ready */
 /* backward of the LAST showo_projector_forward (same T rows): dout fp32 [T,out] -> gw0 fp32 [out,in], gb0 [out], gw1 [out,out],
  * gb1 [out], dx fp32 [T,in] (optional).  Autograd of nn.Sequential(Linear, GELU(), Linear) (training/train_w_clip_vit.py trains it). */
 int showo_projector_backward(showo_projector* p, const float* dout, int T, float* dx, float* gw0, float* gb0, float* gw1, float* gb1,

@@ -141,10 +141,12 @@ _PROTOS = {
     "showo_clip_features": [c_p, c_p, c_i, c_p, c_p],
     "showo_clip_set_precision": [c_p, c_i],
     "showo_clip_get_precision": [c_p],
+    "showo_clip_precise_ready": [c_p],
     "showo_projector_create": [c_i, c_i, c_i, c_p],
     "showo_projector_load": [c_p, C.c_char_p, c_p, c_i64, c_p],
     "showo_projector_forward": [c_p, c_p, c_i, c_p, c_p],
     "showo_projector_set_precision": [c_p, c_i],
+    "showo_projector_precise_ready": [c_p],
     "showo_projector_backward": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "showo_image_resize_crop_normalize": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p,
                                           c_p, c_p],

@@ -171,6 +171,8 @@ class CLIPVisionTower(nn.Module):
         self._precision = int(precision)
         if self._clip is not None:
             _lib.call("showo_clip_set_precision", self._clip, self._precision)
+            if self._precision == 1 and not _lib.load().showo_clip_precise_ready(self._clip):
+                self._versions = {}  # the low halves are made by the loader: upload everything again at the next call
         return self
 
     def engine(self, batch=1):

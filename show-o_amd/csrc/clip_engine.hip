@@ -13,11 +13,14 @@
 // needs are run (23 of 24 for select_layer = -2; the post-LayerNorm is never used by the reference).
 #include "common.h"
 #include "../../include/showo_hip.h"
+#include <cstring>
 #include <set>
 #include <string>
 #include <vector>
 
 using namespace showo;
+struct showo_projector;
+extern "C" int showo_projector_precise_ready(const showo_projector* p);
 
 namespace showo {  // csrc/precise.hip: the fp32-class building blocks of the accuracy mode (shared with the Phi engine)
 int precise_ln_split(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* hi, bf16_t* lo, int rows, int H,
@@ -154,6 +157,7 @@ struct showo_clip {
     int precision = 0;
     // accuracy-mode workspace (allocated by the first showo_clip_set_precision(c, 1))
     bf16_t *patches_lo = nullptr, *h_lo = nullptr, *act_lo = nullptr;
+    std::set<std::string> lo_keys;  // GEMM weights uploaded since the low-half images exist (1 + 6 per layer when complete)
     float *p_qkv = nullptr, *p_Q = nullptr, *p_K = nullptr, *p_V = nullptr, *p_a = nullptr;
     float *cls = nullptr, *pos = nullptr, *pre_w = nullptr, *pre_b = nullptr;
     std::vector<ClipLayer> layers;
@@ -193,13 +197,12 @@ extern "C" int showo_clip_create(const showo_clip_config* cf, showo_clip** out) 
     const int64_t H = c->H, F = c->F, B = cf->max_batch, T = B * c->L;
     const int Lp = ((c->L + 63) / 64) * 64;
     int rc = 0;
-    rc |= c->alloc(&c->wpatch, H * c->Kp); rc |= c->alloc(&c->wpatch_lo, H * c->Kp); rc |= c->alloc(&c->cls, H); rc |= c->alloc(&c->pos, c->L * H);
+    rc |= c->alloc(&c->wpatch, H * c->Kp); rc |= c->alloc(&c->cls, H); rc |= c->alloc(&c->pos, c->L * H);
     rc |= c->alloc(&c->pre_w, H); rc |= c->alloc(&c->pre_b, H);
     c->layers.resize(c->nRun);
     for (auto& l : c->layers) {
         rc |= c->alloc(&l.wqkv, 3 * H * H); rc |= c->alloc(&l.bqkv, 3 * H); rc |= c->alloc(&l.wo, H * H); rc |= c->alloc(&l.bo, H);
         rc |= c->alloc(&l.w1, F * H); rc |= c->alloc(&l.b1, F); rc |= c->alloc(&l.w2, H * F); rc |= c->alloc(&l.b2, H);
-        rc |= c->alloc(&l.wqkv_lo, 3 * H * H); rc |= c->alloc(&l.wo_lo, H * H); rc |= c->alloc(&l.w1_lo, F * H); rc |= c->alloc(&l.w2_lo, H * F);
         rc |= c->alloc(&l.ln1_w, H); rc |= c->alloc(&l.ln1_b, H); rc |= c->alloc(&l.ln2_w, H); rc |= c->alloc(&l.ln2_b, H);
     }
     rc |= c->alloc(&c->patches, B * c->P * c->Kp); rc |= c->alloc(&c->pout, B * c->P * H);
@@ -210,7 +213,6 @@ extern "C" int showo_clip_create(const showo_clip_config* cf, showo_clip** out) 
     if (rc) { showo_clip_destroy(c); return rc; }
     hipMemset(c->Vt, 0, (size_t)B * H * Lp * sizeof(bf16_t));
     hipMemset(c->wpatch, 0, (size_t)H * c->Kp * sizeof(bf16_t));
-    hipMemset(c->wpatch_lo, 0, (size_t)H * c->Kp * sizeof(bf16_t));
     c->expected = 5 + c->nRun * 16;
     *out = c;
     return 0;
@@ -225,7 +227,13 @@ int copy_f32(float* dst, const float* src, int64_t n, int64_t expect, hipStream_
     return 0;
 }
 // bf16 image + its low half (w = hi + lo to 2^-17): the hi half is the round-to-nearest cast the bf16 path has always used
+// GEMM weight: bf16 image, plus the low half when accuracy mode has allocated it (dst_lo == nullptr: precision 0 only -- the low halves
+// are made lazily by the first showo_*_set_precision(., 1), which also asks for a re-upload: ADVICE r4)
 int split_w(bf16_t* dst, bf16_t* dst_lo, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+    if (!dst_lo) {
+        if (n != expect) return set_error_msg(2, "clip_load: element count mismatch");
+        return showo_cast_f32_bf16(src, dst, n, s);
+    }
     if (n != expect) return set_error_msg(2, "clip_load: element count mismatch");
     return showo_split_f32_bf16(src, dst, dst_lo, n, s);
 }
@@ -236,7 +244,7 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, bf16_t* __restric
     if (i >= total) return;
     const bf16_t h = f2bf(src[i]);
     dst[(i / K) * Kp + (i % K)] = h;
-    dst_lo[(i / K) * Kp + (i % K)] = f2bf(src[i] - bf2f(h));
+    if (dst_lo) dst_lo[(i / K) * Kp + (i % K)] = f2bf(src[i] - bf2f(h));
 }
 }  // namespace
 
@@ -271,8 +279,8 @@ extern "C" int showo_clip_load(showo_clip* c, const char* key, const float* src,
         ClipLayer& l = c->layers[li];
         std::string t(sub);
         if (t == "self_attn.q_proj.weight") rc = split_w(l.wqkv, l.wqkv_lo, src, n, H * H, s);
-        else if (t == "self_attn.k_proj.weight") rc = split_w(l.wqkv + H * H, l.wqkv_lo + H * H, src, n, H * H, s);
-        else if (t == "self_attn.v_proj.weight") rc = split_w(l.wqkv + 2 * H * H, l.wqkv_lo + 2 * H * H, src, n, H * H, s);
+        else if (t == "self_attn.k_proj.weight") rc = split_w(l.wqkv + H * H, l.wqkv_lo ? l.wqkv_lo + H * H : nullptr, src, n, H * H, s);
+        else if (t == "self_attn.v_proj.weight") rc = split_w(l.wqkv + 2 * H * H, l.wqkv_lo ? l.wqkv_lo + 2 * H * H : nullptr, src, n, H * H, s);
         else if (t == "self_attn.q_proj.bias") rc = copy_f32(l.bqkv, src, n, H, s);
         else if (t == "self_attn.k_proj.bias") rc = copy_f32(l.bqkv + H, src, n, H, s);
         else if (t == "self_attn.v_proj.bias") rc = copy_f32(l.bqkv + 2 * H, src, n, H, s);
@@ -289,6 +297,9 @@ extern "C" int showo_clip_load(showo_clip* c, const char* key, const float* src,
     }
     if (rc == -1) return set_error_msg(3, "clip_load: unknown state-dict key");
     if (rc == 0) c->loaded.insert(k);
+    const auto ends = [&](const char* suf) { const size_t m = strlen(suf); return k.size() >= m && k.compare(k.size() - m, m, suf) == 0; };
+    if (rc == 0 && c->wpatch_lo && (ends("proj.weight") || ends("fc1.weight") || ends("fc2.weight") || ends("patch_embedding.weight")))
+        c->lo_keys.insert(k);  // this GEMM weight now has a current low half
     return rc;
 }
 
@@ -300,6 +311,14 @@ extern "C" int showo_clip_set_precision(showo_clip* c, int precision) {
     if (precision == 1 && !c->p_qkv) {
         const int64_t H = c->H, F = c->F, T = (int64_t)c->cfg.max_batch * c->L;
         int rc = 0;
+        // low halves of the GEMM weights: made here, on first use (0.6 GB at ViT-L/14-336 that a precision-0 user never pays); the
+        // weights loaded so far have no low half yet -> showo_clip_precise_ready() == 0 until they are uploaded again
+        rc |= c->alloc(&c->wpatch_lo, H * c->Kp);
+        for (auto& l : c->layers) {
+            rc |= c->alloc(&l.wqkv_lo, 3 * H * H); rc |= c->alloc(&l.wo_lo, H * H); rc |= c->alloc(&l.w1_lo, F * H); rc |= c->alloc(&l.w2_lo, H * F);
+        }
+        if (!rc) hipMemset(c->wpatch_lo, 0, (size_t)H * c->Kp * sizeof(bf16_t));
+        c->lo_keys.clear();
         rc |= c->alloc(&c->patches_lo, (int64_t)c->cfg.max_batch * c->P * c->Kp); rc |= c->alloc(&c->h_lo, T * H);
         rc |= c->alloc(&c->act_lo, T * F); rc |= c->alloc(&c->p_qkv, T * 3 * H); rc |= c->alloc(&c->p_Q, T * H);
         rc |= c->alloc(&c->p_K, T * H); rc |= c->alloc(&c->p_V, T * H); rc |= c->alloc(&c->p_a, T * H);
@@ -309,6 +328,8 @@ extern "C" int showo_clip_set_precision(showo_clip* c, int precision) {
     return 0;
 }
 extern "C" int showo_clip_get_precision(const showo_clip* c) { return c ? c->precision : -1; }
+// 1 when every GEMM weight has a current low half (patch embedding + q, k, v, out, fc1, fc2 per layer): precision 1 can run
+extern "C" int showo_clip_precise_ready(const showo_clip* c) { return c && c->wpatch_lo && (int)c->lo_keys.size() == 1 + 6 * c->nRun; }
 
 // images fp32 [B,3,S,S] (already normalised by the image processor) -> features fp32 [B, P, hidden] =
 // CLIPVisionModel(images, output_hidden_states=True).hidden_states[run_layers][:, 1:]   (clip_encoder.py:29-37, 40-49)
@@ -323,6 +344,9 @@ extern "C" int showo_clip_features(showo_clip* c, const float* images, int B, fl
     {   // patch embedding: im2col (bf16) + GEMM, then class token / position embeddings, then pre-LayerNorm (fp32 in place)
         const int64_t n = (int64_t)B * P * c->Kp;
         const bool precise = c->precision == 1;
+        if (precise && !showo_clip_precise_ready(c))
+            return set_error_msg(4, "clip (precision 1): the low halves of the weights are missing (weights were loaded before "
+                                    "showo_clip_set_precision(c, 1)): upload the weights again");
         patchify_kernel<<<dim3(launch1d(n)), dim3(256), 0, s>>>(images, c->patches, precise ? c->patches_lo : nullptr, S, c->cfg.patch_size,
                                                                 c->G, c->Kp, n);
         if (precise)
@@ -377,7 +401,8 @@ extern "C" int showo_clip_features(showo_clip* c, const float* images, int B, fl
 struct showo_projector {
     int in_dim, out_dim, max_rows;
     bf16_t *w0 = nullptr, *w1 = nullptr, *xb = nullptr, *act = nullptr;
-    bf16_t *w0_lo = nullptr, *w1_lo = nullptr, *xb_lo = nullptr, *act_lo = nullptr;  // low halves (accuracy mode)
+    bf16_t *w0_lo = nullptr, *w1_lo = nullptr, *xb_lo = nullptr, *act_lo = nullptr;  // low halves (accuracy mode; made by the first set_precision(1))
+    std::set<std::string> lo_keys;
     int precision = 0;
     float *b0 = nullptr, *b1 = nullptr, *f = nullptr;
     std::set<std::string> loaded;
@@ -406,8 +431,6 @@ extern "C" int showo_projector_create(int in_dim, int out_dim, int max_rows, sho
     p->in_dim = in_dim; p->out_dim = out_dim; p->max_rows = max_rows;
     const int64_t I = in_dim, D = out_dim, T = max_rows;
     bool ok = hipMalloc((void**)&p->w0, D * I * 2) == hipSuccess && hipMalloc((void**)&p->w1, D * D * 2) == hipSuccess &&
-              hipMalloc((void**)&p->w0_lo, D * I * 2) == hipSuccess && hipMalloc((void**)&p->w1_lo, D * D * 2) == hipSuccess &&
-              hipMalloc((void**)&p->xb_lo, T * I * 2) == hipSuccess && hipMalloc((void**)&p->act_lo, T * D * 2) == hipSuccess &&
               hipMalloc((void**)&p->b0, D * 4) == hipSuccess && hipMalloc((void**)&p->b1, D * 4) == hipSuccess &&
               hipMalloc((void**)&p->xb, T * I * 2) == hipSuccess && hipMalloc((void**)&p->f, T * D * 4) == hipSuccess &&
               hipMalloc((void**)&p->act, T * D * 2) == hipSuccess;
@@ -430,15 +453,24 @@ extern "C" int showo_projector_load(showo_projector* p, const char* key, const f
     else if (k == "2.bias") rc = copy_f32(p->b1, src, n, D, s);
     else return set_error_msg(3, "projector_load: unknown key");
     if (rc == 0) { p->loaded.insert(k); p->wT_valid = false; }
+    if (rc == 0 && p->w0_lo && (k == "0.weight" || k == "2.weight")) p->lo_keys.insert(k);
     return rc;
 }
 
 extern "C" int showo_projector_set_precision(showo_projector* p, int precision) {
     if (!p) return set_error_msg(1, "projector_set_precision: null handle");
     if (precision != 0 && precision != 1) return set_error_msg(1, "projector_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class)");
+    if (precision == 1 && !p->w0_lo) {  // low halves on first use; the weights must be uploaded again (showo_projector_precise_ready)
+        const int64_t I = p->in_dim, D = p->out_dim, T = p->max_rows;
+        const bool ok = hipMalloc((void**)&p->w0_lo, D * I * 2) == hipSuccess && hipMalloc((void**)&p->w1_lo, D * D * 2) == hipSuccess &&
+                        hipMalloc((void**)&p->xb_lo, T * I * 2) == hipSuccess && hipMalloc((void**)&p->act_lo, T * D * 2) == hipSuccess;
+        if (!ok) return set_error_msg(7, "projector_set_precision: hipMalloc failed");
+        p->lo_keys.clear();
+    }
     p->precision = precision;
     return 0;
 }
+extern "C" int showo_projector_precise_ready(const showo_projector* p) { return p && p->w0_lo && p->lo_keys.size() == 2; }
 
 // x fp32 [T, in] -> out fp32 [T, out] = W1 gelu(W0 x + b0) + b1
 extern "C" int showo_projector_forward(showo_projector* p, const float* x, int T, float* out, void* stream) {
@@ -447,6 +479,9 @@ extern "C" int showo_projector_forward(showo_projector* p, const float* x, int T
     if (T <= 0 || T > p->max_rows) return set_error_msg(5, "projector_forward: too many rows for the workspace");
     if (p->loaded.size() != 4) return set_error_msg(4, "projector_forward: weights missing");
     const int I = p->in_dim, D = p->out_dim;
+    if (p->precision == 1 && !showo_projector_precise_ready(p))
+        return set_error_msg(4, "projector (precision 1): the low halves of the weights are missing (weights were loaded before "
+                                "showo_projector_set_precision(p, 1)): upload the weights again");
     if (p->precision == 1) {  // accuracy mode: split-bf16 GEMMs, exact GELU in fp32 -> (hi, lo); inference only (the backward keeps bf16)
         TRY(showo_split_f32_bf16(x, p->xb, p->xb_lo, (int64_t)T * I, s));
         TRY(showo_gemm_bf16x3(p->xb, p->xb_lo, I, p->w0, p->w0_lo, I, p->b0, 0, p->f, D, nullptr, 0, T, D, I, s));

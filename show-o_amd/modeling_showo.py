@@ -211,6 +211,8 @@ class _MMProjector(nn.Sequential):
         self._precision = int(precision)
         if getattr(self, "_proj", None) is not None:
             _lib.call("showo_projector_set_precision", self._proj, self._precision)
+            if self._precision == 1 and not _lib.load().showo_projector_precise_ready(self._proj):
+                self._versions = {}  # the low halves are made by the loader (allocated on first use): upload the weights again
         return self
 
     def mark_weights_dirty(self):
