@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshowo_hip.so")
+LIB_PATH = os.environ.get("SHOWO_LIB_PATH") or os.path.join(_HERE, "libshowo_hip.so")  # SHOWO_LIB_PATH: a second build for same-box A/B runs
 _lib = None
 
 c_p = C.c_void_p

@@ -3,24 +3,25 @@
 # A failed compile stops the build: the stale object is removed before compiling and every job's exit status is checked.
 set -e
 cd "$(dirname "$0")"
-OUT=../libshowo_hip.so
+OUT=${SHOWO_BUILD_OUT:-../libshowo_hip.so}   # SHOWO_BUILD_OUT / SHOWO_BUILD_DIR / SHOWO_BUILD_FLAGS: a second library for same-box A/B runs
+BD=${SHOWO_BUILD_DIR:-_build}
 # -Wno-inline-asm: the LDS-DMA helpers (common.h glds16_untracked, gemm_tn.hip glds16_sa) list "m0" as clobbered so that the compiler
 # never assumes M0 survives them; the backend notes for every inlined copy that m0 is a reserved register (a remark, not a defect)
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-result -Wno-unused-value -Wno-inline-asm $SHOWO_BUILD_FLAGS"
 OBJS=""
 PIDS=""
-mkdir -p _build
+mkdir -p $BD
 for f in basic gemm gemm2p gemm3w gemm_tn attention attention_bwd train_kernels decode decode_batch prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops precise; do
-  if [ ! -f _build/$f.o ] || [ $f.hip -nt _build/$f.o ] || [ common.h -nt _build/$f.o ] || [ engine.h -nt _build/$f.o ] || [ gemm_common.h -nt _build/$f.o ] || [ decode_common.h -nt _build/$f.o ] || [ prof.h -nt _build/$f.o ] || [ ../../include/showo_hip.h -nt _build/$f.o ]; then
-    rm -f _build/$f.o
-    hipcc $FLAGS -c $f.hip -o _build/$f.o &
+  if [ ! -f $BD/$f.o ] || [ $f.hip -nt $BD/$f.o ] || [ common.h -nt $BD/$f.o ] || [ engine.h -nt $BD/$f.o ] || [ gemm_common.h -nt $BD/$f.o ] || [ decode_common.h -nt $BD/$f.o ] || [ prof.h -nt $BD/$f.o ] || [ ../../include/showo_hip.h -nt $BD/$f.o ]; then
+    rm -f $BD/$f.o
+    hipcc $FLAGS -c $f.hip -o $BD/$f.o &
     PIDS="$PIDS $!"
   fi
-  OBJS="$OBJS _build/$f.o"
+  OBJS="$OBJS $BD/$f.o"
 done
-if [ ! -f _build/errors.o ] || [ errors.cpp -nt _build/errors.o ]; then
-  rm -f _build/errors.o
-  hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -c errors.cpp -o _build/errors.o &
+if [ ! -f $BD/errors.o ] || [ errors.cpp -nt $BD/errors.o ]; then
+  rm -f $BD/errors.o
+  hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -c errors.cpp -o $BD/errors.o &
   PIDS="$PIDS $!"
 fi
 FAIL=0
@@ -32,5 +33,5 @@ if [ $FAIL -ne 0 ]; then
   exit 1
 fi
 rm -f $OUT
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS _build/errors.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $BD/errors.o -o $OUT
 echo "built $(realpath $OUT)"

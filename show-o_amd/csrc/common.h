@@ -29,7 +29,11 @@ __host__ __device__ inline float bf2f(bf16_t v) {
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __host__ __device__ inline bf16_t f2bf(float f) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SHOWO_PACK_ASM)  // A/B build of the round-4 form (scripts/gpu_r5_l.sh); never the shipped library
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(f));
+    return (bf16_t)(r & 0xffffu);
+#elif defined(__HIP_DEVICE_COMPILE__)
     const __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 #else
@@ -43,8 +47,14 @@ __host__ __device__ inline bf16_t f2bf(float f) {
 }
 
 __device__ inline uint32_t pack_bf2(float lo, float hi) {
+#if defined(SHOWO_PACK_ASM)
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#else
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+#endif
 }
 
 __device__ inline float wave_sum(float v) {
