@@ -62,6 +62,17 @@ __device__ inline float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// wave_sum with its first two steps (partners 32 and 16 lanes away) on gfx950's row-swap instructions -- VALU only, no trip through the
+// LDS crossbar -- and the same order of additions: identical bits (the decode GEMVs reduce once per weight row per wave)
+__device__ inline float wave_sum_swap(float v) {
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __device__ inline float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -40,7 +40,7 @@ struct LnGemvArgs {
 template <int R>
 __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 2048: one 4-load group covers a weight row
     extern __shared__ bf16_t sh[];  // normalised row, bf16 like showo_layernorm_f32_bf16's output
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: weight-row bases in SGPRs
     const int H = g.H, Ntot = g.N0 + g.N1;
     const int stride = gridDim.x * 4;
     int n = blockIdx.x * 4 + wave;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
     }
     __syncthreads();
     auto finish = [&](int c, float acc) {
-        acc = wave_sum(acc);
+        acc = wave_sum_swap(acc);
         if (lane == 0) {
             if (c < g.N0) {
                 const float v = acc + g.b0[c];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
 template <int C, int MODE>
 __global__ __launch_bounds__(512) void out_gemv2_kernel(OutGemvArgs g) {
     extern __shared__ bf16_t sa[];  // [K0] attention row, [K1] gelu(fc1) row: read once per block instead of once per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: weight-row bases in SGPRs
     const int stride = gridDim.x * 8;
     const int c0 = (g.K0 + 2047) / 2048;
     int n = blockIdx.x * 8 + wave;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(512) void out_gemv2_kernel(OutGemvArgs g) {
             else acc1 = fma4(buf[t], a1, (t - c0) * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) issue(nn, t, buf[t]);
         }
-        acc0 = wave_sum(acc0);
-        acc1 = wave_sum(acc1);
+        acc0 = wave_sum_swap(acc0);
+        acc1 = wave_sum_swap(acc1);
         if (lane == 0) {
             if (MODE == 1) {
                 g.y2[n] = acc1 + g.b1[n];

@@ -65,7 +65,7 @@ static __device__ __forceinline__ void fc2_columns_role(const OutGemvArgs& g, in
             acc1 = fma4(buf[t], sa, t * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) load4(g.W1 + (int64_t)nn * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
         }
-        acc1 = wave_sum(acc1);
+        acc1 = wave_sum_swap(acc1);
         if (lane == 0) g.y2[n] = acc1 + g.b1[n];
         n = nn;
     }
