@@ -574,173 +574,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void attn_fwd_lds_split_kernel(AttnArg
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Resident form (round 5; short key ranges: Lk <= 448, at most 13 query tiles -- the 18-step t2i loop at 256 x 256 (Lq = 258, Lk = 387),
-// the 387-token training / prefill rows): ONE block per (batch, head), one wave per 32-row query tile, and the WHOLE K / V^T range of
-// the head staged into LDS up front (7 tiles x 16 KiB) by all waves with a single wait + barrier; the waves then walk their visible
-// sub-tiles without any further block synchronisation.
-// Why: the double-buffered kernel above is latency-bound at these lengths, not MFMA-bound -- a wave's MFMA work for 7 key tiles is
-// ~0.9 us, but every tile costs one global-load latency (the prefetch is one tile ahead and each iteration ends with vmcnt(0) + barrier),
-// and at Lq = 258 the 9th query tile (2 rows) sits in a third, nearly empty block per head that streams every tile again (PMC r4: MFMA
-// busy 10.4 %).  Here the loads of all tiles are in flight at once and every K / V^T byte is fetched once per head.
-// Per-wave arithmetic, sub-tile order and the deferred rescale are those of attn_lds_body: the same bits.
-// ------------------------------------------------------------------------------------------------
-template <bool DENSE, int NW>
-__device__ __forceinline__ void attn_res_body(const AttnArgs& a, bf16_t* sm) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh_ = blockIdx.x;  // one block per (batch, head)
-    const int b = bh_ / a.nH, head = bh_ - b * a.nH;
-    const int qblk = wave;
-    const bool wactive = qblk * 32 < a.Lq;
-    const int qi = lane & 31, hh = lane >> 5;
-    const int qrow_raw = qblk * 32 + qi;
-    const int qrow = qrow_raw < a.Lq ? qrow_raw : a.Lq - 1;
-    const int64_t bh = (int64_t)b * a.nH + head;
-    // ---- every K / V^T tile of the head, requested before anything else (piece = 8 rows x 128 B, lane-linear LDS image, source-side
-    // swizzle; K rows in the order pi of attn_lds_body)
-    const int nkt = (a.Lk + 63) >> 6;
-    {
-        const int prow = lane >> 3;
-        const bf16_t* Kg = a.K + bh * a.Lcap * 64;
-        const bf16_t* Vg = a.Vt + bh * 64 * a.Lp;
-        for (int pc = wave; pc < nkt * 16; pc += NW) {
-            const int t = pc >> 4, isv = (pc >> 3) & 1, p = pc & 7;
-            const int r = 8 * p + prow;
-            const int kch = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
-            if (!isv) {
-                const int blk = (r >> 2) & 3;
-                int key = 64 * t + (r & ~15) + 4 * (((blk & 1) << 1) | (blk >> 1)) + (r & 3);
-                key = key < a.Lk ? key : a.Lk - 1;  // clamped rows are masked out below
-                glds16_untracked(Kg + (int64_t)key * 64 + kch, lds_addr_of(sm + t * 2 * AT_TILE + p * 512));
-            } else {
-                glds16_untracked(Vg + (int64_t)r * a.Lp + kch + 64 * t, lds_addr_of(sm + t * 2 * AT_TILE + AT_TILE + p * 512));
-            }
-        }
-    }
-    bf16x8 qf[4];
-    {
-        const bf16_t* Qp = a.Q + (bh * a.Lq + qrow) * 64 + 8 * hh;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const bf16x8*>(Qp + 16 * m);
-    }
-    constexpr bool dense = DENSE;
-    int lo1, hi1, lo2, hi2;
-    if (dense) {
-        lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0;
-    } else if (a.iv) {
-        int4 v = *reinterpret_cast<const int4*>(a.iv + ((int64_t)b * a.Lq + qrow) * 4);
-        lo1 = v.x; hi1 = v.y; lo2 = v.z; hi2 = v.w;
-    } else {
-        lo1 = 0; hi1 = qrow + 1 + (a.Lk - a.Lq); lo2 = 0; hi2 = 0;
-    }
-    hi1 = min(hi1, a.Lk);
-    hi2 = min(hi2, a.Lk);
-    if (!wactive) { lo1 = hi1 = lo2 = hi2 = 0; }
-    const int wmin = wave_min_i(min(lo1 < hi1 ? lo1 : 0x7fffffff, lo2 < hi2 ? lo2 : 0x7fffffff));
-    const int wmax = wave_max_i(max(lo1 < hi1 ? hi1 : 0, lo2 < hi2 ? hi2 : 0));
-    const float* drow = dense ? a.dense + ((int64_t)b * a.Lq + qrow) * a.Lk : nullptr;
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(lo1), "+v"(hi1), "+v"(lo2), "+v"(hi2)::"memory");
-    __syncthreads();  // the only block-wide synchronisation: every tile is in LDS
-
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    const int fsw = (qi >> 1) & 7;
-    const int kt0 = wmin >= 0x7fffffff ? 0 : (wmin & ~63);
-    for (int kt = kt0; kt < wmax; kt += 64) {
-        const bf16_t* sK = sm + (kt >> 6) * 2 * AT_TILE;
-        const bf16_t* sV = sK + AT_TILE;
-#pragma unroll 1
-        for (int sub = 0; sub < 2; ++sub) {
-            const int ks = kt + 32 * sub;
-            if (ks >= wmax || ks + 32 <= wmin) continue;
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * sub + qi) * 64 + (((2 * m + hh) ^ fsw) << 3));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m], s, 0, 0, 0);
-            }
-            const bool inner = !dense && __all(((lo1 <= ks) & (ks + 32 <= hi1)) | ((lo2 <= ks) & (ks + 32 <= hi2)));
-            float sv[16];
-            float mx = -INFINITY;
-            if (inner) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sv[r] = s[r]; mx = fmaxf(mx, sv[r]); }
-            } else {
-                const unsigned len1 = (unsigned)max(hi1 - lo1, 0), len2 = (unsigned)max(hi2 - lo2, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = ks + 16 * (r >> 3) + 8 * hh + (r & 7);
-                    const bool vis = ((unsigned)(key - lo1) < len1) | ((unsigned)(key - lo2) < len2);
-                    float x = s[r];
-                    if (dense) x += (key < a.Lk) ? drow[key] : 0.f;
-                    sv[r] = vis ? x : -INFINITY;
-                    mx = fmaxf(mx, sv[r]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (__any(mx > m_run + AT_DEFER)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - ((m_new == -INFINITY) ? 0.f : m_new)) * LOG2E);
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            }
-            const float mb = ((m_run == -INFINITY) ? 0.f : m_run) * LOG2E;
-            float p[16];
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -mb));
-                ps += p[r];
-            }
-            l_run += ps;
-            uint4 u0, u1;
-            u0.x = cvt_pk_bf16(p[0], p[1]); u0.y = cvt_pk_bf16(p[2], p[3]); u0.z = cvt_pk_bf16(p[4], p[5]); u0.w = cvt_pk_bf16(p[6], p[7]);
-            u1.x = cvt_pk_bf16(p[8], p[9]); u1.y = cvt_pk_bf16(p[10], p[11]); u1.z = cvt_pk_bf16(p[12], p[13]); u1.w = cvt_pk_bf16(p[14], p[15]);
-            const bf16x8 pb0 = __builtin_bit_cast(bf16x8, u0), pb1 = __builtin_bit_cast(bf16x8, u1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = ((4 * sub + 2 * kk + hh) ^ fsw) << 3;
-                bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(sV + qi * 64 + c);
-                bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(sV + (32 + qi) * 64 + c);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pb1 : pb0, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pb1 : pb0, o1, 0, 0, 0);
-            }
-        }
-    }
-    if (!wactive) return;
-    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    float inv = 1.0f / l_tot;
-    if (a.lse && hh == 0 && qrow_raw < a.Lq) a.lse[bh * a.Lq + qrow_raw] = m_run + __logf(l_tot);
-    if (qrow_raw < a.Lq) {
-        bf16_t* op = a.O + ((int64_t)b * a.Lq + qrow_raw) * a.ldo + head * 64 + 4 * hh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 w0, w1;
-            w0.x = cvt_pk_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv);
-            w0.y = cvt_pk_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            w1.x = cvt_pk_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv);
-            w1.y = cvt_pk_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(op + 8 * g) = w0;
-            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
-        }
-    }
-}
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_res_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char at_res[];
-    bf16_t* sm = reinterpret_cast<bf16_t*>(at_res);
-    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);  // block-uniform
-    if (dense) attn_res_body<true, NW>(a, sm);
-    else attn_res_body<false, NW>(a, sm);
-}
-
+// (Round 5 measured a RESIDENT form -- the whole key range of a head staged into LDS up front, one 576-thread block per (batch, head),
+// no barrier in the key loop; bit-identical to attn_lds_body -- and it was slower: 312 vs 346 TF/s at the t2i shape, 37.8 vs 38.4
+// images/s on one box (profiles/r5m_attention_resident_ab.txt): 112 KiB of LDS leave one block per CU and the up-front stage is bound by
+// what one CU can pull.  The kernel is in the git history, not in the library.)
 template <int MINW, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sm[4 * AT_TILE];  // [buf][K | Vt]
@@ -995,7 +832,7 @@ extern "C" int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag
 static int g_attn_forced = -1;
 
 extern "C" int showo_attn_set_impl(int impl) {
-    g_attn_forced = (impl >= 1 && impl <= 4) ? impl : 0;  // 1 gather, 2 LDS double-buffered, 3 the same with 3 blocks per CU, 4 resident (short key ranges)
+    g_attn_forced = (impl >= 1 && impl <= 3) ? impl : 0;  // 1 gather, 2 LDS double-buffered, 3 the same with 3 blocks per CU
     return 0;
 }
 
@@ -1034,22 +871,6 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
     if (xcd < 0) { const char* e = getenv("SHOWO_ATTN_XCD"); xcd = e ? (atoi(e) != 0) : 1; }
     if (wpb9 < 0) { const char* e = getenv("SHOWO_ATTN_WPB9"); wpb9 = e ? (atoi(e) != 0) : 0; }
     auto grid = [&](int nqb) { if (xcd) { a.nqb = nqb; return dim3((unsigned)nqb * nH * B); } a.nqb = 0; return dim3(nqb, nH, B); };
-    // resident form: the whole key range of a head in LDS, one block per (batch, head) (SHOWO_ATTN_RES=0 / showo_attn_set_impl(2): off)
-    static int res_on = -1;
-    if (res_on < 0) { const char* e = getenv("SHOWO_ATTN_RES"); res_on = e ? (atoi(e) != 0) : 1; }
-    if (tiled && (forced == 4 || (forced == 0 && res_on)) && Lk <= 448 && qblocks >= 3 && qblocks <= 13) {
-        const size_t smem = (size_t)((Lk + 63) / 64) * 2 * AT_TILE * sizeof(bf16_t);
-        static bool attr9 = false, attr13 = false;
-        if (qblocks <= 9) {
-            if (!attr9) { SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_res_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2 * AT_TILE * 2)); attr9 = true; }
-            attn_fwd_res_kernel<9><<<dim3((unsigned)(nH * B)), dim3(576), smem, (hipStream_t)stream>>>(a);
-        } else {
-            if (!attr13) { SHOWO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_res_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 2 * AT_TILE * 2)); attr13 = true; }
-            attn_fwd_res_kernel<13><<<dim3((unsigned)(nH * B)), dim3(832), smem, (hipStream_t)stream>>>(a);
-        }
-        SHOWO_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
     if (tiled && forced == 3) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<3><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
     else if (tiled && wpb9 && qblocks > 4 && qblocks <= 9) { const dim3 g = grid(1); attn_fwd_lds_kernel<2, 9><<<g, dim3(576), 0, (hipStream_t)stream>>>(a); }
     else if (tiled && (qblocks + 4) / 5 < (qblocks + 3) / 4 && g_attn_wpb5) {  // five query tiles per block save a block per (b, head)
