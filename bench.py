@@ -535,10 +535,10 @@ def main():
         # utilisation on the transformer blocks"): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); same staleness guard
         mfma_pmc = None
         try:
-            mj = json.load(open(os.path.join(ROOT, "profiles", "pmc", "r4z_mfma_util.json")))
+            mj = json.load(open(os.path.join(ROOT, "profiles", "pmc", "bench_mfma_util.json")))
             if mj.get("kernel_src_sha1") == gemm_src_sha1():
                 top = sorted(((k, v) for k, v in mj["kernels"].items() if k.startswith("gemm")), key=lambda kv: -kv[1]["dispatches"] * kv[1]["avg_us"])[:2]
-                mfma_pmc = {"source": "profiles/pmc/r4z_mfma_util.json (" + mj["formula"] + ")",
+                mfma_pmc = {"source": f"profiles/pmc/bench_mfma_util.json ({mj.get('tag')}: " + mj["formula"] + ")",
                             "kernels": {k: {"mfma_busy_frac": round(v["mfma_busy_frac"], 4), "avg_us_profiled": round(v["avg_us"], 1)} for k, v in top}}
         except (OSError, KeyError, TypeError, ValueError):
             pass
