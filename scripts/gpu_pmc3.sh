@@ -9,7 +9,7 @@ i=0
 for G in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 400 rocprofv3 --pmc $G --output-format csv -d /tmp/pmc_$i -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-leg --no-events > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $G --output-format csv -d /tmp/pmc_$i -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-leg --no-accuracy-leg --no-config-legs --roofline-steps 0 --no-events > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1
   echo "pmc pass $i ($G) rc=$?"
 done
 cd $R

@@ -786,13 +786,12 @@ __global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPre
 
 // Batched form of the co-scheduled launch (decode_batch.hip): blocks [0, nH * B) = the (sequence, head) attention blocks, the rest
 // stream the fc2 weights ONCE for all NB sequences (fc2_columns_roleB: activations as fp32 in LDS).
-template <int NB, bool ROWS2>
+template <int NB>
 __global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPrep f, showo::OutGemvBArgs g) {
     const int nab = a.nH * a.B;
     if ((int)blockIdx.x >= nab) {
         extern __shared__ float sp[];
-        if constexpr (ROWS2) showo::fc2_columns_roleB2<4, NB>(g, blockIdx.x - nab, gridDim.x - nab, 16, sp);
-        else showo::fc2_columns_roleB1<4, NB>(g, blockIdx.x - nab, gridDim.x - nab, 16, sp);
+        showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, gridDim.x - nab, 16, sp);
         return;
     }
     attn_decode_body<true>(a, f, blockIdx.x % a.nH, blockIdx.x / a.nH);
@@ -961,22 +960,16 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
     const size_t smem = smem_a > smem_f ? smem_a : smem_f;
     const dim3 grid(nH * B + co_blocks);
     static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};
-    // SHOWO_DECODE_BATCH_ROWS2=1: the fc2 role works on two weight rows per activation read (half the LDS traffic, but 44 spilled
-    // registers under the 128-VGPR budget of a 1024-thread block: measured 32.2 us per launch against 21 for the one-row form, r5i)
-    static int rows2 = -1;
-    if (rows2 < 0) { const char* e = getenv("SHOWO_DECODE_BATCH_ROWS2"); rows2 = e ? (atoi(e) != 0) : 0; }
     auto launch = [&](auto kfn) -> int {
-        if (!attr[B + 5 * rows2]) {
+        if (!attr[B]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(attn_decode_coB)", __FILE__, __LINE__);
-            attr[B + 5 * rows2] = true;
+            attr[B] = true;
         }
         kfn<<<grid, dim3(1024), smem, s>>>(a, f, fc2);
         return 0;
     };
-    int rc;
-    if (rows2) rc = B == 2 ? launch(attn_decode_coB_kernel<2, true>) : B == 3 ? launch(attn_decode_coB_kernel<3, true>) : launch(attn_decode_coB_kernel<4, true>);
-    else rc = B == 2 ? launch(attn_decode_coB_kernel<2, false>) : B == 3 ? launch(attn_decode_coB_kernel<3, false>) : launch(attn_decode_coB_kernel<4, false>);
+    const int rc = B == 2 ? launch(attn_decode_coB_kernel<2>) : B == 3 ? launch(attn_decode_coB_kernel<3>) : launch(attn_decode_coB_kernel<4>);
     if (rc) return rc;
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;

@@ -59,9 +59,10 @@ struct LnGemvBArgs {
 // lane * 8 + u * 512 + j are the same for every weight row), so a weight row costs 32 conversions + 32 NB FMAs per lane and no LDS
 // read -- with the activations re-read from LDS as bf16 per row (the batch-1 form, !REG) four sequences made the step VALU-bound
 // (1.61 ms per 4-token step against 0.96 ms per batch-1 token).  Fewer, longer-lived waves (2 blocks per CU) amortise the register
-// fill.  Same products and the same accumulation order per sequence either way.
-template <int NB, bool REG, int R = 2>
-__global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048; R = weight rows in flight per wave
+// fill (grid caps 256 / 1024 and 4 rows in flight measured slower: profiles/r5_decode_batch_sweep.txt).  Same products and the same accumulation order per sequence either way.
+template <int NB, bool REG>
+__global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048; 2 weight rows in flight per wave (4: measured slower)
+    constexpr int R = 2;
     extern __shared__ bf16_t sh[];  // [NB][H] normalised rows (bf16, like showo_layernorm_f32_bf16's output)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
     const int H = g.H, Ntot = g.N0 + g.N1;
@@ -348,19 +349,13 @@ __global__ __launch_bounds__(1024) void greedy_seam_rows_kernel(const float* __r
     for (int i = tid; i < H; i += 1024) xr[i] = src[i];
 }
 
-int g_batch_reg = -1;  // SHOWO_DECODE_BATCH_REG=0: activations re-read from LDS per weight row (A/B; the form NB > 4 uses)
 template <int NB>
 int launch_ln_gemvB(const LnGemvBArgs& g, hipStream_t s) {
     const int Ntot = g.N0 + g.N1;
-    if (g_batch_reg < 0) { const char* e = getenv("SHOWO_DECODE_BATCH_REG"); g_batch_reg = e ? (atoi(e) != 0) : 1; }
-    static int rows_fl = 0, cap = 0;  // A/B knobs: SHOWO_DECODE_BATCH_R = 2 | 4 rows in flight per wave, SHOWO_DECODE_BATCH_LNBLOCKS = grid cap
-    if (!rows_fl) { const char* e = getenv("SHOWO_DECODE_BATCH_R"); rows_fl = (e && atoi(e) == 4) ? 4 : 2; }
-    if (!cap) { const char* e = getenv("SHOWO_DECODE_BATCH_LNBLOCKS"); cap = (e && atoi(e) > 0) ? atoi(e) : 512; }
-    if (NB <= 4 && g_batch_reg) {
-        int blocks = (Ntot + 4 * rows_fl - 1) / (4 * rows_fl);  // >= R rows per wave; at most 2 blocks per CU: every wave is resident from the start
-        if (blocks > cap) blocks = cap;
-        if (rows_fl == 4) ln_gemvB_kernel<NB, (NB <= 4), 4><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
-        else ln_gemvB_kernel<NB, (NB <= 4), 2><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+    if (NB <= 4) {  // register-resident activations: >= 2 rows per wave, at most 2 blocks per CU -- every wave is resident from the start
+        int blocks = (Ntot + 7) / 8;
+        if (blocks > 512) blocks = 512;
+        ln_gemvB_kernel<NB, (NB <= 4)><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
     } else {
         int blocks = (Ntot + 11) / 12;
         if (blocks > 1280) blocks = 1280;

@@ -109,10 +109,6 @@ static __device__ __forceinline__ float wave_sum_groups(const float (&acc)[NB]) 
     return r;
 }
 
-// float4 slot q of the fp32 activation image is stored at q ^ ((q >> 4) & 1): the 16 lanes of a quarter-wave read slots 32 B apart
-// (lane l: 2 l and 2 l + 1), which would otherwise use every second bank group twice
-static __device__ __forceinline__ int lds32_slot(int q) { return q ^ ((q >> 4) & 1); }
-
 // acc[b] += sum over the 4 loaded 8-element groups of w * act[b], in fma4's order (u ascending, j ascending) with the weight
 // converted ONCE for all NB sequences.  act: this lane's 32 activation values per sequence (registers).
 template <int NB>
@@ -130,7 +126,7 @@ static __device__ __forceinline__ void fma4_regs(const uint4 (&wv)[4], const flo
     }
 }
 // the same with the activations in LDS as fp32 (sa: row b at sa + b * ld): one conversion per weight element, none per activation
-template <int NB, bool SWZ = false>
+template <int NB>
 static __device__ __forceinline__ void fma4_lds32(const uint4 (&wv)[4], const float* sa, int ld, int k0, int K, float (&acc)[NB]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -142,8 +138,8 @@ static __device__ __forceinline__ void fma4_lds32(const uint4 (&wv)[4], const fl
         for (int j = 0; j < 8; ++j) w[j] = bf2f(ew[j]);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {  // one sequence at a time: 8 activation registers live, the chain of acc[b] stays j-ascending
-            const float4 lo = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + (SWZ ? 4 * lds32_slot(k >> 2) : k));
-            const float4 hi = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + (SWZ ? 4 * lds32_slot((k >> 2) + 1) : k + 4));
+            const float4 lo = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + k);
+            const float4 hi = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + k + 4);
             acc[b] = fmaf(lo.x, w[0], acc[b]); acc[b] = fmaf(lo.y, w[1], acc[b]); acc[b] = fmaf(lo.z, w[2], acc[b]); acc[b] = fmaf(lo.w, w[3], acc[b]);
             acc[b] = fmaf(hi.x, w[4], acc[b]); acc[b] = fmaf(hi.y, w[5], acc[b]); acc[b] = fmaf(hi.z, w[6], acc[b]); acc[b] = fmaf(hi.w, w[7], acc[b]);
         }
@@ -152,27 +148,24 @@ static __device__ __forceinline__ void fma4_lds32(const uint4 (&wv)[4], const fl
 
 // fc2 role of the co-scheduled BATCHED decode launch (attention.hip, attn_decode_coB_kernel): y2[b][n] = W1[n, :] a1[b] + b1[n] for
 // the columns of role-block rb of nrb, nw waves per block.  fc2_columns_role's lane split and accumulation order per sequence (chunks
-// t ascending into ONE accumulator chain, then the wave reduction): the bits of the batch-1 launch.
-// The role is LDS-bound when every weight row re-reads its activations (NB x K1 fp32 per 16 KB of weights: measured 23.7 us per launch
-// against 14.3 for the batch-1 launch), so a wave works on TWO weight rows at a time -- each activation read serves both -- with the
-// weights double-buffered per 2048-element chunk (2 rows x 2 chunks x 64 B per lane in flight), and the fp32 image is swizzled
-// (float4 slot q stored at q ^ ((q >> 4) & 1)) so that the 16 lanes of a quarter-wave, 32 B apart, hit 16 different bank groups.
-// sa: NB * K1 floats of LDS.
-// swizzled fp32 image of the NB activation rows (all threads of the block; the caller synchronises)
-template <int NB, bool SWZ>
+// t ascending into ONE accumulator chain, then the wave reduction): the bits of the batch-1 launch.  The NB activation rows live in
+// LDS as fp32 (one conversion per weight element, none per activation).  sa: NB * K1 floats of LDS.
+// Measured alternatives (profiles/r5_decode_batch_sweep.txt): two weight rows per activation read (half the LDS traffic) needs more
+// than the 128 VGPRs a 1024-thread block has -- 44 spills, 32 us per launch instead of 21; a bank-swizzled image costs 17 spills.
+// fp32 image of the NB activation rows (all threads of the block; the caller synchronises)
+template <int NB>
 static __device__ __forceinline__ void fill_lds32(const OutGemvBArgs& g, int nw, float* sa) {
     for (int b = 0; b < NB; ++b)
         for (int i = threadIdx.x * 8; i < g.K1; i += nw * 64 * 8) {
             const uint4 av = *reinterpret_cast<const uint4*>(g.a1 + (int64_t)b * g.lda1 + i);
             const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
             const int q = i >> 2;
-            *reinterpret_cast<float4*>(sa + (size_t)b * g.K1 + 4 * (SWZ ? lds32_slot(q) : q)) = make_float4(bf2f(ea[0]), bf2f(ea[1]), bf2f(ea[2]), bf2f(ea[3]));
-            *reinterpret_cast<float4*>(sa + (size_t)b * g.K1 + 4 * (SWZ ? lds32_slot(q + 1) : q + 1)) = make_float4(bf2f(ea[4]), bf2f(ea[5]), bf2f(ea[6]), bf2f(ea[7]));
+            *reinterpret_cast<float4*>(sa + (size_t)b * g.K1 + 4 * q) = make_float4(bf2f(ea[0]), bf2f(ea[1]), bf2f(ea[2]), bf2f(ea[3]));
+            *reinterpret_cast<float4*>(sa + (size_t)b * g.K1 + 4 * (q + 1)) = make_float4(bf2f(ea[4]), bf2f(ea[5]), bf2f(ea[6]), bf2f(ea[7]));
         }
 }
-// one weight row at a time, all C chunks in flight (fc2_columns_role's structure)
 template <int C, int NB>
-static __device__ __forceinline__ void fc2_columns_roleB1(const OutGemvBArgs& g, int rb, int nrb, int nw, float* sa) {
+static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, int rb, int nrb, int nw, float* sa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int stride = nrb * nw;
     int n = wave * nrb + rb;
@@ -181,7 +174,7 @@ static __device__ __forceinline__ void fc2_columns_roleB1(const OutGemvBArgs& g,
 #pragma unroll
         for (int t = 0; t < C; ++t) load4(g.W1 + (int64_t)n * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
     }
-    fill_lds32<NB, false>(g, nw, sa);  // plain image: the swizzled address arithmetic costs the 6 registers this role does not have
+    fill_lds32<NB>(g, nw, sa);
     __syncthreads();
     while (n < g.N) {
         const int nn = n + stride;
@@ -198,64 +191,4 @@ static __device__ __forceinline__ void fc2_columns_roleB1(const OutGemvBArgs& g,
         n = nn;
     }
 }
-template <int C, int NB>
-static __device__ __forceinline__ void fc2_columns_roleB2(const OutGemvBArgs& g, int rb, int nrb, int nw, float* sa) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int stride = nrb * nw;
-    int n = wave * nrb + rb;  // this wave's rows: n, n + stride, ... taken two at a time
-    uint4 w0[4], w1[4];       // the current 2048-element chunk of the two rows; slot u is refilled as soon as it has been converted
-    const int K1 = g.K1;
-    auto ld1 = [&](int row, int t, int u) -> uint4 {
-        const int k = t * 2048 + lane * 8 + u * 512;
-        return (row < g.N && k < K1) ? ldg_nt16(g.W1 + (int64_t)row * K1 + k) : make_uint4(0, 0, 0, 0);
-    };
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { w0[u] = ld1(n, 0, u); w1[u] = ld1(n + stride, 0, u); }
-    fill_lds32<NB, true>(g, nw, sa);
-    __syncthreads();
-    while (n < g.N) {
-        const int n1 = n + stride, nn = n + 2 * stride;
-        float acc0[NB], acc1[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < C; ++t) {
-            const int tn = t + 1 < C ? t + 1 : 0;          // chunk that takes over each register slot: the next one of this row pair,
-            const int r0 = t + 1 < C ? n : nn;             // or chunk 0 of the wave's next pair
-            const int r1 = t + 1 < C ? n1 : nn + stride;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = t * 2048 + lane * 8 + u * 512;
-                const bf16_t* e0 = reinterpret_cast<const bf16_t*>(&w0[u]);
-                const bf16_t* e1 = reinterpret_cast<const bf16_t*>(&w1[u]);
-                float wa[8], wb[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { wa[j] = bf2f(e0[j]); wb[j] = bf2f(e1[j]); }
-                w0[u] = ld1(r0, tn, u);  // one whole chunk of lead
-                w1[u] = ld1(r1, tn, u);
-                if (k < K1) {
-                    const int q = k >> 2;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const float4 lo = *reinterpret_cast<const float4*>(sa + (size_t)b * K1 + 4 * lds32_slot(q));
-                        const float4 hi = *reinterpret_cast<const float4*>(sa + (size_t)b * K1 + 4 * lds32_slot(q + 1));
-                        const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc0[b] = fmaf(a[j], wa[j], acc0[b]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc1[b] = fmaf(a[j], wb[j], acc1[b]);
-                        __builtin_amdgcn_sched_barrier(0);  // one sequence at a time: 8 activation registers live (1024-thread blocks: 128 VGPRs)
-                    }
-                }
-            }
-        }
-        const float t0 = wave_sum_groups<NB>(acc0), t1 = wave_sum_groups<NB>(acc1);
-        if ((lane & 15) == 0 && (lane >> 4) < NB) {
-            g.y2[(int64_t)(lane >> 4) * g.N + n] = t0 + g.b1[n];
-            if (n1 < g.N) g.y2[(int64_t)(lane >> 4) * g.N + n1] = t1 + g.b1[n1];
-        }
-        n = nn;
-    }
-}
-
 }  // namespace showo
