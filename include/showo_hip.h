@@ -249,6 +249,13 @@ int showo_attn_set_impl(int impl);
  * dense GEMV + both residual adds; default), 1 = the general seven-launch layer, 2 = the fused layer as a plain chain
  * (fc2 in the third launch).  All three give the same bits; 1 and 2 exist so that tests and profiles can compare them. */
 int showo_decode_set_impl(int impl);
+/* Infinity-Cache prefetch role of the co-scheduled decode launches (batch 1 and batched): `blocks` extra blocks of every layer's
+ * attention launch read, by LDS-DMA, weights the NEXT launches will stream -- this layer's dense matrix when dense != 0, then
+ * next_mb MB of the next layer's [Wqkv ; W1] (the lm_head after the last layer) -- so that those launches find them in the 256 MiB
+ * memory-side cache.  Nothing is computed from the prefetched bytes: results are bit-identical for every setting
+ * (tests/test_modules_gpu.py).  blocks = 0 or (next_mb = 0 and dense = 0): role absent.  Defaults: SHOWO_DECODE_PF_MB /
+ * SHOWO_DECODE_PF_DENSE / SHOWO_DECODE_PF_BLOCKS.  Takes effect at the next decode call (its graph is captured per call). */
+int showo_decode_set_prefetch(int next_mb, int dense, int blocks);
 int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                    void* stream);

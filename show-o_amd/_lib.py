@@ -36,6 +36,7 @@ _PROTOS = {
     "showo_gemm_counters": [c_p, c_i],
     "showo_attn_set_impl": [c_i],
     "showo_decode_set_impl": [c_i],
+    "showo_decode_set_prefetch": [c_i, c_i, c_i],
     "showo_mask_predict_next": [c_p, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_p, c_p, c_p, c_p],
     "showo_mask_mmu": [c_p, c_i, c_i, c_i64, c_p, c_p, c_p],
     "showo_mask_mmu_vit": [c_i, c_i, c_i, c_i, c_p, c_p, c_p],

@@ -775,10 +775,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f
 // remaining blocks stream the fc2 weights (33.5 MB at Phi-1.5's shape) and write y2 = fc2(gelu(fc1)) + b2, which does not depend on
 // the attention (Phi's block is parallel-residual, models/phi.py:806-835).  No synchronisation between the roles: the following
 // out_gemv2_kernel<1, 2> launch adds dense(attn) and y2 into the residual row.  One launch instead of a stream fork / join.
-__global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPrep f, showo::OutGemvArgs g) {
+__global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPrep f, showo::OutGemvArgs g, showo::DecodePrefetch pf) {
     if ((int)blockIdx.x >= a.nH) {
         extern __shared__ float sp[];
-        showo::fc2_columns_role<4>(g, blockIdx.x - a.nH, gridDim.x - a.nH, 16, reinterpret_cast<bf16_t*>(sp));
+        const int nrole = gridDim.x - a.nH - pf.blocks;
+        if ((int)blockIdx.x >= a.nH + nrole) showo::prefetch_role(pf, blockIdx.x - a.nH - nrole, pf.blocks, sp);
+        else showo::fc2_columns_role<4>(g, blockIdx.x - a.nH, nrole, 16, reinterpret_cast<bf16_t*>(sp));
         return;
     }
     attn_decode_body<true>(a, f, blockIdx.x, 0);
@@ -787,11 +789,13 @@ __global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPre
 // Batched form of the co-scheduled launch (decode_batch.hip): blocks [0, nH * B) = the (sequence, head) attention blocks, the rest
 // stream the fc2 weights ONCE for all NB sequences (fc2_columns_roleB: activations as fp32 in LDS).
 template <int NB>
-__global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPrep f, showo::OutGemvBArgs g) {
+__global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPrep f, showo::OutGemvBArgs g, showo::DecodePrefetch pf) {
     const int nab = a.nH * a.B;
     if ((int)blockIdx.x >= nab) {
         extern __shared__ float sp[];
-        showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, gridDim.x - nab, 16, sp);
+        const int nrole = gridDim.x - nab - pf.blocks;
+        if ((int)blockIdx.x >= nab + nrole) showo::prefetch_role(pf, blockIdx.x - nab - nrole, pf.blocks, sp);
+        else showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, nrole, 16, sp);
         return;
     }
     attn_decode_body<true>(a, f, blockIdx.x % a.nH, blockIdx.x / a.nH);
@@ -945,7 +949,10 @@ int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb,
 }
 int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                          const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
-                         const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s) {
+                         const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s,
+                         const DecodePrefetch* pfp) {
+    DecodePrefetch pf{};
+    if (pfp) pf = *pfp;
     if ((Lp % 64) || !pos_dev || B < 2 || B > 4 || fc2.K1 != 8192 || !fc2.y2 || co_blocks < 1)
         return set_error_msg(1, "batched co-scheduled decode attention: 2..4 sequences, fc2 with K = 8192 and y2 required");
     AttnArgs a;
@@ -958,7 +965,7 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
     if (smem_a > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
     const size_t smem_f = (size_t)B * fc2.K1 * sizeof(float);
     const size_t smem = smem_a > smem_f ? smem_a : smem_f;
-    const dim3 grid(nH * B + co_blocks);
+    const dim3 grid(nH * B + co_blocks + pf.blocks);
     static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};
     auto launch = [&](auto kfn) -> int {
         if (!attr[B]) {
@@ -966,7 +973,7 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
             if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(attn_decode_coB)", __FILE__, __LINE__);
             attr[B] = true;
         }
-        kfn<<<grid, dim3(1024), smem, s>>>(a, f, fc2);
+        kfn<<<grid, dim3(1024), smem, s>>>(a, f, fc2, pf);
         return 0;
     };
     const int rc = B == 2 ? launch(attn_decode_coB_kernel<2>) : B == 3 ? launch(attn_decode_coB_kernel<3>) : launch(attn_decode_coB_kernel<4>);
@@ -977,8 +984,10 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s, const bf16_t* W2, const bf16_t* ffn, const float* b2, int F, int Hout, float* y2,
-                      int co_blocks) {
+                      int co_blocks, const DecodePrefetch* pfp) {
     if ((Lp % 64) || Lp <= pos || Lcap <= pos) return set_error_msg(1, "decode attention: bad Lp/Lcap");
+    DecodePrefetch pf{};
+    if (pfp && W2) pf = *pfp;
     AttnArgs a;
     a.Q = nullptr; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = nullptr; a.dense = nullptr; a.O = O;
     a.B = 1; a.nH = nH; a.Lq = 1; a.Lk = pos + 1; a.Lcap = Lcap; a.Lp = Lp; a.ldo = nH * 64; a.lse = nullptr;
@@ -991,7 +1000,7 @@ int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const
         if (F != 8192 || !y2 || !ffn || !b2) return set_error_msg(1, "decode attention: co-scheduled fc2 needs F = 8192 and y2");
         showo::OutGemvArgs g{nullptr, nullptr, nullptr, nullptr, 0, W2, ffn, b2, F, Hout, y2};
         const size_t smem2 = smem > (size_t)F * sizeof(bf16_t) ? smem : (size_t)F * sizeof(bf16_t);
-        attn_decode_co_kernel<<<dim3(nH + co_blocks, 1), dim3(1024), smem2, s>>>(a, f, g);
+        attn_decode_co_kernel<<<dim3(nH + co_blocks + pf.blocks, 1), dim3(1024), smem2, s>>>(a, f, g, pf);
     } else {
         attn_decode_kernel<true><<<dim3(nH, 1), dim3(1024), smem, s>>>(a, f);
     }

@@ -23,7 +23,8 @@ using namespace showo;
 namespace showo {
 int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                          const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
-                         const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s);
+                         const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s,
+                         const DecodePrefetch* pf);
 int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                             const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
                             const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s);
@@ -462,7 +463,11 @@ extern "C" int showo_engine_batch_begin(showo_engine* e, int nb, int cap_tokens)
     if (!e->bd) e->bd = new showo_engine::BatchDecode();
     auto* d = e->bd;
     const int64_t need = (int64_t)e->nL * nb * e->nH * cap * 64;
-    if (need > d->elems) {
+    if (need > d->elems) {  // grow: the previous caches are freed first (nothing of an earlier batch survives a batch_begin)
+        SHOWO_CHECK_HIP(hipDeviceSynchronize());
+        e->release(&d->k);
+        e->release(&d->vt);
+        d->elems = 0;
         TRY(e->alloc(&d->k, need));
         TRY(e->alloc(&d->vt, need));
         d->elems = need;
@@ -553,9 +558,11 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
                 // [ attention of the nb x heads (sequence, head) pairs || fc2 of all nb sequences -> y2 ] -> dense + both residual adds
                 // (Phi's block is parallel-residual, models/phi.py:806-835: fc2 does not depend on the attention; decode.hip's batch-1 layer
                 // co-schedules the same way)
+                showo::DecodePrefetch pf;
+                showo::decode_prefetch_plan(e, li, &pf);
                 TRY(showo::attn_decode_co_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,
                                                 d->vt + li * lstride, d->iv_dev, e->attn, nb, nH, e->cfg.rotary_dim, e->cfg.ln_eps,
-                                                d->pos_dev, lk_max, d->cap, d->cap, o, co_blocks, s));
+                                                d->pos_dev, lk_max, d->cap, d->cap, o, co_blocks, s, &pf));
                 TRY(out_dense_y2B(nb, o, s));
             } else {
                 TRY(showo::attn_decode_fused_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,

@@ -71,6 +71,33 @@ static __device__ __forceinline__ void fc2_columns_role(const OutGemvArgs& g, in
     }
 }
 
+// ---- Infinity-Cache prefetch role of the co-scheduled decode launches ---------------------------------------------------------------
+// The attention launch of a decode layer is latency-bound (32 x NB single-query blocks) and its fc2 role needs 33.5 MB: HBM idles for
+// part of it, and the CUs neither role occupies idle throughout.  Extra blocks of the SAME launch read weights the NEXT launches will
+// stream (this layer's dense matrix, the next layer's [Wqkv ; W1]) so that those launches find them in the 256 MiB memory-side cache.
+// The reads are LDS-DMA (global_load_lds, 16 B per lane, default cache policy, no VGPR round trip; the LDS image is scratch that every
+// wave overwrites): nothing is computed from them, the product's results cannot depend on this role.
+struct DecodePrefetch {
+    const void* p[3];   // up to three segments, read in order
+    int64_t bytes[3];   // multiples of 16
+    int blocks;         // prefetch blocks appended to the grid (0: role absent)
+};
+// block rb of nrb: a contiguous slice of every segment; lds: >= nw KiB of LDS (1 KiB per wave)
+static __device__ __forceinline__ void prefetch_role(const DecodePrefetch& pf, int rb, int nrb, void* lds) {
+    const int wave = threadIdx.x >> 6, nthr = blockDim.x;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(lds) + wave * 512;
+#pragma unroll 1
+    for (int sgm = 0; sgm < 3; ++sgm) {
+        const int64_t n16 = pf.bytes[sgm] >> 4;
+        if (n16 <= 0) continue;
+        const int64_t per = (((n16 + nrb - 1) / nrb) + nthr - 1) / nthr * nthr;
+        const int64_t i0 = (int64_t)rb * per, i1 = i0 + per < n16 ? i0 + per : n16;
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(pf.p[sgm]);
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += nthr) glds16(src + i * 8, dst);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- batched decode (decode_batch.hip): NB sequences share one weight stream --------------------------------------------------
 struct OutGemvBArgs {
     float* x;          // [NB, N] fp32 residual rows (ld = N), updated in place

@@ -34,6 +34,7 @@ void attn_set_decode_pos(const int* p, int lk_max = 0);
 int sample_topk_launch(const float* logits, int V, int top_k, float temperature, const float* exp_noise, int64_t noise_stride,
                        uint64_t seed, int step, const int* pos_dev, int pos_base, int64_t* tok, hipStream_t s);
 // fused decode layer (decode.hip, attention.hip)
+struct DecodePrefetch;
 bool decode_fused_shapes_ok(int H, int F);
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
                     bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s);
@@ -42,7 +43,11 @@ int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* 
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s, const bf16_t* W2 = nullptr, const bf16_t* ffn = nullptr, const float* b2 = nullptr,
-                      int F = 0, int Hout = 0, float* y2 = nullptr, int co_blocks = 0);
+                      int F = 0, int Hout = 0, float* y2 = nullptr, int co_blocks = 0, const DecodePrefetch* pf = nullptr);
+// Infinity-Cache prefetch role of the co-scheduled decode launches (decode_common.h): what layer li's attention launch reads ahead.
+// next_mb: MB of the next launches' weights ([Wqkv ; W1] of layer li + 1, the lm_head after the last layer), dense: this layer's Wd
+// first, blocks: prefetch blocks per launch (0: off).  Defaults from SHOWO_DECODE_PF_MB / _DENSE / _BLOCKS; showo_decode_set_prefetch.
+void decode_prefetch_plan(const ::showo_engine* e, int li, DecodePrefetch* pf);
 int greedy_token_seam(const float* logits, int n, int64_t* tok, int64_t* out_tokens, int* pos, int base, const float* table, float* x, int H,
                       int V, const int32_t* last_iv, int L0, int32_t* iv, hipStream_t s);
 int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t s);
@@ -159,6 +164,15 @@ struct showo_engine {
     float* sched_dev = nullptr;
     int sched_cap = 0;
 
+    // hipFree a buffer obtained from alloc() and forget it (buffers that are re-sized during the engine's life)
+    template <class T>
+    void release(T** p) {
+        if (!*p) return;
+        for (size_t i = 0; i < allocs.size(); ++i)
+            if (allocs[i] == (void*)*p) { allocs.erase(allocs.begin() + i); break; }
+        hipFree((void*)*p);
+        *p = nullptr;
+    }
     template <class T>
     int alloc(T** p, int64_t n) {
         void* q = nullptr;

@@ -14,6 +14,7 @@
 //   weights: Wqkv [3H,H], Wd [H,H], W1 [F,H], W2 [H,F], Wlm [V,H] bf16 row-major (= nn.Linear layout,
 //   K-contiguous, exactly what the MFMA GEMM's operand loader wants); biases / LayerNorm params fp32.
 #include "engine.h"
+#include "decode_common.h"
 #include <cstdio>
 #include <vector>
 #include <cstring>
@@ -384,6 +385,52 @@ static int collect_x(showo_engine* e, int slot, int T, hipStream_t s) {
     return 0;
 }
 
+// ---- Infinity-Cache prefetch plan of the decode layers (decode_common.h, prefetch_role) -------------------------------------------
+static int g_pf_mb = -1, g_pf_dense = 1, g_pf_blocks = 64;
+static void decode_prefetch_env() {
+    if (g_pf_mb >= 0) return;
+    const char* m = getenv("SHOWO_DECODE_PF_MB");
+    g_pf_mb = m ? atoi(m) : 0;
+    if (g_pf_mb < 0) g_pf_mb = 0;
+    const char* d = getenv("SHOWO_DECODE_PF_DENSE");
+    if (d) g_pf_dense = atoi(d) != 0;
+    const char* b = getenv("SHOWO_DECODE_PF_BLOCKS");
+    if (b && atoi(b) > 0) g_pf_blocks = atoi(b);
+}
+extern "C" int showo_decode_set_prefetch(int next_mb, int dense, int blocks) {
+    if (next_mb < 0 || blocks < 0 || blocks > 1024) return set_error_msg(1, "showo_decode_set_prefetch: next_mb >= 0, 0 <= blocks <= 1024");
+    decode_prefetch_env();
+    g_pf_mb = next_mb;
+    g_pf_dense = dense != 0;
+    g_pf_blocks = blocks;
+    return 0;
+}
+namespace showo {
+void decode_prefetch_plan(const ::showo_engine* e, int li, DecodePrefetch* pf) {
+    decode_prefetch_env();
+    *pf = DecodePrefetch{};
+    if ((g_pf_mb == 0 && !g_pf_dense) || g_pf_blocks == 0) return;
+    const int64_t H = e->H, F = e->F;
+    int n = 0;
+    if (g_pf_dense) { pf->p[n] = e->layers[li].wd; pf->bytes[n] = H * H * 2; ++n; }
+    int64_t left = (int64_t)g_pf_mb << 20;
+    auto add = [&](const void* p, int64_t bytes) {
+        if (left <= 0 || !p) return;
+        const int64_t b = (bytes < left ? bytes : left) & ~(int64_t)15;
+        pf->p[n] = p; pf->bytes[n] = b; ++n;
+        left -= b;
+    };
+    if (li + 1 < e->nL) {
+        add(e->layers[li + 1].wqkv, 3 * H * H * 2);
+        if (n < 3) add(e->layers[li + 1].w1, F * H * 2);
+    } else {
+        add(e->wlm, (int64_t)e->V * H * 2);
+    }
+    pf->blocks = n ? g_pf_blocks : 0;
+}
+}  // namespace showo
+
+
 // ---- accuracy mode ----------------------------------------------------------------------------------------------------------------
 // Two implementations.  (1) precise.hip (run_layers_precise): split-bf16 GEMMs on the 128^2 kernel, everything between them in fp32 on
 // the vector ALU: any shape, slow.  (2) run_layers_precise_fast (round 5): the PRODUCTION kernels on K-concatenated split images.  A
@@ -611,8 +658,10 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             if (co) {
                 TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
                                            e->ffn, F, s));
+                showo::DecodePrefetch pf;
+                showo::decode_prefetch_plan(e, li, &pf);
                 TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
-                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, l.w2, e->ffn, l.b2, F, H, e->y2, co_blocks));
+                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, l.w2, e->ffn, l.b2, F, H, e->y2, co_blocks, &pf));
                 TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2));
                 continue;
             }

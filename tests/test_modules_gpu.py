@@ -613,6 +613,14 @@ def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
     got4 = [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=embs, attention_mask=ams, max_new_tokens=24, top_k=1)]
     print(f"[parity] full-size cfg4, 4 sequences (631 / 620 / 643 / 600 embeddings) decoded together == 4 batch-1 calls: {got4 == single}")
     assert got4 == single and got4[0][:len(toks)] == toks
+    # the Infinity-Cache prefetch role of the co-scheduled launches (decode_common.h) computes nothing: same tokens for any setting
+    for mb, dense, blocks in ((58, 1, 64), (7, 0, 3), (300, 1, 200)):
+        L.call("showo_decode_set_prefetch", mb, dense, blocks)
+        try:
+            assert [int(t) for t in m.mmu_generate(input_embeddings=embs[1], attention_mask=ams[1], max_new_tokens=24, top_k=1)] == single[1]
+            assert [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=embs, attention_mask=ams, max_new_tokens=24, top_k=1)] == single
+        finally:
+            L.call("showo_decode_set_prefetch", 0, 0, 0)
     # ---- accuracy mode (projector + transformer): 1e-3 against the fp32 reference, tokens identical
     m.set_precision(1)
     imgp, embp = splice()
