@@ -39,6 +39,9 @@ int showo_cu_usable(void* stream);
 /* which CUs does a launch on `stream` run on?  Launches `blocks` one-wave blocks and records per block (xcc_id << 16) | hw_id bits
  * (se, sh, cu) into ids int32 [blocks] (device): tests count the distinct CUs per XCD under a mask. */
 int showo_cu_census(int32_t* ids, int blocks, int spin, void* stream);
+/* test probe of the wave reductions (common.h): wave w reduces in[64 w .. 64 w + 63]; out[4 w + {0,1,2,3}] = the ds_bpermute butterfly
+ * sum, the VALU-only sum (v_permlane32/16_swap + DPP) the decode kernels use, the butterfly max, the VALU-only max.  Same bits. */
+int showo_wave_reduce_probe(const float* in, float* out, int n_waves, void* stream);
 
 /* per-launch HIP-event timing of the hot kernels (bench.py roofline leg).  kind: 0 = GEMM, 1 = attention,
  * 2 = conv.  read() synchronises the device and returns summed elapsed ms, launch count, summed algorithmic flops. */
@@ -256,6 +259,10 @@ int showo_decode_set_impl(int impl);
  * (tests/test_modules_gpu.py).  blocks = 0 or (next_mb = 0 and dense = 0): role absent.  Defaults: SHOWO_DECODE_PF_MB /
  * SHOWO_DECODE_PF_DENSE / SHOWO_DECODE_PF_BLOCKS.  Takes effect at the next decode call (its graph is captured per call). */
 int showo_decode_set_prefetch(int next_mb, int dense, int blocks);
+/* Grid knobs of the decode launches for sweeps in one process (defaults <- environment): name in
+ * { "co_blocks", "batch_co_blocks", "batch_ln_blocks", "ln_blocks", "out_blocks" }.  Results never depend on them (every grid walks
+ * the output columns with a stride; each column is reduced by one wave in one fixed order). */
+int showo_decode_set_tuning(const char* name, int value);
 int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                    void* stream);

@@ -37,6 +37,7 @@ _PROTOS = {
     "showo_attn_set_impl": [c_i],
     "showo_decode_set_impl": [c_i],
     "showo_decode_set_prefetch": [c_i, c_i, c_i],
+    "showo_decode_set_tuning": [C.c_char_p, c_i],
     "showo_mask_predict_next": [c_p, c_i, c_i, c_i64, c_i64, c_i64, c_i, c_p, c_p, c_p, c_p],
     "showo_mask_mmu": [c_p, c_i, c_i, c_i64, c_p, c_p, c_p],
     "showo_mask_mmu_vit": [c_i, c_i, c_i, c_i, c_p, c_p, c_p],
@@ -167,6 +168,7 @@ _PROTOS = {
     "showo_grad_clip_norm": [c_p, c_i64, c_f, c_p, c_p, c_p],
     "showo_grad_clip_ws_doubles": [],
     "showo_cu_census": [c_p, c_i, c_i, c_p],
+    "showo_wave_reduce_probe": [c_p, c_p, c_i, c_p],
     "showo_prof_enable": [c_i],
     "showo_prof_reset": [],
     "showo_prof_read": [c_i, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)],

@@ -15,6 +15,7 @@
 // L2 (one head's K+V is 97 KB at L=387), waves of a block are independent (no LDS, no barriers).
 #include "common.h"
 #include "decode_common.h"
+#include <type_traits>
 #include "../../include/showo_hip.h"
 #include "prof.h"
 #include <cfloat>
@@ -615,55 +616,77 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
     // a.Lk from the host is exact for a direct launch and an UPPER BOUND under graph replay (pos_dev set: the engine passes the last
     // position the captured loop can reach); the cache loads below are predicated on it, so they do not wait for the pos_dev round trip.
     const int Lhint = a.Lk;
-    // Everything the cache contributes is requested up front (the first 1024 key rows: one per thread; the first 1024
-    // keys of this wave's four V^T rows), so the launch costs one HBM round trip, not one per phase.
+    // ONE memory round trip for everything that does not depend on the position, issued in this order:
+    //   (1) FUSED: the new token's q / k / v element of this head and the q / k LayerNorm weight + bias of this lane -- first in program
+    //       order, so that the wave can wait for them (vmcnt counts in order) while the cache loads behind them are still in flight;
+    //   (2) the cache: the first 1024 key rows (one per thread) and the first 1024 keys of this wave's four V^T rows.
+    // No load sits under a branch (a wait behind a conditionally issued load can only be vmcnt(0), which made the prologue four
+    // SERIAL round trips: position -> [token element + all cache loads] -> LayerNorm parameters -> RoPE row): rows / columns at or
+    // beyond the hint are clamped onto the last live one (same address for every such lane: no extra traffic).
     const bf16_t* Kb = a.K + bh * a.Lcap * 64;
     const int d0 = wave * 4;
     const bf16_t* vr = a.Vt + (bh * 64 + d0) * a.Lp;
     // key rows are read coalesced: a wave instruction covers 8 whole rows (lane -> row lane>>3, 16-B chunk lane&7), wave w of
     // the block takes row group it*16 + w; the first 8 groups per wave (1024 keys) are requested before anything else.
     const int r8 = lane >> 3, ch = lane & 7;
+    int pos = -1;  // FUSED: index of the key that lives in LDS
+    if (FUSED) pos = a.pos_dev ? a.pos_dev[b] : f.pos;  // one position per sequence (b = 0 in the batch-1 launches); requested first
+    // the mask operands too (absent ones read a valid dummy address instead of branching)
+    const int flagv = *(a.flag ? a.flag : reinterpret_cast<const int32_t*>(a.K));
+    const int4 ivrow = *reinterpret_cast<const int4*>(a.iv ? a.iv + (int64_t)b * 4 : reinterpret_cast<const int32_t*>(a.K));
+    bf16_t xin = 0;
+    float lnw = 0.f, lnb = 0.f;
+    if (FUSED) {
+        const int Hq = a.nH * 64;
+        f.qkv += (int64_t)b * 3 * Hq;  // projection row of sequence b
+        const int sel = wave < 2 ? wave : 2;  // wave 0: q, wave 1: k, the others: v (one cache line)
+        xin = f.qkv[sel * Hq + head * 64 + lane];
+        lnw = (sel == 0 ? f.qw : f.kw)[lane];
+        lnb = (sel == 0 ? f.qb : f.kb)[lane];
+    }
     uint4 ku[8], vu[2][4];
+    const int klast = Lhint - 1, vlast = (Lhint - 1) & ~7;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const int k = (it * 16 + wave) * 8 + r8;
-        ku[it] = k < Lhint ? *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+        const int k = min((it * 16 + wave) * 8 + r8, klast);
+        ku[it] = *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8);
     }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            vu[cc][i] = (cc * 512 + 8 * lane < Lhint) ? *reinterpret_cast<const uint4*>(vr + (int64_t)i * a.Lp + cc * 512 + 8 * lane)
-                                                      : make_uint4(0, 0, 0, 0);
+            vu[cc][i] = *reinterpret_cast<const uint4*>(vr + (int64_t)i * a.Lp + min(cc * 512 + 8 * lane, vlast));
     // rows / columns at or beyond the live length (and the row being appended by this launch, k == pos) may hold stale or
     // uninitialised bits: score() and accum() never let them reach a result
-    int pos = -1;  // FUSED: index of the key that lives in LDS
     if (FUSED) {
-        pos = a.pos_dev ? a.pos_dev[b] : f.pos;  // one position per sequence (b = 0 in the batch-1 launches)
         a.Lk = pos + 1;
     } else if (a.pos_dev) {
         a.Lk = *a.pos_dev + 1;
     }
     float qv[8];  // this lane's 8 query dimensions (chunk ch)
     if (FUSED) {
-        const int Hq = a.nH * 64;
-        f.qkv += (int64_t)b * 3 * Hq;  // projection row of sequence b
-        if (wave < 2) {
-            const float* cosr = f.cosT + (int64_t)pos * f.rot;
-            const float* sinr = f.sinT + (int64_t)pos * f.rot;
-            if (wave == 0) {
-                const float y = ln_rope_lane(bf2f(f.qkv[head * 64 + lane]), f.qw[lane], f.qb[lane], f.eps, cosr, sinr, f.rot, lane);
-                sq[lane] = bf2f(f2bf(y * 0.125f));
-            } else {
-                const float y = ln_rope_lane(bf2f(f.qkv[Hq + head * 64 + lane]), f.kw[lane], f.kb[lane], f.eps, cosr, sinr, f.rot, lane);
-                const bf16_t kb = f2bf(y);
-                sk[lane] = bf2f(kb);
-                const_cast<bf16_t*>(a.K)[(bh * a.Lcap + pos) * 64 + lane] = kb;
-            }
+        // the RoPE row of the new token: the only loads that depend on the position (every wave issues them: no branch before the wait)
+        const int dl = lane < f.rot ? lane : 0;
+        const float cs = f.cosT[(int64_t)pos * f.rot + dl], sn = f.sinT[(int64_t)pos * f.rot + dl];
+        __builtin_amdgcn_sched_barrier(0);  // every load of the prologue is issued before the first wait (the scheduler otherwise starts the LayerNorm -- and its wait for the token element -- ahead of the RoPE loads)
+        // ln_rope_lane's expressions with the statistics on the VALU-only reductions (same bits) and the RoPE operands in registers
+        const float x0 = bf2f(xin);
+        const float mean = wave_sum_swap(x0) * (1.0f / 64.0f);
+        const float c = x0 - mean;
+        const float var = wave_sum_swap(c * c) * (1.0f / 64.0f);
+        float y = c * (1.0f / sqrtf(var + f.eps)) * lnw + lnb;
+        const int half = f.rot >> 1;
+        const float partner = __shfl_xor(y, half, 64);
+        if (lane < f.rot) y = y * cs + (lane < half ? -partner : partner) * sn;
+        if (wave == 0) {
+            sq[lane] = bf2f(f2bf(y * 0.125f));
+        } else if (wave == 1) {
+            const bf16_t kb = f2bf(y);
+            sk[lane] = bf2f(kb);
+            const_cast<bf16_t*>(a.K)[(bh * a.Lcap + pos) * 64 + lane] = kb;
         } else if (wave == 2) {
-            const bf16_t vb = f.qkv[2 * Hq + head * 64 + lane];
-            sv[lane] = bf2f(vb);
-            const_cast<bf16_t*>(a.Vt)[(bh * 64 + lane) * a.Lp + pos] = vb;
+            sv[lane] = bf2f(xin);
+            const_cast<bf16_t*>(a.Vt)[(bh * 64 + lane) * a.Lp + pos] = xin;
         }
         __syncthreads();
 #pragma unroll
@@ -674,42 +697,57 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
 #pragma unroll
         for (int j = 0; j < 8; ++j) qv[j] = bf2f(e[j]);
     }
-    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);
+    // the new token's key chunk / value dimensions in registers: the selects below stay selects (an LDS read under a per-element
+    // condition compiles to a branch per element)
+    float skv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, svv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FUSED) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) skv[j] = sk[ch * 8 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) svv[i] = sv[d0 + i];
+    }
+    const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (flagv != 0);
     int lo1, hi1, lo2, hi2;
     if (dense) { lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0; }
     else if (a.iv) {
-        const int4 v = *reinterpret_cast<const int4*>(a.iv + (int64_t)b * 4);
-        lo1 = v.x; hi1 = v.y; lo2 = v.z; hi2 = v.w;
+        lo1 = ivrow.x; hi1 = ivrow.y; lo2 = ivrow.z; hi2 = ivrow.w;
     } else { lo1 = 0; hi1 = a.Lk; lo2 = 0; hi2 = 0; }  // causal: the newest token sees every key
     hi1 = min(hi1, a.Lk); hi2 = min(hi2, a.Lk);
     const float* drow = dense ? a.dense + (int64_t)b * a.Lk : nullptr;
     const int Lkp = (a.Lk + 511) & ~511;
     float mx = -INFINITY;
-    auto score = [&](int k, const uint4& kr) {  // all 8 lanes of a row end with the row's score
+    // all 8 lanes of a row end with the row's score.  Branch-free up to the LDS store, so the eight unrolled calls interleave; the
+    // 8-lane sum runs on DPP (partners 1, 2 = quad permutes; partner 4 = the half-row mirror, whose source lane sits in the other quad
+    // and -- quads being uniform after the first two steps -- holds lane^4's value): __shfl_xor's values and order, no LDS round trip.
+    auto score = [&](auto dense_c, int k, const uint4& kr) {  // dense_c: the (block-uniform) dense-mask case as a compile-time constant
         const bf16_t* e = reinterpret_cast<const bf16_t*>(&kr);
         float sc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sc = fmaf(qv[j], (FUSED && k == pos) ? sk[ch * 8 + j] : bf2f(e[j]), sc);
-        sc += __shfl_xor(sc, 1, 64);
-        sc += __shfl_xor(sc, 2, 64);
-        sc += __shfl_xor(sc, 4, 64);
-        if (k < a.Lk) {
-            const bool vis = ((k >= lo1) & (k < hi1)) | ((k >= lo2) & (k < hi2));
-            if (dense) sc += drow[k];
-            sc = vis ? sc : -INFINITY;
-            if (ch == 0) sp[k] = sc;
-            mx = fmaxf(mx, sc);
-        }
+        for (int j = 0; j < 8; ++j) sc = fmaf(qv[j], (FUSED && k == pos) ? skv[j] : bf2f(e[j]), sc);
+        sc += dpp_move<DPP_XOR1>(sc);
+        sc += dpp_move<DPP_XOR2>(sc);
+        sc += dpp_move<DPP_HALF_MIRROR>(sc);
+        const bool live = k < a.Lk;
+        const bool vis = ((k >= lo1) & (k < hi1)) | ((k >= lo2) & (k < hi2));
+        if (decltype(dense_c)::value && live) sc += drow[k];
+        sc = (live && vis) ? sc : -INFINITY;
+        if (live && ch == 0) sp[k] = sc;
+        mx = fmaxf(mx, sc);
     };
+    if (dense) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
-        if ((it * 16 + wave) * 8 < a.Lk) score((it * 16 + wave) * 8 + r8, ku[it]);
+        for (int it = 0; it < 8; ++it) score(std::true_type{}, (it * 16 + wave) * 8 + r8, ku[it]);
+    } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) score(std::false_type{}, (it * 16 + wave) * 8 + r8, ku[it]);
+    }
     for (int g = 128 + wave; g * 8 < a.Lk; g += 16) {
         const int k = g * 8 + r8;
         const uint4 kr = (k < a.Lk && k != pos) ? *reinterpret_cast<const uint4*>(Kb + (int64_t)k * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
-        score(k, kr);
+        if (dense) score(std::true_type{}, k, kr);
+        else score(std::false_type{}, k, kr);
     }
-    mx = wave_max(mx);
+    mx = wave_max_swap(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = red[0];
@@ -726,7 +764,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         }
         sp[k] = p;
     }
-    sum = wave_sum(sum);
+    sum = wave_sum_swap(sum);
     if (lane == 0) red[16 + wave] = sum;
     __syncthreads();
     float tot = 0.f;
@@ -746,7 +784,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         for (int i = 0; i < 4; ++i) {
             const bf16_t* e = reinterpret_cast<const bf16_t*>(&u[i]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[i] = fmaf(pr[j], j == jn ? sv[d0 + i] : (j < nvalid ? bf2f(e[j]) : 0.f), o[i]);
+            for (int j = 0; j < 8; ++j) o[i] = fmaf(pr[j], j == jn ? svv[i] : (j < nvalid ? bf2f(e[j]) : 0.f), o[i]);
         }
     };
     accum(0, vu[0]);
@@ -759,7 +797,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         accum(c, u);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = wave_sum(o[i]);
+    for (int i = 0; i < 4; ++i) o[i] = wave_sum_swap(o[i]);
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a.O[(int64_t)b * a.ldo + head * 64 + d0 + i] = f2bf(o[i] * inv);
@@ -787,7 +825,7 @@ __global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPre
 }
 
 // Batched form of the co-scheduled launch (decode_batch.hip): blocks [0, nH * B) = the (sequence, head) attention blocks, the rest
-// stream the fc2 weights ONCE for all NB sequences (fc2_columns_roleB: activations as fp32 in LDS).
+// stream the fc2 weights ONCE for all NB sequences (fc2_columns_roleB: the NB activation rows as bf16 in LDS).
 template <int NB>
 __global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPrep f, showo::OutGemvBArgs g, showo::DecodePrefetch pf) {
     const int nab = a.nH * a.B;
@@ -795,7 +833,7 @@ __global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPr
         extern __shared__ float sp[];
         const int nrole = gridDim.x - nab - pf.blocks;
         if ((int)blockIdx.x >= nab + nrole) showo::prefetch_role(pf, blockIdx.x - nab - nrole, pf.blocks, sp);
-        else showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, nrole, 16, sp);
+        else showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, nrole, 16, reinterpret_cast<bf16_t*>(sp));
         return;
     }
     attn_decode_body<true>(a, f, blockIdx.x % a.nH, blockIdx.x / a.nH);
@@ -963,7 +1001,7 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
     DecPrep f{qkv, qw, qb, kw, kb, cosT, sinT, rot, 0, eps};
     const size_t smem_a = (size_t)((Lcap + 511) & ~511) * sizeof(float);
     if (smem_a > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
-    const size_t smem_f = (size_t)B * fc2.K1 * sizeof(float);
+    const size_t smem_f = (size_t)B * fc2.K1 * sizeof(bf16_t);
     const size_t smem = smem_a > smem_f ? smem_a : smem_f;
     const dim3 grid(nH * B + co_blocks + pf.blocks);
     static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};

@@ -547,3 +547,23 @@ extern "C" int showo_cu_census(int32_t* ids, int blocks, int spin, void* stream)
     if (e != hipSuccess) return showo::set_error_hip(e, "cu_census launch", __FILE__, __LINE__);
     return 0;
 }
+
+// Probe of the wave reductions (tests): wave w of the launch reduces in[64 w .. 64 w + 63]; out[4 w + {0, 1, 2, 3}] = wave_sum,
+// wave_sum_swap (permlane swaps + DPP), wave_max, wave_max_swap.  The VALU-only forms must give wave_sum's / wave_max's bits.
+namespace {
+__global__ __launch_bounds__(256) void wave_reduce_probe_kernel(const float* __restrict__ in, float* __restrict__ out, int n_waves) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= n_waves) return;
+    const float v = in[(int64_t)w * 64 + lane];
+    const float a = showo::wave_sum(v), b = showo::wave_sum_swap(v), c = showo::wave_max(v), d = showo::wave_max_swap(v);
+    // every lane must hold the result: report a lane that varies with w
+    if (lane == (w & 63)) { out[4 * w] = a; out[4 * w + 1] = b; out[4 * w + 2] = c; out[4 * w + 3] = d; }
+}
+}  // namespace
+extern "C" int showo_wave_reduce_probe(const float* in, float* out, int n_waves, void* stream) {
+    if (!in || !out || n_waves < 1) return showo::set_error_msg(1, "wave_reduce_probe: bad argument");
+    wave_reduce_probe_kernel<<<dim3((n_waves + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(in, out, n_waves);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return showo::set_error_hip(e, "wave_reduce_probe launch", __FILE__, __LINE__);
+    return 0;
+}

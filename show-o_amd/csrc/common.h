@@ -62,16 +62,46 @@ __device__ inline float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-// wave_sum with its first two steps (partners 32 and 16 lanes away) on gfx950's row-swap instructions -- VALU only, no trip through the
-// LDS crossbar -- and the same order of additions: identical bits (the decode GEMVs reduce once per weight row per wave)
+// DPP lane moves (VALU only, no trip through the LDS crossbar).  On gfx9 a 16-lane row offers rotations and quad permutes, not a
+// general xor: partner 8 away IS the rotation by 8; partner 4 away is the rotation by 4 once the values have period 8 within the row
+// (true after the step-8 addition of a butterfly reduction: v[i] == v[i ^ 8]); partners 2 and 1 are quad permutes.
+template <int CTRL>
+__device__ inline float dpp_move(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_ROR8 = 0x128, DPP_ROR4 = 0x124, DPP_XOR2 = 0x4E, DPP_XOR1 = 0xB1;  // row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i of every 8 <- lane 7 - i
+// the last four steps (partners 8, 4, 2, 1) of a butterfly sum / max on DPP: the partner VALUES of __shfl_xor, hence the same bits
+__device__ inline float row_sum_dpp(float v) {
+    v += dpp_move<DPP_ROR8>(v);
+    v += dpp_move<DPP_ROR4>(v);
+    v += dpp_move<DPP_XOR2>(v);
+    v += dpp_move<DPP_XOR1>(v);
+    return v;
+}
+__device__ inline float row_max_dpp(float v) {
+    v = fmaxf(v, dpp_move<DPP_ROR8>(v));
+    v = fmaxf(v, dpp_move<DPP_ROR4>(v));
+    v = fmaxf(v, dpp_move<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_move<DPP_XOR1>(v));
+    return v;
+}
+// wave_sum entirely on the VALU: partners 32 and 16 on gfx950's row-swap instructions, 8 .. 1 on DPP -- the same partner values in the
+// same order of additions as wave_sum: identical bits (tests/test_kernels_gpu.py).  The decode GEMVs reduce once per weight row per
+// wave and the single-query attention runs five dependent reductions: a ds_bpermute step costs an LDS round trip (~100 cycles) each.
 __device__ inline float wave_sum_swap(float v) {
     const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
     const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return row_sum_dpp(v);
+}
+__device__ inline float wave_max_swap(float v) {
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+    return row_max_dpp(v);
 }
 __device__ inline float wave_max(float v) {
 #pragma unroll
@@ -93,6 +123,22 @@ __device__ inline float gelu_new_fast(float x) {
     // gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
     float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+
+// acc + w[0] a[0] + w[1] a[1] on packed bf16 pairs: v_dot2c_f32_bf16 (gfx950), no bf16 -> fp32 conversions (the converting FMA form
+// costs 3 VALU instructions per product; the decode GEMVs were VALU-bound next to their weight stream).  dot8_bf16 -- the four pairs of
+// a 16-byte group in ascending order into ONE accumulator -- is THE accumulation order of every GEMV of the decode step (gemv_kernel,
+// ln_gemv2 / out_gemv2, the batched kernels, the co-scheduled fc2 roles): they all give the same bits per output column.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ inline float dot2_bf16(uint32_t w, uint32_t a, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, a), acc, false);
+}
+__device__ inline float dot8_bf16(const uint4& w, const uint4& a, float acc) {
+    acc = dot2_bf16(w.x, a.x, acc);
+    acc = dot2_bf16(w.y, a.y, acc);
+    acc = dot2_bf16(w.z, a.z, acc);
+    acc = dot2_bf16(w.w, a.w, acc);
+    return acc;
 }
 
 // 16-byte streaming load with the non-temporal hint (global_load_dwordx4 ... nt): weights that ONE wave reads once (decode GEMVs)

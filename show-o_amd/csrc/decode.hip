@@ -12,6 +12,7 @@
 // lane split, same accumulation order, same epilogue expressions -- so the fused step is bit-identical to the unfused one.
 // The next 4 x 16-B weight loads of a wave are always in flight while the current ones are multiplied.
 #include "common.h"
+#include "engine.h"
 #include "decode_common.h"
 #include "../../include/showo_hip.h"
 
@@ -188,7 +189,7 @@ int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float ep
     // token in one box, gpurun_out/bench_mmu_r2z_*: 123 VGPRs halve the resident waves and the single burst queues behind itself)
     static int lnr = 0;
     if (!lnr) { const char* e = getenv("SHOWO_DECODE_LNR"); lnr = (e && atoi(e) == 4) ? 4 : 2; }
-    if (lnr == 2) ln_gemv2_kernel<2><<<dim3(pick_blocks(N0 + N1, 12, 1280)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    if (lnr == 2) ln_gemv2_kernel<2><<<dim3(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
     else ln_gemv2_kernel<4><<<dim3(pick_blocks(N0 + N1, 16, 1024)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "ln_gemv2 launch", __FILE__, __LINE__);
@@ -203,7 +204,7 @@ int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* 
     if (mode == 2) g.K1 = 0;
     if (mode && !y2) return set_error_msg(1, "decode_out_gemv2: y2 required");
     const int C = (g.K0 + 2047) / 2048 + (g.K1 + 2047) / 2048;
-    const dim3 grid(pick_blocks(N, 8, 256));
+    const dim3 grid(pick_blocks(N, 8, showo::decode_tuning().out_blocks));
     const size_t smem = (size_t)(g.K0 + g.K1) * sizeof(bf16_t);
     if (mode == 1 && C == 4) out_gemv2_kernel<4, 1><<<grid, dim3(512), smem, s>>>(g);
     else if (mode == 1 && C >= 1 && C <= 3) out_gemv2_kernel<3, 1><<<grid, dim3(512), smem, s>>>(g);

@@ -56,11 +56,11 @@ struct LnGemvBArgs {
     int N1, ld1;
 };
 
-// REG (NB <= 4): after the LayerNorm every lane keeps ITS 32 activation values of each sequence in registers as fp32 (the k positions
-// lane * 8 + u * 512 + j are the same for every weight row), so a weight row costs 32 conversions + 32 NB FMAs per lane and no LDS
-// read -- with the activations re-read from LDS as bf16 per row (the batch-1 form, !REG) four sequences made the step VALU-bound
-// (1.61 ms per 4-token step against 0.96 ms per batch-1 token).  Fewer, longer-lived waves (2 blocks per CU) amortise the register
-// fill (grid caps 256 / 1024 and 4 rows in flight measured slower: profiles/r5_decode_batch_sweep.txt).  Same products and the same accumulation order per sequence either way.
+// REG (NB <= 4): after the LayerNorm every lane keeps ITS 32 activation values of each sequence in registers as 16 packed bf16 pairs
+// (the k positions lane * 8 + u * 512 + j are the same for every weight row), so a weight row costs 16 NB v_dot2c_f32_bf16 per lane, no
+// conversion and no LDS read -- with the activations re-read from LDS per row (the batch-1 form, !REG) four sequences made the step
+// VALU / LDS-bound.  Fewer, longer-lived waves (2 blocks per CU) amortise the register fill (grid caps 256 / 1024 and 4 rows in flight
+// measured slower: profiles/r5_decode_batch_sweep.txt).  Same products and the same accumulation order per sequence either way.
 template <int NB, bool REG>
 __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048; 2 weight rows in flight per wave (4: measured slower)
     constexpr int R = 2;
@@ -111,19 +111,10 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
         }
     }
     __syncthreads();
-    float act[REG ? NB : 1][32];
+    uint32_t act[REG ? NB : 1][16];
     if constexpr (REG) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = lane * 8 + u * 512;
-                uint4 av = make_uint4(0, 0, 0, 0);
-                if (k < H) av = *reinterpret_cast<const uint4*>(sh + b * H + k);
-                const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) act[b][u * 8 + j] = bf2f(ea[j]);
-            }
+        for (int b = 0; b < NB; ++b) load_act_pairs(sh + b * H, lane * 8, H, act[b]);
     }
     while (n < Ntot) {
 #pragma unroll
@@ -253,18 +244,9 @@ __global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
     int n = blockIdx.x * 8 + wave;
     uint4 buf[4];
     if (n < g.N) load4(g.W0 + (int64_t)n * g.K0, lane * 8, g.K0, buf);
-    float act[NB][32];
+    uint32_t act[NB][16];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = lane * 8 + u * 512;
-            uint4 av = make_uint4(0, 0, 0, 0);
-            if (k < g.K0) av = *reinterpret_cast<const uint4*>(g.a0 + (int64_t)b * g.lda0 + k);
-            const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) act[b][u * 8 + j] = bf2f(ea[j]);
-        }
+    for (int b = 0; b < NB; ++b) load_act_pairs(g.a0 + (int64_t)b * g.lda0, lane * 8, g.K0, act[b]);
     while (n < g.N) {
         const int nn = n + stride;
         // epilogue operands of this column requested up front (they do not depend on the products): no dependent round trip at the tail
@@ -353,9 +335,10 @@ __global__ __launch_bounds__(1024) void greedy_seam_rows_kernel(const float* __r
 template <int NB>
 int launch_ln_gemvB(const LnGemvBArgs& g, hipStream_t s) {
     const int Ntot = g.N0 + g.N1;
-    if (NB <= 4) {  // register-resident activations: >= 2 rows per wave, at most 2 blocks per CU -- every wave is resident from the start
+    if (NB <= 4) {  // register-resident activations (16 NB packed registers per lane): up to 4 blocks per CU resident
         int blocks = (Ntot + 7) / 8;
-        if (blocks > 512) blocks = 512;
+        const int cap = showo::decode_tuning().batch_ln_blocks;
+        if (blocks > cap) blocks = cap;
         ln_gemvB_kernel<NB, (NB <= 4)><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
     } else {
         int blocks = (Ntot + 11) / 12;
@@ -390,7 +373,7 @@ int launch_out_gemvB(const OutGemvBArgs& g, hipStream_t s) {
     }
     if (smem > 160 * 1024) return set_error_msg(5, "batched decode: activations exceed the LDS");
     int blocks = (g.N + 7) / 8;
-    if (blocks > 256) blocks = 256;
+    if (blocks > showo::decode_tuning().out_blocks) blocks = showo::decode_tuning().out_blocks;
     kfn<<<dim3(blocks), dim3(512), smem, s>>>(g);
     return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "out_gemvB launch failed");
 }
@@ -407,7 +390,7 @@ int out_gemvB_c(const OutGemvBArgs& g, hipStream_t s) {
 }
 int out_dense_y2B(int nb, const OutGemvBArgs& g, hipStream_t s) {
     int blocks = (g.N + 7) / 8;
-    if (blocks > 256) blocks = 256;
+    if (blocks > showo::decode_tuning().out_blocks) blocks = showo::decode_tuning().out_blocks;
     switch (nb) {
         case 2: out_dense_y2B_kernel<2><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
         case 3: out_dense_y2B_kernel<3><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
@@ -538,15 +521,14 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
     SHOWO_CHECK_HIP(hipGetLastError());
     const int64_t per_seq = (int64_t)nH * d->cap * 64, lstride = (int64_t)nb * per_seq;
     // co-scheduled layer (fc2 streams next to the latency-bound attention blocks): Phi-1.5's shape, 2..4 sequences (the fc2 role
-    // keeps nb x 8192 fp32 activations in LDS); SHOWO_DECODE_BATCH_CO=0 / other shapes: three plain launches per layer
-    static int co_on = -1, co_blocks = 128;  // 128 role blocks + 32 nb attention blocks = one block per CU at nb = 4 (r5e sweep: 64 / 96 / 128 -> 1.64 / 1.53 / 1.49 ms per step)
+    // keeps nb x 8192 bf16 activations in LDS); SHOWO_DECODE_BATCH_CO=0 / other shapes: three plain launches per layer
+    static int co_on = -1;
     if (co_on < 0) {
         const char* env = getenv("SHOWO_DECODE_BATCH_CO");
         co_on = env ? (atoi(env) != 0) : 1;
-        const char* cb = getenv("SHOWO_DECODE_BATCH_CO_BLOCKS");
-        if (cb && atoi(cb) > 0) co_blocks = atoi(cb);
     }
-    const bool co = co_on && F == 8192 && H <= 2048 && nb >= 2 && nb <= 4 && (size_t)nb * F * 4 <= 128 * 1024;
+    const int co_blocks = showo::decode_tuning().batch_co_blocks;  // 128 role blocks + 32 nb attention blocks = one block per CU at nb = 4
+    const bool co = co_on && F == 8192 && H <= 2048 && nb >= 2 && nb <= 4 && (size_t)nb * F * 2 <= 128 * 1024;
     if (co && !d->y2) TRY(e->alloc(&d->y2, (int64_t)MAXB * H));
     auto one = [&]() -> int {
         for (int li = 0; li < e->nL; ++li) {

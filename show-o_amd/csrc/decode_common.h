@@ -11,18 +11,14 @@ static __device__ __forceinline__ void load4(const bf16_t* row, int k0, int K, u
         wv[u] = k < K ? ldg_nt16(row + k) : make_uint4(0, 0, 0, 0);
     }
 }
-// acc += sum over the 4 loaded 8-element groups, in gemv_kernel's order (u ascending, j ascending)
+// acc += sum over the 4 loaded 8-element groups, in gemv_kernel's order (u ascending, pairs ascending: dot8_bf16)
 template <class AP>
 static __device__ __forceinline__ float fma4(const uint4 (&wv)[4], AP act, int k0, int K, float acc) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * 512;
         if (k >= K) break;
-        const uint4 av = *reinterpret_cast<const uint4*>(act + k);
-        const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
-        const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf(bf2f(ea[j]), bf2f(ew[j]), acc);
+        acc = dot8_bf16(wv[u], *reinterpret_cast<const uint4*>(act + k), acc);
     }
     return acc;
 }
@@ -116,7 +112,7 @@ struct OutGemvBArgs {
 // wave_sum of up to four accumulators at once, each with wave_sum's own order of additions (partners 32, 16, 8, 4, 2, 1 away: the same
 // bits).  The 32 / 16 steps run on every accumulator with gfx950's row-swap instructions (VALU only); after them a lane holds, for
 // each b, the sum over its 4-lane group {l, l^16, l^32, l^48}, so lane group g = lane >> 4 continues with accumulator g alone: ONE
-// register takes the remaining four steps.  4 LDS-crossbar permutes per weight row instead of 6 per sequence.  Returns, in the lanes
+// register takes the remaining four steps (DPP: row_sum_dpp).  No LDS-crossbar permute at all (6 per sequence in wave_sum).  Returns, in the lanes
 // 16 b .. 16 b + 15, the wave-wide sum of acc[b] (b < NB <= 4).
 template <int NB>
 static __device__ __forceinline__ float wave_sum_groups(const float (&acc)[NB]) {
@@ -131,68 +127,52 @@ static __device__ __forceinline__ float wave_sum_groups(const float (&acc)[NB]) 
         const float w = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
         r = g == b ? w : r;
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
-    return r;
+    return row_sum_dpp(r);
 }
 
-// acc[b] += sum over the 4 loaded 8-element groups of w * act[b], in fma4's order (u ascending, j ascending) with the weight
-// converted ONCE for all NB sequences.  act: this lane's 32 activation values per sequence (registers).
+// acc[b] += sum over the 4 loaded 8-element groups of w * act[b], in fma4's order (u ascending, pairs ascending) per sequence.
+// act: this lane's 32 activation values per sequence as 16 packed bf16 pairs (registers).
 template <int NB>
-static __device__ __forceinline__ void fma4_regs(const uint4 (&wv)[4], const float (&act)[NB][32], int k0, int K, float (&acc)[NB]) {
+static __device__ __forceinline__ void fma4_regs(const uint4 (&wv)[4], const uint32_t (&act)[NB][16], int k0, int K, float (&acc)[NB]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (k0 + u * 512 >= K) break;
-        const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u]);
+        const uint32_t w[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float w = bf2f(ew[j]);
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = fmaf(act[b][u * 8 + j], w, acc[b]);
-        }
+            for (int b = 0; b < NB; ++b) acc[b] = dot2_bf16(w[p], act[b][u * 4 + p], acc[b]);
     }
 }
-// the same with the activations in LDS as fp32 (sa: row b at sa + b * ld): one conversion per weight element, none per activation
+// this lane's 16 pairs of one bf16 activation row (global or LDS), zero beyond K
+template <class AP>
+static __device__ __forceinline__ void load_act_pairs(AP row, int k0, int K, uint32_t (&act)[16]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * 512;
+        uint4 av = make_uint4(0, 0, 0, 0);
+        if (k < K) av = *reinterpret_cast<const uint4*>(row + k);
+        act[u * 4 + 0] = av.x; act[u * 4 + 1] = av.y; act[u * 4 + 2] = av.z; act[u * 4 + 3] = av.w;
+    }
+}
+// the same with the activations in LDS (sa: row b at sa + b * ld, bf16): one 16-byte read per 8 products per sequence
 template <int NB>
-static __device__ __forceinline__ void fma4_lds32(const uint4 (&wv)[4], const float* sa, int ld, int k0, int K, float (&acc)[NB]) {
+static __device__ __forceinline__ void fma4_lds(const uint4 (&wv)[4], const bf16_t* sa, int ld, int k0, int K, float (&acc)[NB]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * 512;
         if (k >= K) break;
-        const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u]);
-        float w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = bf2f(ew[j]);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {  // one sequence at a time: 8 activation registers live, the chain of acc[b] stays j-ascending
-            const float4 lo = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + k);
-            const float4 hi = *reinterpret_cast<const float4*>(sa + (size_t)b * ld + k + 4);
-            acc[b] = fmaf(lo.x, w[0], acc[b]); acc[b] = fmaf(lo.y, w[1], acc[b]); acc[b] = fmaf(lo.z, w[2], acc[b]); acc[b] = fmaf(lo.w, w[3], acc[b]);
-            acc[b] = fmaf(hi.x, w[4], acc[b]); acc[b] = fmaf(hi.y, w[5], acc[b]); acc[b] = fmaf(hi.z, w[6], acc[b]); acc[b] = fmaf(hi.w, w[7], acc[b]);
-        }
+        for (int b = 0; b < NB; ++b) acc[b] = dot8_bf16(wv[u], *reinterpret_cast<const uint4*>(sa + (size_t)b * ld + k), acc[b]);
     }
 }
 
 // fc2 role of the co-scheduled BATCHED decode launch (attention.hip, attn_decode_coB_kernel): y2[b][n] = W1[n, :] a1[b] + b1[n] for
 // the columns of role-block rb of nrb, nw waves per block.  fc2_columns_role's lane split and accumulation order per sequence (chunks
 // t ascending into ONE accumulator chain, then the wave reduction): the bits of the batch-1 launch.  The NB activation rows live in
-// LDS as fp32 (one conversion per weight element, none per activation).  sa: NB * K1 floats of LDS.
-// Measured alternatives (profiles/r5_decode_batch_sweep.txt): two weight rows per activation read (half the LDS traffic) needs more
-// than the 128 VGPRs a 1024-thread block has -- 44 spills, 32 us per launch instead of 21; a bank-swizzled image costs 17 spills.
-// fp32 image of the NB activation rows (all threads of the block; the caller synchronises)
-template <int NB>
-static __device__ __forceinline__ void fill_lds32(const OutGemvBArgs& g, int nw, float* sa) {
-    for (int b = 0; b < NB; ++b)
-        for (int i = threadIdx.x * 8; i < g.K1; i += nw * 64 * 8) {
-            const uint4 av = *reinterpret_cast<const uint4*>(g.a1 + (int64_t)b * g.lda1 + i);
-            const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
-            const int q = i >> 2;
-            *reinterpret_cast<float4*>(sa + (size_t)b * g.K1 + 4 * q) = make_float4(bf2f(ea[0]), bf2f(ea[1]), bf2f(ea[2]), bf2f(ea[3]));
-            *reinterpret_cast<float4*>(sa + (size_t)b * g.K1 + 4 * (q + 1)) = make_float4(bf2f(ea[4]), bf2f(ea[5]), bf2f(ea[6]), bf2f(ea[7]));
-        }
-}
+// LDS as bf16 (NB * K1 * 2 bytes: 64 KiB at NB = 4).
 template <int C, int NB>
-static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, int rb, int nrb, int nw, float* sa) {
+static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, int rb, int nrb, int nw, bf16_t* sa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int stride = nrb * nw;
     int n = wave * nrb + rb;
@@ -201,7 +181,9 @@ static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, 
 #pragma unroll
         for (int t = 0; t < C; ++t) load4(g.W1 + (int64_t)n * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
     }
-    fill_lds32<NB>(g, nw, sa);
+    for (int b = 0; b < NB; ++b)
+        for (int i = threadIdx.x * 8; i < g.K1; i += nw * 64 * 8)
+            *reinterpret_cast<uint4*>(sa + (size_t)b * g.K1 + i) = *reinterpret_cast<const uint4*>(g.a1 + (int64_t)b * g.lda1 + i);
     __syncthreads();
     while (n < g.N) {
         const int nn = n + stride;
@@ -210,7 +192,7 @@ static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, 
         for (int b = 0; b < NB; ++b) acc1[b] = 0.f;
 #pragma unroll
         for (int t = 0; t < C; ++t) {
-            fma4_lds32<NB>(buf[t], sa, g.K1, t * 2048 + lane * 8, g.K1, acc1);
+            fma4_lds<NB>(buf[t], sa, g.K1, t * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) load4(g.W1 + (int64_t)nn * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
         }
         const float tot = wave_sum_groups<NB>(acc1);

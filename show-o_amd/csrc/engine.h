@@ -48,6 +48,16 @@ int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const
 // next_mb: MB of the next launches' weights ([Wqkv ; W1] of layer li + 1, the lm_head after the last layer), dense: this layer's Wd
 // first, blocks: prefetch blocks per launch (0: off).  Defaults from SHOWO_DECODE_PF_MB / _DENSE / _BLOCKS; showo_decode_set_prefetch.
 void decode_prefetch_plan(const ::showo_engine* e, int li, DecodePrefetch* pf);
+// grid knobs of the decode launches: defaults <- environment (read once) <- showo_decode_set_tuning (sweeps in one process)
+struct DecodeTuning {
+    // defaults = the best of the one-process sweeps of profiles/r5_decode_dot2_sweep.txt (cfg4 shape, after the v_dot2c rewrite)
+    int co_blocks = 128;        // fc2 role blocks of the batch-1 attention launch (one column per wave) SHOWO_DECODE_CO_BLOCKS
+    int batch_co_blocks = 128;  // fc2 role blocks of the batched attention launch                       SHOWO_DECODE_BATCH_CO_BLOCKS
+    int batch_ln_blocks = 1024; // grid cap of ln_gemvB_kernel<NB <= 4> (register activations)           SHOWO_DECODE_BATCH_LN_BLOCKS
+    int ln_blocks = 1024;       // grid cap of ln_gemv2_kernel<2>                                        SHOWO_DECODE_LN_BLOCKS
+    int out_blocks = 256;       // grid cap of out_gemv2_kernel / out_gemvB / out_dense_y2B              SHOWO_DECODE_OUT_BLOCKS
+};
+DecodeTuning& decode_tuning();
 int greedy_token_seam(const float* logits, int n, int64_t* tok, int64_t* out_tokens, int* pos, int base, const float* table, float* x, int H,
                       int V, const int32_t* last_iv, int L0, int32_t* iv, hipStream_t s);
 int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t s);

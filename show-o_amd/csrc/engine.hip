@@ -406,6 +406,34 @@ extern "C" int showo_decode_set_prefetch(int next_mb, int dense, int blocks) {
     return 0;
 }
 namespace showo {
+DecodeTuning& decode_tuning() {
+    static DecodeTuning t;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        auto env = [](const char* name, int* v) { const char* e = getenv(name); if (e && atoi(e) > 0) *v = atoi(e); };
+        env("SHOWO_DECODE_CO_BLOCKS", &t.co_blocks);
+        env("SHOWO_DECODE_BATCH_CO_BLOCKS", &t.batch_co_blocks);
+        env("SHOWO_DECODE_BATCH_LN_BLOCKS", &t.batch_ln_blocks);
+        env("SHOWO_DECODE_LN_BLOCKS", &t.ln_blocks);
+        env("SHOWO_DECODE_OUT_BLOCKS", &t.out_blocks);
+    }
+    return t;
+}
+}  // namespace showo
+extern "C" int showo_decode_set_tuning(const char* name, int value) {
+    if (!name || value < 1 || value > 65535) return set_error_msg(1, "showo_decode_set_tuning: name and 1 <= value <= 65535");
+    showo::DecodeTuning& t = showo::decode_tuning();
+    const std::string n(name);
+    if (n == "co_blocks") t.co_blocks = value;
+    else if (n == "batch_co_blocks") t.batch_co_blocks = value;
+    else if (n == "batch_ln_blocks") t.batch_ln_blocks = value;
+    else if (n == "ln_blocks") t.ln_blocks = value;
+    else if (n == "out_blocks") t.out_blocks = value;
+    else return set_error_msg(1, "showo_decode_set_tuning: unknown knob");
+    return 0;
+}
+namespace showo {
 void decode_prefetch_plan(const ::showo_engine* e, int li, DecodePrefetch* pf) {
     decode_prefetch_env();
     *pf = DecodePrefetch{};
@@ -631,13 +659,12 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         //   LN + qkv GEMV + fc1 GEMV  ->  [ attention (32 blocks) || fc2 GEMV -> y2 (co_blocks) ]  ->  dense GEMV + both residual adds
         // Measured (gpurun_out/bench_mmu_r2p_*, one box, cfg4): chain 857-861 tokens/s; co-scheduled 922-928 with 224 fc2 blocks,
         // 965 with 128, 969 with 96 (fewer, fuller blocks leave the attention blocks' CUs alone) -> default, SHOWO_DECODE_FORK=0 is the chain.
-        static int fork_on = -1, co_blocks = 96;
+        static int fork_on = -1;
         if (fork_on < 0) {
             const char* env = getenv("SHOWO_DECODE_FORK");
             fork_on = env ? atoi(env) : 2;
-            const char* cb = getenv("SHOWO_DECODE_CO_BLOCKS");
-            if (cb && atoi(cb) > 0) co_blocks = atoi(cb);
         }
+        const int co_blocks = showo::decode_tuning().co_blocks;
         bool fork = fork_on == 1;
         const bool co = fork_on == 2 && F == 8192 && !g_decode_chain;
         if (co && !e->y2) TRY(e->alloc(&e->y2, H));

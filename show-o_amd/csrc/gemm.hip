@@ -505,13 +505,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
             for (int m = 0; m < MR; ++m) {
                 if (m >= g.M) break;
                 const uint4 av = *reinterpret_cast<const uint4*>(g.A + (int64_t)m * g.lda + k);
-                const bf16_t* ea = reinterpret_cast<const bf16_t*>(&av);
 #pragma unroll
-                for (int c = 0; c < GV_COLS; ++c) {
-                    const bf16_t* ew = reinterpret_cast<const bf16_t*>(&wv[u][c]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(bf2f(ea[j]), bf2f(ew[j]), acc[m][c]);
-                }
+                for (int c = 0; c < GV_COLS; ++c) acc[m][c] = dot8_bf16(wv[u][c], av, acc[m][c]);  // common.h: the decode GEMVs' order
             }
         }
     }

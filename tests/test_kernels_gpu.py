@@ -1112,3 +1112,24 @@ def test_grad_clip_norm_kernel_matches_torch_and_is_reproducible():
         else:
             assert torch.equal(runs[0][0], g0)
         assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_valu_only_wave_reductions_give_the_bits_of_the_butterfly_reductions():
+    """common.h: wave_sum_swap / wave_max_swap (v_permlane32/16_swap + DPP row rotations / quad permutes, no ds_bpermute) pair every
+    lane with the same partner VALUES in the same order as the __shfl_xor butterfly -> identical bits, in every lane."""
+    n = 4096
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 64, generator=g) * torch.logspace(-6, 6, n).reshape(n, 1)  # wide dynamic range: rounding differs by order
+    x[7, 13] = float("inf"); x[8, :] = -0.0; x[9, 3] = float("-inf")
+    xd = x.cuda().contiguous()
+    out = torch.full((n, 4), float("nan"), device="cuda")
+    L().call("showo_wave_reduce_probe", L().ptr(xd), L().ptr(out), n, S())
+    sync()
+    o = out.cpu()
+    assert torch.equal(o[:, 0].view(torch.int32), o[:, 1].view(torch.int32))
+    assert torch.equal(o[:, 2].view(torch.int32), o[:, 3].view(torch.int32))
+    assert torch.equal(o[:, 2], x.max(dim=1).values)
+    ref = x.double().sum(dim=1)
+    mag = x.double().abs().sum(dim=1)
+    fin = torch.isfinite(ref) & (mag > 0)
+    assert float(((o[:, 0].double() - ref)[fin].abs() / mag[fin]).max()) < 1e-6

@@ -1,6 +1,9 @@
-"""Sweep of the Infinity-Cache prefetch role of the decode layers (csrc/decode_common.h, prefetch_role) on the cfg4 shape, one process:
-   batch-1 (`mmu_generate`) and batch-4 (`mmu_generate_batch`) decode time per step for (next_mb, dense, blocks) settings.
-   usage: python tools/decode_prefetch_sweep.py [--new 100] [--reps 3]   (GPU)"""
+"""Sweep of the decode launches' knobs on the cfg4 shape in ONE process (the per-call hipGraph is re-captured, so a setter takes effect
+   at the next call): batch-1 (`mmu_generate`) and batch-4 (`mmu_generate_batch`) decode time per step.
+   A configuration = comma-separated assignments on top of the defaults: `pf=next_mb:dense:blocks` (Infinity-Cache prefetch role,
+   showo_decode_set_prefetch) and `knob=value` for showo_decode_set_tuning's knobs (co_blocks, batch_co_blocks, batch_ln_blocks,
+   ln_blocks, out_blocks).  Configurations are separated by ';'.
+   usage: python tools/decode_sweep.py [--new 100] [--reps 3] [--configs "pf=0:0:0;co_blocks=128;batch_ln_blocks=1024,batch_co_blocks=96"]   (GPU)"""
 import argparse
 import os
 import sys
@@ -15,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--new", type=int, default=100)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--settings", default="0:0:0,0:1:64,16:1:64,32:1:64,58:1:64,58:0:64,58:1:32,58:1:96,32:1:96")
+    ap.add_argument("--configs", default="pf=0:0:0")
     a = ap.parse_args()
     import showo_amd
     from showo_amd import synthetic
@@ -41,10 +44,19 @@ def main():
         return best, out
 
     ref1 = refB = None
-    print("# next_mb:dense:blocks | batch-1 ms/step tok/s | batch-4 ms/step agg tok/s (decode steps only)")
-    for st in a.settings.split(","):
-        mb, dn, bl = (int(v) for v in st.split(":"))
-        L.call("showo_decode_set_prefetch", mb, dn, bl)
+    DEFAULTS = {"co_blocks": 128, "batch_co_blocks": 128, "batch_ln_blocks": 1024, "ln_blocks": 1024, "out_blocks": 256}  # engine.h DecodeTuning
+    print("# configuration | batch-1 ms/step tok/s | batch-4 ms/step agg tok/s (decode steps only)")
+    for st in a.configs.split(";"):
+        knobs, pf = dict(DEFAULTS), (0, 0, 0)
+        for item in st.split(","):
+            k, v = item.split("=")
+            if k == "pf":
+                pf = tuple(int(t) for t in v.split(":"))
+            else:
+                knobs[k] = int(v)
+        L.call("showo_decode_set_prefetch", *pf)
+        for k, v in knobs.items():
+            L.call("showo_decode_set_tuning", k.encode(), v)
         f1, _ = t_call(lambda: model.mmu_generate(input_embeddings=embs[0], attention_mask=masks[0], max_new_tokens=1, top_k=1))
         t1, o1 = t_call(lambda: model.mmu_generate(input_embeddings=embs[0], attention_mask=masks[0], max_new_tokens=a.new, top_k=1))
         fB, _ = t_call(lambda: model.mmu_generate_batch(input_embeddings=embs, attention_mask=masks, max_new_tokens=1, top_k=1))
@@ -56,7 +68,7 @@ def main():
         same = (o1 == ref1) and (oB == refB)
         s1 = (t1 - f1) / (a.new - 1)
         sB = (tB - fB) / (a.new - 1)
-        print(f"{mb:3d}:{dn}:{bl:3d} | {s1 * 1e3:.4f} {1 / s1:7.1f} | {sB * 1e3:.4f} {NB / sB:7.1f} | tokens_equal={same}", flush=True)
+        print(f"{st:44s} | {s1 * 1e3:.4f} {1 / s1:7.1f} | {sB * 1e3:.4f} {NB / sB:7.1f} | tokens_equal={same}", flush=True)
 
 
 if __name__ == "__main__":
