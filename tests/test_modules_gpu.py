@@ -621,6 +621,17 @@ def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
             assert [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=embs, attention_mask=ams, max_new_tokens=24, top_k=1)] == single
         finally:
             L.call("showo_decode_set_prefetch", 0, 0, 0)
+    # ... and the grid knobs only move columns between waves (each column is reduced by ONE wave in ONE fixed order): same tokens
+    defaults = {"co_blocks": 128, "batch_co_blocks": 128, "batch_ln_blocks": 1024, "ln_blocks": 1024, "out_blocks": 256}
+    try:
+        for knobs in ({"co_blocks": 37, "ln_blocks": 100, "out_blocks": 17}, {"batch_co_blocks": 61, "batch_ln_blocks": 333, "out_blocks": 512}):
+            for k, v in knobs.items():
+                L.call("showo_decode_set_tuning", k.encode(), v)
+            assert [int(t) for t in m.mmu_generate(input_embeddings=embs[1], attention_mask=ams[1], max_new_tokens=24, top_k=1)] == single[1]
+            assert [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=embs, attention_mask=ams, max_new_tokens=24, top_k=1)] == single
+    finally:
+        for k, v in defaults.items():
+            L.call("showo_decode_set_tuning", k.encode(), v)
     # ---- accuracy mode (projector + transformer): 1e-3 against the fp32 reference, tokens identical
     m.set_precision(1)
     imgp, embp = splice()
