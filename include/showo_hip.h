@@ -127,6 +127,10 @@ int showo_conv3x3_bf16x3(const uint16_t* x, const uint16_t* xlo, const uint16_t*
 int showo_conv3x3_bf16x3_gn(const uint16_t* x, const uint16_t* xlo, const uint16_t* w, const uint16_t* wlo, const float* bias,
                             const float* resid, float* out, double* stats, int B, int Hin, int Win, int Cin, int Cout, int mode,
                             void* stream);
+/* Launches so far of the split conv kernel that stages the activation operand once per (ky, channel chunk) for all three kx taps
+ * (gemm.hip conv3t_split_kernel: modes 0 / 1, Wout a multiple of 16 that divides or is a multiple of 256, Hout * Wout % 256 == 0, launches
+ * that do not split K; SHOWO_CONV_3TAP=0 turns it off).  Tests assert their coverage with it. */
+int64_t showo_conv3t_launches(void);
 /* fp32 -> (hi, lo) bf16 pair */
 int showo_split_f32_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, void* stream);
 

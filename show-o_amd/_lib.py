@@ -175,7 +175,7 @@ _PROTOS = {
     "showo_prof_set_stride": [c_i],
     "showo_prof_totals": [c_i, c_p, c_p],
 }
-_I64 = {"showo_gemm_tiled_elems": [c_i, c_i]}
+_I64 = {"showo_gemm_tiled_elems": [c_i, c_i], "showo_conv3t_launches": []}
 _VOID = {"showo_engine_destroy": [c_p], "showo_vq_destroy": [c_p], "showo_train_destroy": [c_p], "showo_clip_destroy": [c_p], "showo_projector_destroy": [c_p]}
 EXPORTED_SYMBOLS = sorted(list(_PROTOS) + list(_VOID) + list(_I64) + ["showo_last_error"])
 

@@ -887,6 +887,74 @@ static __device__ __forceinline__ bool conv_splitk_exchange(const GemmArgs& g, f
     return true;
 }
 
+// Epilogue shared by the split-precision conv kernels: fp32 stores of the wave's 64 (cout) x 64 (pixel) tile (acc[i][j]: couts
+// n0 + wn * 64 + i * 16 + fg * 4 .. + 3, pixel m0 + arow0 + j * 16 + fr), optionally with the GroupNorm(32) statistics of what was stored.
+template <int EPI>
+static __device__ __forceinline__ void conv_split_epilogue(const GemmArgs& g, const ConvArgs& c, f32x4 (&acc)[4][4], unsigned char* smem_raw,
+                                                           int m0, int n0, int tm, int arow0, int wn, int wave, int fr, int fg, int tid) {
+    if (c.gn_part == nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn);
+        }
+    } else {
+        // Same stores, plus the GroupNorm statistics of what was stored (the next op of the VQGAN block is GroupNorm(32) of this
+        // tensor: showo_gn_stats would read it back from HBM).  A lane's 4 columns belong to ONE group (Cout / 32 is a multiple of 4);
+        // sums are carried in double and combined in a fixed order (lane butterfly -> wave slots in LDS -> quads -> groups): the
+        // partial of a tile has the same bits on every run, like gn_partial_kernel's.
+        double gs[4], gq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
+            gs[i] = 0.0; gq[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+                if (store_frag_vals<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn, v)) {
+                    gs[i] += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+                    gq[i] += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {  // the 16 lanes fr = 0..15 hold the tile rows of the same 4 columns
+                gs[i] += __shfl_xor(gs[i], o, 64);
+                gq[i] += __shfl_xor(gq[i], o, 64);
+            }
+        double* sred = reinterpret_cast<double*>(smem_raw);  // [8 waves][16 quads][2]; every LDS read of the main loop has retired
+        __syncthreads();
+        if (fr == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sred[(wave * 16 + i * 4 + fg) * 2 + 0] = gs[i];
+                sred[(wave * 16 + i * 4 + fg) * 2 + 1] = gq[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int q = tid >> 1, which = tid & 1;  // q: column quad of the block (columns n0 + 4 q ..)
+            const int wq = q >> 4, ql = q & 15;
+            double a = 0.0;
+#pragma unroll
+            for (int pw = 0; pw < 4; ++pw) a += sred[((((pw >> 1) * 4 + (pw & 1) * 2 + wq) * 16) + ql) * 2 + which];
+            const int qpg = c.gn_cpg >> 2;  // quads per group: 1, 2, 4 or 8
+            if (qpg >= 2) a += __shfl_down(a, 2, 64);
+            if (qpg >= 4) a += __shfl_down(a, 4, 64);
+            if (qpg >= 8) a += __shfl_down(a, 8, 64);
+            const int ncol = n0 + 4 * q;
+            if ((q % qpg) == 0 && ncol < g.N) c.gn_part[((int64_t)tm * 32 + ncol / c.gn_cpg) * 2 + which] = a;
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1075,67 +1143,7 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
         if (!conv_splitk_exchange(g, acc, tn * tilesM + tm, split, &s_last)) return;
     }
 
-    if (c.gn_part == nullptr) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fg * 4;
-            float bn[4];
-            load_bias4(g, n, bn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn);
-        }
-    } else {
-        // Same stores, plus the GroupNorm statistics of what was stored (the next op of the VQGAN block is GroupNorm(32) of this
-        // tensor: showo_gn_stats would read it back from HBM).  A lane's 4 columns belong to ONE group (Cout / 32 is a multiple of 4);
-        // sums are carried in double and combined in a fixed order (lane butterfly -> wave slots in LDS -> quads -> groups): the
-        // partial of a tile has the same bits on every run, like gn_partial_kernel's.
-        double gs[4], gq[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fg * 4;
-            float bn[4];
-            load_bias4(g, n, bn);
-            gs[i] = 0.0; gq[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
-                if (store_frag_vals<EPI>(g, acc[i][j], m0 + arow0 + j * 16 + fr, n, bn, v)) {
-                    gs[i] += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
-                    gq[i] += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {  // the 16 lanes fr = 0..15 hold the tile rows of the same 4 columns
-                gs[i] += __shfl_xor(gs[i], o, 64);
-                gq[i] += __shfl_xor(gq[i], o, 64);
-            }
-        double* sred = reinterpret_cast<double*>(smem_raw);  // [8 waves][16 quads][2]; every LDS read of the main loop has retired
-        __syncthreads();
-        if (fr == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sred[(wave * 16 + i * 4 + fg) * 2 + 0] = gs[i];
-                sred[(wave * 16 + i * 4 + fg) * 2 + 1] = gq[i];
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int q = tid >> 1, which = tid & 1;  // q: column quad of the block (columns n0 + 4 q ..)
-            const int wq = q >> 4, ql = q & 15;
-            double a = 0.0;
-#pragma unroll
-            for (int pw = 0; pw < 4; ++pw) a += sred[((((pw >> 1) * 4 + (pw & 1) * 2 + wq) * 16) + ql) * 2 + which];
-            const int qpg = c.gn_cpg >> 2;  // quads per group: 1, 2, 4 or 8
-            if (qpg >= 2) a += __shfl_down(a, 2, 64);
-            if (qpg >= 4) a += __shfl_down(a, 4, 64);
-            if (qpg >= 8) a += __shfl_down(a, 8, 64);
-            const int ncol = n0 + 4 * q;
-            if ((q % qpg) == 0 && ncol < g.N) c.gn_part[((int64_t)tm * 32 + ncol / c.gn_cpg) * 2 + which] = a;
-        }
-    }
+    conv_split_epilogue<EPI>(g, c, acc, smem_raw, m0, n0, tm, arow0, wn, wave, fr, fg, tid);
 #undef CS_TILE
 #undef CS_TAP
 #undef CS_MFMA
@@ -1143,6 +1151,224 @@ __global__ __launch_bounds__(512) void conv2p_split_kernel(GemmArgs g, ConvArgs 
 #undef CS_READ_W
 #undef CS_DMA_A
 #undef CS_DMA_W
+}
+
+// =====================================================================================================
+// Split-precision 3x3 convolution with the activation operand staged ONCE per (ky, channel chunk) for all three kx taps.
+// conv2p_split_kernel folds the tap into the DMA source address, so the nine taps of a pixel are nine DMA reads of the same L2 lines:
+// 48 KiB through LDS-DMA per k-tile for 6.3 MFLOP = 75 GB/s per CU to keep the MFMAs fed, against the ~30 GB/s a CU lands:
+// the kernel sat at 39 % MFMA busy on the operand fetch.  Here a 256-pixel tile = R image rows x TW columns (TW = min(Wout, 256),
+// R = 256 / TW); a stage holds, per tile row, the TW + 2 input entries of ONE ky (columns c0 - 1 .. c0 + TW, zero outside the image)
+// x 32 channels: NE = 256 + 2 R entries of 64 B (hi and lo image).  The k-tile of tap (ky, kx) reads its pixel rows from that stage
+// at entry r (TW + 2) + x + kx -- a shifted view, no second fetch: A bytes per k-tile 32 KiB -> (256 + 2 R) / 768 of that (12 KiB),
+// W unchanged (16 KiB): 28 instead of 48 KiB per k-tile.  k order: (ky, channel chunk, kx); weights are addressed by k0 = (3 ky + kx)
+// Cin + cb as before.  modes 0 (stride 1, pad 1) and 1 (nearest 2x upsample + pad 1: the entry's source is (uy >> 1, ux >> 1));
+// the stride-2 form and split-K launches stay on conv2p_split_kernel.  Same wave tiling, fragment layout, swizzle (a function of the
+// PHYSICAL LDS row, so 16 consecutive rows from any start are conflict-free) and epilogue as conv2p_split_kernel.
+// Schedule: one barrier per k-tile; the DMA of the next k-tile's weights (and, at kx = 0, of the next stage) is issued before the
+// fragment reads + 48 MFMAs of the current one and waited for at the barrier.
+// =====================================================================================================
+constexpr int C3_NE_MAX = 288;                                   // 256 + 2 R, R <= 16
+constexpr int C3_A_IMG = C3_NE_MAX * CS_BK;                      // elements of one A image of a stage
+constexpr int C3_W_BUF = 2 * CS_WROWS * CS_BK;                   // Wh | Wl of one k-tile
+constexpr int C3_A_BUF = 2 * C3_A_IMG;                           // Ah | Al of one stage
+constexpr int C3_O_A = 3 * C3_W_BUF;                             // A buffers behind the three W buffers
+constexpr int C3_SMEM = (3 * C3_W_BUF + 2 * C3_A_BUF) * 2;       // 122 880 B
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in {0, 2, 4, 6, 8} (the immediate must be a constant)
+static __device__ __forceinline__ void c3_wait_vm(int n) {
+    if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void conv3t_split_kernel(GemmArgs g, ConvArgs c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tilesM = g.M / CS_AROWS, tilesN = (g.N + CS_WROWS - 1) / CS_WROWS;
+    int nwg = tilesM * tilesN, bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = bid / tilesM, tm = bid - tn * tilesM;
+    const int m0 = tm * CS_AROWS, n0 = tn * CS_WROWS;
+    const int grp = wave >> 2, wn = wave & 1, wmg = (wave >> 1) & 1;
+    const int arow0 = grp * 128 + wmg * 64;
+
+    // ---- tile geometry
+    const int hw = c.Hout * c.Wout;
+    const int TW = c.Wout < 256 ? c.Wout : 256, TW2 = TW + 2;
+    const int R = 256 / TW, NE = R * TW2, NP = (NE + 15) >> 4;
+    const int bimg = m0 / hw, p0 = m0 - bimg * hw;
+    const int oy0 = p0 / c.Wout, c0 = p0 - oy0 * c.Wout;
+    const bf16_t* img = c.X + (int64_t)bimg * c.Hin * c.Win * c.Cin;
+    const int64_t xlo_delta = c.Xlo - c.X;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+    // ---- DMA roles (piece = 16 entries x 64 B; lane -> entry lane >> 2, physical chunk lane & 3 = logical chunk ^ f(entry >> 2))
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((0 - (prow >> 2)) & 3);
+    const int koff = lchunk * 8;
+    uint32_t woffb;
+    {
+        int n = n0 + wave * 16 + prow;
+        n = n < g.N ? n : g.N - 1;
+        woffb = (uint32_t)(((int64_t)n * g.ldw + koff) * 2);
+    }
+    const char* whb = reinterpret_cast<const char*>(g.W);
+    const char* wlb = reinterpret_cast<const char*>(g.Wlo);
+    // this lane's entries: pieces wave, wave + 8, wave + 16 (< NP).  colofs = element offset of the entry's source column + chunk
+    // (-1: outside the image), uyb = its (upsampled) source row for ky = 0
+    int colofs[3], uyb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = (wave + 8 * i) * 16 + prow;
+        const int r = e / TW2, xe = e - r * TW2;
+        const int ux = c0 + xe - 1;
+        const bool ok = e < NE && ux >= 0 && ux < c.Wout;
+        colofs[i] = ok ? (c.mode == 1 ? (ux >> 1) : ux) * c.Cin + koff : -1;
+        uyb[i] = oy0 + r - 1;
+    }
+    const uint32_t lds0 = lds_addr_of(smem);
+    auto dma_w = [&](int wb, int k0) {
+        const uint32_t d = lds0 + (uint32_t)(wb * C3_W_BUF + wave * 16 * CS_BK) * 2;
+        glds16_untracked(reinterpret_cast<const bf16_t*>(whb + (size_t)k0 * 2 + (size_t)woffb), d);
+        glds16_untracked(reinterpret_cast<const bf16_t*>(wlb + (size_t)k0 * 2 + (size_t)woffb), d + CS_WROWS * CS_BK * 2);
+    };
+    // piece slot i of this wave (i = 2 exists for the first NP - 16 waves only: has2) of stage (ky, cb) -> A buffer ab: two DMA instructions
+    const bool has2 = wave + 16 < NP;
+    auto dma_a = [&](int i, int ab, int ky, int cb) {
+        const int uy = uyb[i] + ky;
+        const bool ok = colofs[i] >= 0 && uy >= 0 && uy < c.Hout;
+        const int iy = c.mode == 1 ? (uy >> 1) : uy;
+        const bf16_t* p = img + (int64_t)iy * c.Win * c.Cin + colofs[i] + cb;
+        const uint32_t d = lds0 + (uint32_t)(C3_O_A + ab * C3_A_BUF + (wave + 8 * i) * 16 * CS_BK) * 2;
+        glds16_untracked(ok ? p : zero, d);
+        glds16_untracked(ok ? p + xlo_delta : zero, d + C3_A_IMG * 2);
+    };
+
+    // ---- fragment read offsets (elements): lane -> row lane & 15, logical chunk lane >> 4; the swizzle follows the physical row
+    const int fr = lane & 15, fg = lane >> 4;
+    const int lsw = fr * CS_BK + ((fg ^ ((0 - (fr >> 2)) & 3)) << 3);
+    const bf16_t* ldsW = smem + (wn * 64) * CS_BK + lsw;
+    int aoff[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = arow0 + j * 16;
+        const int r = p / TW, x = p - r * TW;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int row = r * TW2 + x + kx + fr;
+            aoff[j][kx] = C3_O_A + row * CS_BK + ((fg ^ ((0 - (row >> 2)) & 3)) << 3);
+        }
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // k-tile t = 3 s + kx of stage s = (ky, channel chunk).  DMA issued during k-tile t, in this order: W(t + 2) [2 instructions], then the
+    // A pieces of stage s + 1 assigned to this kx (slots 0 and 2 at kx = 0, slot 1 at kx = 1, none at kx = 2) [2 each].  vmcnt counts in
+    // order, so at the end of k-tile t the wave waits until only the instructions YOUNGER than what k-tile t + 1 needs are in flight:
+    //   kx = 0: W(t + 1) is the head of the previous list  -> may stay in flight: W(t + 2) + this tile's A pieces        = 2 + 2 a0
+    //   kx = 1: W(t + 1) heads the list of kx = 0          -> its A pieces (2 a0) + W(t + 2) + slot 1                  = 2 a0 + 4
+    //   kx = 2: the next stage must be complete             -> W(t + 2) only                                             = 2
+    // (a0 = 1 + has2).  Weights have two k-tiles to land, activations one to two.  The last stage (no prefetch left) waits for everything.
+    const int cchunks = c.Cin / CS_BK, nstages = 3 * cchunks, nk = 3 * nstages;
+    const int a0 = has2 ? 2 : 1;
+    dma_w(0, 0);
+    dma_w(1, c.Cin);  // tap (0, 1), channel chunk 0
+    dma_a(0, 0, 0, 0);
+    dma_a(1, 0, 0, 0);
+    if (has2) dma_a(2, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar_raw_fn();
+    // Two phases per k-tile -- [DMA issue + fragment reads + the counted wait] | barrier | [48 MFMAs] | barrier -- with wave group 1
+    // (waves 4-7: the SIMD partners of waves 0-3) running ONE barrier behind group 0, so that on every SIMD one wave multiplies while the
+    // other reads its fragments (conv2p_split_kernel's arrangement).  A wave's reads have returned (lgkmcnt(0)) and its DMA of what the
+    // next k-tile needs has landed before it passes the mid barrier, i.e. one full phase before any wave touches that data / that buffer.
+    if (grp == 1) bar_raw_fn();
+    int ky = 0, cbi = 0;  // stage s = ky * cchunks + cbi
+    int wb = 0;           // W buffer of k-tile t: t % 3
+    for (int s = 0; s < nstages; ++s) {
+        const int cb = cbi * CS_BK;
+        int nky = ky, ncbi = cbi + 1;
+        if (ncbi == cchunks) { ncbi = 0; ++nky; }
+        const bool more = s + 1 < nstages;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int t = s * 3 + kx;
+            const int wb2 = wb == 0 ? 2 : wb - 1;  // (t + 2) % 3
+            if (t + 2 < nk) {
+                // k-tile t + 2: tap (ky, 2) of this stage at kx = 0, taps (nky, 0) / (nky, 1) of the next stage at kx = 1 / 2
+                const int k2 = kx == 0 ? (ky * 3 + 2) * c.Cin + cb : (nky * 3 + (kx - 1)) * c.Cin + ncbi * CS_BK;
+                dma_w(wb2, k2);
+            }
+            if (more) {
+                if (kx == 0) { dma_a(0, (s + 1) & 1, nky, ncbi * CS_BK); if (has2) dma_a(2, (s + 1) & 1, nky, ncbi * CS_BK); }
+                if (kx == 1) dma_a(1, (s + 1) & 1, nky, ncbi * CS_BK);
+            }
+            const bf16_t* wbase = ldsW + wb * C3_W_BUF;
+            const bf16_t* abase = smem + (s & 1) * C3_A_BUF;
+            bf16x8 wh[4], wl[4], ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wh[i] = *reinterpret_cast<const bf16x8*>(wbase + i * 16 * CS_BK);
+                wl[i] = *reinterpret_cast<const bf16x8*>(wbase + CS_WROWS * CS_BK + i * 16 * CS_BK);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ah[j] = *reinterpret_cast<const bf16x8*>(abase + aoff[j][kx]);
+                al[j] = *reinterpret_cast<const bf16x8*>(abase + C3_A_IMG + aoff[j][kx]);
+            }
+            if (!more) c3_wait_vm(0);
+            else if (kx == 0) c3_wait_vm(2 + 2 * a0);
+            else if (kx == 1) c3_wait_vm(2 * a0 + 4);
+            else c3_wait_vm(2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar_raw_fn();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], ah[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], al[j], acc[i][j], 0, 0, 0);
+            if (c.products == 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], ah[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            bar_raw_fn();
+            wb = wb == 2 ? 0 : wb + 1;
+        }
+        ky = nky; cbi = ncbi;
+    }
+    if (grp == 0) bar_raw_fn();
+    conv_split_epilogue<EPI>(g, c, acc, smem_raw, m0, n0, tm, arow0, wn, wave, fr, fg, tid);
+}
+
+static long g_conv3t_launches = 0;  // tests assert that their shapes reached this kernel (showo_conv3t_launches)
+// shapes the 3-tap-reuse kernel serves (everything else: conv2p_split_kernel)
+static bool conv3t_ok(const GemmArgs& g, const ConvArgs& c) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SHOWO_CONV_3TAP"); on = e ? atoi(e) : 1; }
+    if (!on || c.mode == 2) return false;
+    const int hw = c.Hout * c.Wout;
+    if ((hw % CS_AROWS) || (c.Wout % 16) || (c.Cin % CS_BK)) return false;
+    if (c.Wout <= 256 ? (256 % c.Wout) != 0 : (c.Wout % 256) != 0) return false;
+    return (g.M % CS_AROWS) == 0;
 }
 
 template <int EPI>
@@ -1174,6 +1400,20 @@ int launch_conv2p_split(const GemmArgs& g, const ConvArgs& c, hipStream_t s) {
         if (S >= 2 && tiles * S <= gemm_splitk_ticks() &&
             gemm_splitk_ws(s, (size_t)tiles * S * 16 * 512 * sizeof(float4), &gs.ws, &gs.tick))
             gs.splits = S;  // (no workspace -- first use inside a stream capture: the unsplit launch is always valid)
+    }
+    if (gs.splits == 1 && conv3t_ok(g, c)) {
+        static bool attr3_set = false;
+        auto k3 = conv3t_split_kernel<EPI>;
+        if (!attr3_set) {
+            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, C3_SMEM);
+            if (e3 != hipSuccess) return set_error_hip(e3, "hipFuncSetAttribute(conv3t_split)", __FILE__, __LINE__);
+            attr3_set = true;
+        }
+        ++g_conv3t_launches;
+        k3<<<dim3(tiles), dim3(512), C3_SMEM, s>>>(gs, c);
+        hipError_t e3 = hipGetLastError();
+        if (e3 != hipSuccess) return set_error_hip(e3, "conv3t_split launch", __FILE__, __LINE__);
+        return 0;
     }
     kfn<<<dim3(tiles * gs.splits), dim3(512), CS_SMEM, s>>>(gs, c);
     hipError_t e = hipGetLastError();
@@ -1271,3 +1511,6 @@ extern "C" int showo_conv3x3_bf16x3_gn(const uint16_t* x, const uint16_t* xlo, c
     if (Cout % 128) return set_error_msg(1, "conv3x3 x3 gn: Cout must be a multiple of 128 (GroupNorm(32) over channel quads)");
     return conv3x3_x3_impl(x, xlo, w, wlo, bias, resid, out, stats, B, Hin, Win, Cin, Cout, mode, stream);
 }
+
+// number of launches of the 3-tap-reuse conv kernel (conv3t_split_kernel) so far in this process: tests check their coverage with it
+extern "C" int64_t showo_conv3t_launches(void) { return (int64_t)g_conv3t_launches; }

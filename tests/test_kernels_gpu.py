@@ -1133,3 +1133,50 @@ def test_valu_only_wave_reductions_give_the_bits_of_the_butterfly_reductions():
     mag = x.double().abs().sum(dim=1)
     fin = torch.isfinite(ref) & (mag > 0)
     assert float(((o[:, 0].double() - ref)[fin].abs() / mag[fin]).max()) < 1e-6
+
+
+def test_split_conv_three_tap_reuse_kernel_tracks_fp64_and_gn_statistics():
+    """gemm.hip conv3t_split_kernel (the activation operand staged once per (ky, channel chunk) for all three kx taps; launches that do
+    not split K): every tile geometry -- R image rows x TW columns per 256-pixel tile for Wout = 16 ... 512 -- in modes 0 and 1, with and
+    without residual, against an fp64 convolution of the original fp32 operands (3e-5 of the output scale, the split kernels' bound),
+    plus the epilogue-fused GroupNorm statistics against showo_gn_stats of the stored output.  The launch counter proves coverage."""
+    import torch.nn.functional as F
+    torch.manual_seed(21)
+    lib = L().load()
+    cases = [(3, 128, 128, 64, 128, 0, True), (5, 64, 64, 128, 256, 0, False), (1, 128, 512, 64, 128, 0, True), (1, 256, 256, 64, 128, 0, False),
+             (160, 16, 16, 64, 128, 0, True), (40, 32, 32, 64, 128, 0, False), (3, 64, 64, 64, 128, 1, False), (40, 16, 16, 64, 128, 1, False),
+             (1, 64, 256, 128, 128, 1, False)]
+    for (B, H, Wd, Cin, Cout, mode, with_res) in cases:
+        Ho, Wo = (H, Wd) if mode == 0 else (2 * H, 2 * Wd)
+        x = torch.randn(B, H, Wd, Cin) + 0.2
+        wgt = torch.randn(Cout, 3, 3, Cin) * 0.03
+        bias = torch.randn(Cout)
+        res = torch.randn(B, Ho * Wo, Cout) if with_res else None
+        xh, xl = _split(x)
+        wh, wl = _split(wgt)
+        out = torch.full((B, Ho * Wo, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        out1 = torch.full_like(out, float("nan"))
+        nd = lib.showo_gn_stats_doubles(B, Ho * Wo)
+        st1 = torch.full((nd,), float("nan"), dtype=torch.float64, device="cuda")
+        st0 = torch.zeros_like(st1)
+        rp = None if res is None else L().ptr(dev(res))
+        n0 = lib.showo_conv3t_launches()
+        L().call("showo_conv3x3_bf16x3", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), rp, L().ptr(out),
+                 B, H, Wd, Cin, Cout, mode, S())
+        L().call("showo_conv3x3_bf16x3_gn", L().ptr(xh), L().ptr(xl), L().ptr(wh), L().ptr(wl), L().ptr(dev(bias)), rp, L().ptr(out1),
+                 L().ptr(st1), B, H, Wd, Cin, Cout, mode, S())
+        sync()
+        assert lib.showo_conv3t_launches() == n0 + 2, (B, H, Wd, Cin, Cout, mode, "the case must reach the 3-tap-reuse kernel")
+        xd = x.permute(0, 3, 1, 2).double()
+        wd_ = wgt.permute(0, 3, 1, 2).double()
+        if mode == 1:
+            xd = xd.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        ref = F.conv2d(xd, wd_, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)  # CPU, fp64
+        if res is not None:
+            ref = ref + res.double()
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < 3e-5, (B, H, Wd, Cin, Cout, mode, err)
+        assert torch.equal(out, out1)
+        L().call("showo_gn_stats", L().ptr(out), L().ptr(st0), B, Ho * Wo, Cout, S())
+        a, b = st1[:B * 64].cpu(), st0[:B * 64].cpu()
+        assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=1e-12, atol=1e-9), (B, H, Wd, Cin, Cout, mode, float((a - b).abs().max()))
