@@ -386,7 +386,7 @@ static int collect_x(showo_engine* e, int slot, int T, hipStream_t s) {
 }
 
 // ---- Infinity-Cache prefetch plan of the decode layers (decode_common.h, prefetch_role) -------------------------------------------
-static int g_pf_mb = -1, g_pf_dense = 1, g_pf_blocks = 64;
+static int g_pf_mb = -1, g_pf_dense = 0, g_pf_blocks = 64;  // off by default (measured negative: profiles/r5_decode_dot2_sweep.txt)
 static void decode_prefetch_env() {
     if (g_pf_mb >= 0) return;
     const char* m = getenv("SHOWO_DECODE_PF_MB");

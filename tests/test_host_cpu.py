@@ -337,6 +337,21 @@ def test_ctypes_prototypes_match_header_argument_counts_and_kinds():
     assert checked > 95
 
 
+def test_decode_knob_setters_validate_their_arguments_without_a_gpu():
+    """showo_decode_set_tuning / showo_decode_set_prefetch are host-side state (they select grids of later launches): valid knobs are
+    accepted, unknown names and out-of-range values are refused with an error code and a message -- no GPU needed, nothing launched"""
+    L = util.lib()
+    lib = L.load()
+    for name, value in (("co_blocks", 128), ("batch_co_blocks", 128), ("batch_ln_blocks", 1024), ("ln_blocks", 1024), ("out_blocks", 256)):
+        assert lib.showo_decode_set_tuning(name.encode(), value) == 0  # (these are the defaults: state unchanged)
+    assert lib.showo_decode_set_tuning(b"no_such_knob", 8) != 0 and b"unknown knob" in lib.showo_last_error()
+    assert lib.showo_decode_set_tuning(b"co_blocks", 0) != 0
+    assert lib.showo_decode_set_tuning(None, 8) != 0
+    assert lib.showo_decode_set_prefetch(-1, 0, 0) != 0 and lib.showo_decode_set_prefetch(0, 0, 5000) != 0
+    assert lib.showo_decode_set_prefetch(0, 0, 0) == 0
+    assert lib.showo_conv3t_launches() == 0  # no convolution was launched in this process
+
+
 def test_alias_package_shares_module_objects():
     """`showo_amd.x` and `show-o_amd.x` are the same module objects (one instance of every class, so isinstance checks hold no
     matter which spelling user code imports from)"""
