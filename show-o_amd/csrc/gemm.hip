@@ -16,6 +16,7 @@
 //   Block ids are remapped so that the blocks resident on one XCD (id % 8) walk the same weight panel.
 #include "gemm_common.h"
 #include "prof.h"
+#include <atomic>
 #include <cstdlib>
 
 using namespace showo;
@@ -1359,7 +1360,7 @@ __global__ __launch_bounds__(512) void conv3t_split_kernel(GemmArgs g, ConvArgs 
     conv_split_epilogue<EPI>(g, c, acc, smem_raw, m0, n0, tm, arow0, wn, wave, fr, fg, tid);
 }
 
-static long g_conv3t_launches = 0;  // tests assert that their shapes reached this kernel (showo_conv3t_launches)
+static std::atomic<long> g_conv3t_launches{0};  // tests assert that their shapes reached this kernel (showo_conv3t_launches)
 // shapes the 3-tap-reuse kernel serves (everything else: conv2p_split_kernel)
 static bool conv3t_ok(const GemmArgs& g, const ConvArgs& c) {
     static int on = -1;
@@ -1513,4 +1514,4 @@ extern "C" int showo_conv3x3_bf16x3_gn(const uint16_t* x, const uint16_t* xlo, c
 }
 
 // number of launches of the 3-tap-reuse conv kernel (conv3t_split_kernel) so far in this process: tests check their coverage with it
-extern "C" int64_t showo_conv3t_launches(void) { return (int64_t)g_conv3t_launches; }
+extern "C" int64_t showo_conv3t_launches(void) { return (int64_t)g_conv3t_launches.load(); }
