@@ -264,7 +264,7 @@ def self_launch(gpus, script):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def train_leg(world, rank, steps=4, warmup=2, timeout_s=420):
+def train_leg(world, rank, steps=8, warmup=2, timeout_s=420):
     """run `bench_train.py --gpus world` as a child of this rank and return (rank 0) the fields of its JSON line that matter here"""
     import subprocess
     env = dict(os.environ)
