@@ -71,6 +71,16 @@ int showo_lfq_unpack_nchw(const int64_t* ids, float* zq, int B, int C, int hw, v
 int showo_layernorm_f32_bf16(const float* x, const float* w, const float* b, uint16_t* y, const int32_t* row_index,
                              int rows, int H, float eps, void* stream);
 
+/* 16-bit OPERAND TYPE of the `_op16` entry points (round 6): every `uint16_t*` operand, weight image and 16-bit output of such a call
+ * holds raw bits of this type.  SHOWO_OP_BF16 = bfloat16 (what the `_bf16` entry points use; they are the op = SHOWO_OP_BF16 case of
+ * their `_op16` twin).  SHOWO_OP_F16 = IEEE binary16: the same MFMA / dot2 rate with 11 significand bits instead of 8 -- the operands
+ * of showo_engine_set_precision(e, 2), which brings the logits within 1e-3 of the reference's fp32 inference (inference_t2i.py:67,
+ * models/phi.py:1182-1183) at the speed of the bf16 path.  Conversions to fp16 saturate at +-65504; subnormals are kept. */
+enum { SHOWO_OP_BF16 = 0, SHOWO_OP_F16 = 1 };
+/* nn.LayerNorm with the 16-bit output of either type (showo_layernorm_f32_bf16 = op SHOWO_OP_BF16). */
+int showo_layernorm_f32_op16(const float* x, const float* w, const float* b, uint16_t* y, const int32_t* row_index,
+                             int rows, int H, float eps, int op, void* stream);
+
 /* epilogues of showo_gemm_bf16 */
 enum {
     SHOWO_EPI_BF16 = 0,       /* out bf16 = acc + bias                       (q/k/v proj, phi.py:657-659)        */
@@ -82,6 +92,10 @@ enum {
  * K % 64 == 0.  `bias` fp32 or NULL.  `bias_per_row` != 0 adds bias[m] instead of bias[n]. */
 int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
                     void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, void* stream);
+/* The same GEMM on either operand type: A, W and the 16-bit output of SHOWO_EPI_BF16 / SHOWO_EPI_GELU_BF16 are `op` values
+ * (q/k/v/dense/fc1/fc2/lm_head of models/phi.py:657-659,727,208-212,1182-1183 in precision 2). */
+int showo_gemm_op16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
+                    void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, int op, void* stream);
 
 /* kernel selection for tests/benchmarks: 0 = by shape (default), 1 = 128x128 register-staged, 2 = 256x256 global_load_lds,
  * 3 = 256x256 phase-split (4 phases per k-tile), 4 = 256x256 phase-split (2 phases per k-tile),
@@ -140,6 +154,11 @@ int showo_copy_b128(const void* src, void* dst, int64_t nbytes, void* stream);
 
 /* fp32 -> bf16 cast (weight packing) */
 int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+/* fp32 -> 16-bit cast of either operand type (round to nearest even; SHOWO_OP_F16 saturates at +-65504) */
+int showo_cast_f32_op16(const float* src, uint16_t* dst, int64_t n, int op, void* stream);
+/* number of elements of a 16-bit image whose magnitude is >= 65504 or NaN when read as IEEE half: the range check of precision 2
+ * (a saturated convert leaves exactly 65504).  count: device int64, ACCUMULATED into (zero it first). */
+int showo_count_f16_saturated(const uint16_t* x, int64_t n, int64_t* count, void* stream);
 
 /* embedding gather (phi.py:1006): ids int64 [T] -> x fp32 [T, H] from table fp32 [V, H]. */
 int showo_embed_f32(const int64_t* ids, const float* table, float* x, int T, int H, int V, void* stream);
@@ -152,6 +171,10 @@ int showo_embed_f32(const int64_t* ids, const float* table, float* x, int T, int
 int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
                   const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                   int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, void* stream);
+/* the same on either operand type (qkv in, Q / K / Vt out) */
+int showo_qk_prep_op16(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                       const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                       int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, int op, void* stream);
 
 /* The same result as showo_gemm_bf16(h, Wqkv) + showo_qk_prep in ONE kernel: the QKV projection whose epilogue applies
  * bias, the per-head LayerNorm(64) of q and k, the partial rotary embedding (rot must be 32) and writes Q (pre-scaled),
@@ -174,6 +197,13 @@ int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1
                             const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                             uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0, int Lcap,
                             int Lp, int w_tiled, void* stream);
+/* showo_gemm_qkv_fc1_bf16 (ffn_out != NULL) / showo_gemm_qkv_bf16 (ffn_out == NULL: F, ldf, w_tiled ignored) on either operand
+ * type: A, the weight image and Q / K / V^T / ffn_out are `op` values; LayerNorm(64), RoPE and gelu_new see the fp32 accumulators. */
+int showo_gemm_qkv_fc1_op16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
+                            const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                            const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                            uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0, int Lcap,
+                            int Lp, int w_tiled, int op, void* stream);
 
 /* Training forward of showo_gemm_qkv_fc1_bf16 (training/train.py:510-628 through models/phi.py:657-694, 208-212): the same launch
  * also saves what backward reads -- raw_qkv bf16 [B*L, ldraw] = A Wqkv^T + b (pre-LayerNorm q, k and v: the input of
@@ -207,6 +237,10 @@ int showo_gemm_qkv_fc1_split(const uint16_t* A3, int lda, const uint16_t* W3, in
 int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W, int ldw,
                          const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N, int epilogue,
                          int w_tiled, void* stream);
+/* the same on either operand type (A0, A1, W) */
+int showo_gemm_kcat_op16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W, int ldw,
+                         const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N, int epilogue,
+                         int w_tiled, int op, void* stream);
 
 /* Tiled weight layout accepted by the two entry points above (w_tiled = 1): [ceil(N/256)][K/64][256][64] bf16, rows beyond N zero,
  * the eight 16-byte chunks of a row stored at position chunk ^ (row & 7).  One (panel, k-tile) block = 32 KiB = the LDS image the
@@ -270,6 +304,10 @@ int showo_decode_set_tuning(const char* name, int value);
 int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                    const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
                    void* stream);
+/* the same attention on either operand type: Q, K, V^T, the soft-max numerator P inside the kernel and O are `op` values */
+int showo_attn_fwd_op16(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
+                        const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
+                        int op, void* stream);
 
 /* Accuracy-mode attention: Q, K, V^T and the output as (hi, lo) bf16 pairs (same layouts as showo_attn_fwd; O / Olo share ldo);
  * S = Khi Qhi + Khi Qlo + Klo Qhi, fp32 soft-max, O = Vhi Phi + Vhi Plo + Vlo Phi with P split in registers: the fp32 SDPA of
@@ -439,7 +477,7 @@ int showo_engine_t2i_captures(const showo_engine* e);
  * embedded input, slot i = output of transformer block i - 1), so that a test can check each block against the oracle evaluated on
  * the block's own input as the GPU computed it (no error amplification across blocks). */
 int showo_engine_set_collect(showo_engine* e, float* buf);
-/* Accuracy mode.  precision 0 (default): bf16 GEMM / attention operands, fp32 accumulation.  precision 1: the reference's fp32
+/* Operand precision.  precision 0 (default): bf16 GEMM / attention operands, fp32 accumulation.  precision 1: the reference's fp32
  * inference (inference_t2i.py:67 keeps the model in fp32; models/phi.py:1182-1183 returns fp32 logits) to ~1e-5 end to end with
  * split-bf16 operands (x = hi + lo to 2^-17, products hi*hi + lo*hi + hi*lo accumulated in fp32).
  * Production form (showo_engine_precise_fast() == 1: rotary_dim 32, 3 * hidden a multiple of 256 -- Phi-1.5's shape): the SAME
@@ -450,8 +488,22 @@ int showo_engine_set_collect(showo_engine* e, float* buf);
  * kernels of csrc/precise.hip serve forward / forward_rows / t2i_generate and the KV-cached entry points refuse.
  * The weights must be uploaded (showo_engine_load) AFTER switching to precision 1 -- the loader then also keeps their low halves;
  * showo_engine_precise_ready tells whether they are current. */
+/* precision 2 (round 6): IEEE-half ("fp16") operands.  The SAME launches, tiles, prefix reuse and hipGraph replay as precision 0 --
+ * v_mfma_f32_*_f16 runs at the bf16 rate -- with operand rounding 2^-12 instead of 2^-9: weights of the 24 blocks, LayerNorm output,
+ * Q / K / V^T, the soft-max numerator, the attention output and gelu(fc1) are fp16 (saturating converts, subnormals kept); the residual
+ * stream, LayerNorm / RoPE / soft-max arithmetic and every accumulator stay fp32, and the final LayerNorm + lm_head run as the split-bf16
+ * product of precision 1 (so the final hidden state and the lm_head weight are not rounding points).  End to end against the fp32
+ * reference: rel_rms ~8e-4 / rel_max <= 1e-3 at model scale where bf16 operands give 7e-3 (oracle/predict_rounding.py,
+ * tests/test_modules_gpu.py).  KV-cached decode steps run on the general (seven-launch) layer; the batched decode refuses.
+ * Switching between precision 2 and 0 / 1 un-loads the GEMM weights (their images change element type): showo_engine_missing() is
+ * then > 0 until the host has uploaded them again.  Training keeps bf16 images (showo_train_* refuse a precision-2 engine). */
 int showo_engine_set_precision(showo_engine* e, int precision);
 int showo_engine_get_precision(const showo_engine* e);
+/* precision 2 range check: while count != NULL (device int64, zero it first) every forward adds the number of fp16 activation
+ * elements (LayerNorm output, q|k|v or Q, attention output, gelu(fc1)) that left a convert saturated (|x| = 65504) or non-finite.
+ * Extra launches: a diagnostic, not for timed runs.  Random-init weights never saturate; REAL Phi-1.5 checkpoints decide the range
+ * question for a deployment -- run one batch with the counter on. */
+int showo_engine_set_range_check(showo_engine* e, int64_t* count);
 int showo_engine_precise_ready(const showo_engine* e);
 int showo_engine_precise_fast(const showo_engine* e);
 /* process-wide A/B switch of the two accuracy-mode implementations (default: SHOWO_PRECISE_FAST, on): 0 = always the fp32 reference

@@ -75,16 +75,31 @@ class Bf16Points:
       * ffn = bf16(gelu_new(acc + b1)); x += [o | ffn] [Wd | W2]^T + (bd + b2) in fp32;
       * hf = bf16(final LayerNorm(x)); logits fp32."""
 
-    def __init__(self, qkv_round=False, attn_tiles=False):
+    SITES = ("w", "w_lm", "h", "q", "k", "v", "p", "o", "gelu", "hf")
+
+    def __init__(self, qkv_round=False, attn_tiles=False, dtype=torch.bfloat16, sites=None):
         self.qkv_round = qkv_round
         # attn_tiles: model the rounding SCALE of P in the LDS-tiled attention kernel as well (attention_lds_model below); without it
         # P is rounded at the row's final maximum, which the kernel only does for rows whose maximum sits in their first key tile
         self.attn_tiles = attn_tiles
+        # dtype: the 16-bit operand type of the kernels -- torch.bfloat16 (Showo.set_precision(0)) or torch.float16 (set_precision(2):
+        # same MFMA rate, 3 more mantissa bits, saturating converts).  sites: which rounding points are active (None = all of SITES);
+        # a site left out keeps its fp32 value -- the model of an operand carried as a (hi, lo) pair, and the per-site error budget
+        # of oracle/predict_rounding.py
+        self.dtype = dtype
+        self.sites = set(self.SITES if sites is None else sites)
         self._w = {}
+
+    def r(self, site, t):
+        if site not in self.sites:
+            return t
+        if self.dtype == torch.float16:
+            t = t.clamp(-65504.0, 65504.0)  # the kernels' converts saturate (csrc/common.h Op16<true>)
+        return t.to(self.dtype).to(torch.float32)
 
     def w(self, sd, key):
         if key not in self._w:
-            self._w[key] = bf16r(sd[key])
+            self._w[key] = self.r("w_lm" if key.endswith("lm_head.weight") else "w", sd[key])
         return self._w[key]
 
 
@@ -92,7 +107,7 @@ AT_DEFER = 8.0  # csrc/attention.hip: deferred-rescale threshold of the running 
 _LOG2E = 1.4426950408889634
 
 
-def attention_lds_model(q, k, v, vis):
+def attention_lds_model(q, k, v, vis, rp=bf16r, ro=bf16r):
     """The arithmetic of csrc/attention.hip::attn_lds_body with its rounding points, restated for the per-block parity gate.
     q (pre-scaled by 1/8), k, v: bf16-rounded fp32 [B,H,L,64]; vis: bool [B,1|H,L,L] (True = key visible).
     One wave owns 32 consecutive query rows and walks the keys in 32-key sub-tiles (multiples of 32 inside the wave's key hull); the
@@ -129,8 +144,8 @@ def attention_lds_model(q, k, v, vis):
             mb = torch.where(torch.isinf(m), torch.zeros(()), m) * _LOG2E
             pr = torch.exp2(sv * _LOG2E - mb.unsqueeze(-1))    # exp2(fma(s, log2 e, -m log2 e)); masked keys: exp2(-inf) = 0
             l = l + pr.sum(dim=-1)
-            acc = acc + bf16r(pr) @ v[:, :, ks:ke]
-        out[:, :, g0:g1] = bf16r(acc * (1.0 / l).unsqueeze(-1))
+            acc = acc + rp(pr) @ v[:, :, ks:ke]
+        out[:, :, g0:g1] = ro(acc * (1.0 / l).unsqueeze(-1))
     return out
 
 
@@ -141,7 +156,7 @@ def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
     k = h @ W(p + "k_proj.weight").T + sd[p + "k_proj.bias"]
     v = h @ W(p + "v_proj.weight").T + sd[p + "v_proj.bias"]
     if pts is not None and pts.qkv_round:
-        q, k, v = bf16r(q), bf16r(k), bf16r(v)
+        q, k, v = pts.r("q", q), pts.r("k", k), pts.r("v", v)
     q = q.view(B, L, d.heads, d.head_dim).transpose(1, 2)
     k = k.view(B, L, d.heads, d.head_dim).transpose(1, 2)
     v = v.view(B, L, d.heads, d.head_dim).transpose(1, 2)
@@ -151,7 +166,7 @@ def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
     q = apply_partial_rope(q, cos, sin, d.rotary_dim)
     k = apply_partial_rope(k, cos, sin, d.rotary_dim)
     if pts is not None:
-        q, k, v = bf16r(q / math.sqrt(d.head_dim)), bf16r(k), bf16r(v)
+        q, k, v = pts.r("q", q / math.sqrt(d.head_dim)), pts.r("k", k), pts.r("v", v)
         s = q @ k.transpose(2, 3)
     else:
         s = (q @ k.transpose(2, 3)) / math.sqrt(d.head_dim)
@@ -163,10 +178,10 @@ def phi_attention(sd, p, d, h, mask, cos, sin, pts=None):
         s = s.masked_fill(~causal, float("-inf"))
     if pts is not None and pts.attn_tiles:
         vis = (mask == 0) if mask is not None else torch.tril(torch.ones(L, L, dtype=torch.bool)).reshape(1, 1, L, L)
-        return attention_lds_model(q, k, v, vis).transpose(1, 2).reshape(B, L, Hd)
+        return attention_lds_model(q, k, v, vis, lambda t: pts.r("p", t), lambda t: pts.r("o", t)).transpose(1, 2).reshape(B, L, Hd)
     if pts is not None:
         e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
-        o = bf16r((bf16r(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, L, Hd)
+        o = pts.r("o", (pts.r("p", e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, L, Hd)
         return o  # the dense projection joins fc2 in ONE K-concatenated GEMM (phi_hidden)
     a = torch.softmax(s, dim=-1)
     o = (a @ v).transpose(1, 2).reshape(B, L, Hd)
@@ -178,9 +193,9 @@ def phi_layer(sd, d, i, x, mask, cos, sin, pts=None):
     p = f"showo.model.layers.{i}."
     h = layer_norm(x, sd[p + "input_layernorm.weight"], sd[p + "input_layernorm.bias"], d.ln_eps)
     if pts is not None:
-        h = bf16r(h)
+        h = pts.r("h", h)
         o = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin, pts)
-        m = bf16r(gelu_new(h @ pts.w(sd, p + "mlp.fc1.weight").T + sd[p + "mlp.fc1.bias"]))
+        m = pts.r("gelu", gelu_new(h @ pts.w(sd, p + "mlp.fc1.weight").T + sd[p + "mlp.fc1.bias"]))
         return x + (o @ pts.w(sd, p + "self_attn.dense.weight").T + m @ pts.w(sd, p + "mlp.fc2.weight").T
                     + (sd[p + "self_attn.dense.bias"] + sd[p + "mlp.fc2.bias"]))
     a = phi_attention(sd, p + "self_attn.", d, h, mask, cos, sin)
@@ -193,7 +208,7 @@ def phi_head(sd, d, x, pts=None):
     """final LayerNorm + biased lm_head + .float() (models/phi.py:1078, 1182-1183)"""
     hid = layer_norm(x, sd["showo.model.final_layernorm.weight"], sd["showo.model.final_layernorm.bias"], d.ln_eps)
     if pts is not None:
-        return (bf16r(hid) @ pts.w(sd, "showo.lm_head.weight").T + sd["showo.lm_head.bias"]).float()
+        return (pts.r("hf", hid) @ pts.w(sd, "showo.lm_head.weight").T + sd["showo.lm_head.bias"]).float()
     return (hid @ sd["showo.lm_head.weight"].T + sd["showo.lm_head.bias"]).float()
 
 
@@ -210,7 +225,7 @@ def phi_hidden(sd, d, input_ids=None, inputs_embeds=None, attention_mask=None, c
         if collect is not None:
             collect.append(x)
     hid = layer_norm(x, sd["showo.model.final_layernorm.weight"], sd["showo.model.final_layernorm.bias"], d.ln_eps)
-    return bf16r(hid) if pts is not None else hid
+    return pts.r("hf", hid) if pts is not None else hid
 
 
 def showo_logits(sd, d, input_ids=None, input_embeddings=None, attention_mask=None, pts=None):

@@ -86,6 +86,17 @@ _PROTOS = {
     "showo_conv3x3_bf16x3_gn": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "showo_split_f32_bf16": [c_p, c_p, c_p, c_i64, c_p],
     "showo_cast_f32_bf16": [c_p, c_p, c_i64, c_p],
+    # 16-bit operand type as an argument (SHOWO_OP_BF16 = 0 | SHOWO_OP_F16 = 1, second to last): the `_bf16` entry points are op = 0
+    "showo_cast_f32_op16": [c_p, c_p, c_i64, c_i, c_p],
+    "showo_count_f16_saturated": [c_p, c_i64, c_p, c_p],
+    "showo_layernorm_f32_op16": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
+    "showo_gemm_op16": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_qkv_fc1_op16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                                c_f, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_gemm_kcat_op16": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_qk_prep_op16": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "showo_attn_fwd_op16": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "showo_engine_set_range_check": [c_p, c_p],
     "showo_copy_b128": [c_p, c_p, c_i64, c_p],
     "showo_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "showo_gemm_qkv_bf16": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],

@@ -54,6 +54,7 @@ __device__ inline float ln_rope_lane(float x, float w, float b, float eps, const
     return y;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void qk_prep_kernel(PrepArgs a) {
     __shared__ bf16_t sV[64][66];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,10 +71,10 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(PrepArgs a) {
         const float* cosr = a.cosT + (int64_t)pos * a.rot;
         const float* sinr = a.sinT + (int64_t)pos * a.rot;
         // plain heads (qw == NULL: a standard multi-head attention such as the CLIP tower's): only the 1/8 scale and the relayout
-        float q = plain ? bf2f(row[lane]) : ln_rope_lane(bf2f(row[lane]), qw, qb, a.eps, cosr, sinr, a.rot, lane);
-        float k = plain ? bf2f(row[Hq + lane]) : ln_rope_lane(bf2f(row[Hq + lane]), kw, kb, a.eps, cosr, sinr, a.rot, lane);
-        a.Q[(((int64_t)b * a.nH + head) * a.L + l) * 64 + lane] = f2bf(q * 0.125f);  // 1/sqrt(64), exact in bf16
-        a.K[(((int64_t)b * a.nH + head) * a.Lcap + pos) * 64 + lane] = f2bf(k);
+        float q = plain ? Op16<F16>::tof(row[lane]) : ln_rope_lane(Op16<F16>::tof(row[lane]), qw, qb, a.eps, cosr, sinr, a.rot, lane);
+        float k = plain ? Op16<F16>::tof(row[Hq + lane]) : ln_rope_lane(Op16<F16>::tof(row[Hq + lane]), kw, kb, a.eps, cosr, sinr, a.rot, lane);
+        a.Q[(((int64_t)b * a.nH + head) * a.L + l) * 64 + lane] = Op16<F16>::cvt(q * 0.125f);  // 1/sqrt(64): a power of two, exact in either type
+        a.K[(((int64_t)b * a.nH + head) * a.Lcap + pos) * 64 + lane] = Op16<F16>::cvt(k);
         sV[wave * 16 + i][lane] = row[2 * Hq + lane];
     }
     __syncthreads();
@@ -192,15 +193,17 @@ __device__ __forceinline__ void attn_block_coords(const AttnArgs& a, int& qb, in
     head = bh - b * a.nH;
 }
 
+template <bool F16>
 __device__ inline bf16x8 pack8(const float* p) {
     uint4 u;
-    u.x = pack_bf2(p[0], p[1]);
-    u.y = pack_bf2(p[2], p[3]);
-    u.z = pack_bf2(p[4], p[5]);
-    u.w = pack_bf2(p[6], p[7]);
+    u.x = Op16<F16>::pack2(p[0], p[1]);
+    u.y = Op16<F16>::pack2(p[2], p[3]);
+    u.z = Op16<F16>::pack2(p[4], p[5]);
+    u.w = Op16<F16>::pack2(p[6], p[7]);
     return __builtin_bit_cast(bf16x8, u);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (a.pos_dev) a.Lk = *a.pos_dev + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kp + 16 * m);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m], s, 0, 0, 0);
+            s = Op16<F16>::mfma32(kf, qf[m], s);
         }
         float sv[16];
         float mx = -INFINITY;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         m_run = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        bf16x8 pb0 = pack8(p), pb1 = pack8(p + 8);
+        bf16x8 pb0 = pack8<F16>(p), pb1 = pack8<F16>(p + 8);
         // O^T[d][q] += Vt[d][keys] * P^T[keys][q]; lane's 8 k-slots of product kk are keys
         // kt + 16kk + 4hh + {0..3} and kt + 16kk + 8 + 4hh + {0..3}  (same keys as p[8kk .. 8kk+7])
 #pragma unroll
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             uint2 b0 = *reinterpret_cast<const uint2*>(v1), b1 = *reinterpret_cast<const uint2*>(v1 + 8);
             bf16x8 vf0 = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
             bf16x8 vf1 = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pb1 : pb0, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pb1 : pb0, o1, 0, 0, 0);
+            o0 = Op16<F16>::mfma32(vf0, kk ? pb1 : pb0, o0);
+            o1 = Op16<F16>::mfma32(vf1, kk ? pb1 : pb0, o1);
         }
     }
     float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -301,10 +304,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w0, w1;
-            w0.x = pack_bf2(o0[4 * g] * inv, o0[4 * g + 1] * inv);
-            w0.y = pack_bf2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            w1.x = pack_bf2(o1[4 * g] * inv, o1[4 * g + 1] * inv);
-            w1.y = pack_bf2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            w0.x = Op16<F16>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = Op16<F16>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = Op16<F16>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = Op16<F16>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(op + 8 * g) = w0;        // d = 8g + 4hh + {0..3}
             *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;   // d = 32 + 8g + 4hh + {0..3}
         }
@@ -331,7 +334,8 @@ constexpr float AT_DEFER = 8.0f;   // deferred-rescale threshold (natural-log un
 // v_cvt_pk_bf16_f32 on gfx950), NOT inline assembly: the results feed MFMA operands, and the hazard recognizer does not look inside an
 // asm block -- in the split + dense-mask variant an asm-written P fragment was consumed by the next-but-one MFMA and the products
 // came out at bf16 accuracy (round 5: tools/diag_split_attn.py, 4e-3 instead of 3e-5 against the fp64 SDPA).
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }
+template <bool F16 = false>
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return Op16<F16>::pack2(lo, hi); }
 
 // WPB = waves (32-row query tiles) per block: 4, or 5 when that saves a block per (batch, head) -- at Lq = 258 (the 18-step t2i
 // loop: <soi> + 256 image tokens + <eoi>) the ninth query tile would otherwise get a block of its own that streams every K / V^T
@@ -339,8 +343,11 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pac
 // SPLIT (accuracy mode, showo_attn_fwd_split): Q, K, V^T arrive as (hi, lo) bf16 pairs; S = Khi Qhi + Khi Qlo + Klo Qhi and
 // O = Vhi Phi + Vhi Plo + Vlo Phi with P split in registers (P - bf16(P) rounded to bf16): three MFMAs per fragment pair, fp32
 // softmax as before -> the fp32 SDPA of models/phi.py:715-722 to ~1e-5.  LDS holds four tiles per stage (K, V^T, Klo, V^Tlo).
-template <bool DENSE, int WPB, bool SPLIT = false>
+// F16 (precision 2): Q, K, V^T, P and O are IEEE half (common.h Op16): v_mfma_f32_32x32x16_f16.  P <= e^AT_DEFER = 2981 stays far below
+// 65504, and probabilities below the fp16 normal range (6.1e-5 of the running maximum's scale) keep their subnormal encoding.
+template <bool DENSE, int WPB, bool SPLIT = false, bool F16 = false>
 __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int* s_hull) {
+    static_assert(!(SPLIT && F16), "the (hi, lo) form is a bfloat16 scheme");
     constexpr int NT = SPLIT ? 4 : 2;  // tiles per stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int qb_, head, b;
@@ -450,11 +457,11 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * sub + qi) * 64 + (((2 * m + hh) ^ fsw) << 3));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[m], s, 0, 0, 0);
+                s = Op16<F16>::mfma32(kf, qf[m], s);
                 if constexpr (SPLIT) {
                     bf16x8 kl = *reinterpret_cast<const bf16x8*>(sK + 2 * AT_TILE + (32 * sub + qi) * 64 + (((2 * m + hh) ^ fsw) << 3));
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[m], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[m], s, 0, 0, 0);
+                    s = Op16<F16>::mfma32(kf, qfl[m], s);
+                    s = Op16<F16>::mfma32(kl, qf[m], s);
                 }
             }
             // interior sub-tile: every row of the wave sees all 32 keys -> no per-element mask work
@@ -499,8 +506,8 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             bf16x8 pb0, pb1;
             uint4 u0, u1;
             {
-                u0.x = cvt_pk_bf16(p[0], p[1]); u0.y = cvt_pk_bf16(p[2], p[3]); u0.z = cvt_pk_bf16(p[4], p[5]); u0.w = cvt_pk_bf16(p[6], p[7]);
-                u1.x = cvt_pk_bf16(p[8], p[9]); u1.y = cvt_pk_bf16(p[10], p[11]); u1.z = cvt_pk_bf16(p[12], p[13]); u1.w = cvt_pk_bf16(p[14], p[15]);
+                u0.x = cvt_pk_bf16<F16>(p[0], p[1]); u0.y = cvt_pk_bf16<F16>(p[2], p[3]); u0.z = cvt_pk_bf16<F16>(p[4], p[5]); u0.w = cvt_pk_bf16<F16>(p[6], p[7]);
+                u1.x = cvt_pk_bf16<F16>(p[8], p[9]); u1.y = cvt_pk_bf16<F16>(p[10], p[11]); u1.z = cvt_pk_bf16<F16>(p[12], p[13]); u1.w = cvt_pk_bf16<F16>(p[14], p[15]);
                 pb0 = __builtin_bit_cast(bf16x8, u0);
                 pb1 = __builtin_bit_cast(bf16x8, u1);
             }
@@ -510,7 +517,7 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
                 uint32_t lw[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    lw[i] = cvt_pk_bf16(p[2 * i] - __uint_as_float(hw[i] << 16), p[2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u));
+                    lw[i] = cvt_pk_bf16<F16>(p[2 * i] - __uint_as_float(hw[i] << 16), p[2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u));
                 pl0 = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
                 pl1 = __builtin_bit_cast(bf16x8, make_uint4(lw[4], lw[5], lw[6], lw[7]));
             }
@@ -519,15 +526,15 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
                 const int c = ((4 * sub + 2 * kk + hh) ^ fsw) << 3;
                 bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(sV + qi * 64 + c);
                 bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(sV + (32 + qi) * 64 + c);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pb1 : pb0, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pb1 : pb0, o1, 0, 0, 0);
+                o0 = Op16<F16>::mfma32(vf0, kk ? pb1 : pb0, o0);
+                o1 = Op16<F16>::mfma32(vf1, kk ? pb1 : pb0, o1);
                 if constexpr (SPLIT) {
                     bf16x8 vl0 = *reinterpret_cast<const bf16x8*>(sV + 2 * AT_TILE + qi * 64 + c);
                     bf16x8 vl1 = *reinterpret_cast<const bf16x8*>(sV + 2 * AT_TILE + (32 + qi) * 64 + c);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, kk ? pl1 : pl0, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, kk ? pl1 : pl0, o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0, kk ? pb1 : pb0, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1, kk ? pb1 : pb0, o1, 0, 0, 0);
+                    o0 = Op16<F16>::mfma32(vf0, kk ? pl1 : pl0, o0);
+                    o1 = Op16<F16>::mfma32(vf1, kk ? pl1 : pl0, o1);
+                    o0 = Op16<F16>::mfma32(vl0, kk ? pb1 : pb0, o0);
+                    o1 = Op16<F16>::mfma32(vl1, kk ? pb1 : pb0, o1);
                 }
             }
         }
@@ -543,19 +550,19 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w0, w1;
-            w0.x = cvt_pk_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv);
-            w0.y = cvt_pk_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            w1.x = cvt_pk_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv);
-            w1.y = cvt_pk_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            w0.x = cvt_pk_bf16<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = cvt_pk_bf16<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = cvt_pk_bf16<F16>(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = cvt_pk_bf16<F16>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(op + 8 * g) = w0;
             *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
             if constexpr (SPLIT) {
                 bf16_t* ol = a.Olo + ((int64_t)b * a.Lq + qrow_raw) * a.ldo + head * 64 + 4 * hh;
                 uint2 l0, l1;
-                l0.x = cvt_pk_bf16(o0[4 * g] * inv - bf2f((bf16_t)(w0.x & 0xffffu)), o0[4 * g + 1] * inv - bf2f((bf16_t)(w0.x >> 16)));
-                l0.y = cvt_pk_bf16(o0[4 * g + 2] * inv - bf2f((bf16_t)(w0.y & 0xffffu)), o0[4 * g + 3] * inv - bf2f((bf16_t)(w0.y >> 16)));
-                l1.x = cvt_pk_bf16(o1[4 * g] * inv - bf2f((bf16_t)(w1.x & 0xffffu)), o1[4 * g + 1] * inv - bf2f((bf16_t)(w1.x >> 16)));
-                l1.y = cvt_pk_bf16(o1[4 * g + 2] * inv - bf2f((bf16_t)(w1.y & 0xffffu)), o1[4 * g + 3] * inv - bf2f((bf16_t)(w1.y >> 16)));
+                l0.x = cvt_pk_bf16<F16>(o0[4 * g] * inv - bf2f((bf16_t)(w0.x & 0xffffu)), o0[4 * g + 1] * inv - bf2f((bf16_t)(w0.x >> 16)));
+                l0.y = cvt_pk_bf16<F16>(o0[4 * g + 2] * inv - bf2f((bf16_t)(w0.y & 0xffffu)), o0[4 * g + 3] * inv - bf2f((bf16_t)(w0.y >> 16)));
+                l1.x = cvt_pk_bf16<F16>(o1[4 * g] * inv - bf2f((bf16_t)(w1.x & 0xffffu)), o1[4 * g + 1] * inv - bf2f((bf16_t)(w1.x >> 16)));
+                l1.y = cvt_pk_bf16<F16>(o1[4 * g + 2] * inv - bf2f((bf16_t)(w1.y & 0xffffu)), o1[4 * g + 3] * inv - bf2f((bf16_t)(w1.y >> 16)));
                 *reinterpret_cast<uint2*>(ol + 8 * g) = l0;
                 *reinterpret_cast<uint2*>(ol + 32 + 8 * g) = l1;
             }
@@ -579,13 +586,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void attn_fwd_lds_split_kernel(AttnArg
 // no barrier in the key loop; bit-identical to attn_lds_body -- and it was slower: 312 vs 346 TF/s at the t2i shape, 37.8 vs 38.4
 // images/s on one box (profiles/r5m_attention_resident_ab.txt): 112 KiB of LDS leave one block per CU and the up-front stage is bound by
 // what one CU can pull.  The kernel is in the git history, not in the library.)
-template <int MINW, int WPB = 4>
+template <int MINW, int WPB = 4, bool F16 = false>
 __global__ __launch_bounds__(64 * WPB, MINW) void attn_fwd_lds_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sm[4 * AT_TILE];  // [buf][K | Vt]
     __shared__ int s_hull[2 * WPB];
     const bool dense = (a.flag != nullptr) && (a.dense != nullptr) && (*a.flag != 0);  // block-uniform
-    if (dense) attn_lds_body<true, WPB>(a, sm, s_hull);
-    else attn_lds_body<false, WPB>(a, sm, s_hull);
+    if (dense) attn_lds_body<true, WPB, false, F16>(a, sm, s_hull);
+    else attn_lds_body<false, WPB, false, F16>(a, sm, s_hull);
 }
 
 }  // namespace
@@ -606,7 +613,7 @@ struct DecPrep {
     float eps;
 };
 
-template <bool FUSED>
+template <bool FUSED, bool F16 = false>
 static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, const int head, const int b) {
     extern __shared__ float sp[];  // probabilities, zero padded to a multiple of 512 keys
     __shared__ float red[32];
@@ -670,7 +677,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         const float cs = f.cosT[(int64_t)pos * f.rot + dl], sn = f.sinT[(int64_t)pos * f.rot + dl];
         __builtin_amdgcn_sched_barrier(0);  // every load of the prologue is issued before the first wait (the scheduler otherwise starts the LayerNorm -- and its wait for the token element -- ahead of the RoPE loads)
         // ln_rope_lane's expressions with the statistics on the VALU-only reductions (same bits) and the RoPE operands in registers
-        const float x0 = bf2f(xin);
+        const float x0 = Op16<F16>::tof(xin);
         const float mean = wave_sum_swap(x0) * (1.0f / 64.0f);
         const float c = x0 - mean;
         const float var = wave_sum_swap(c * c) * (1.0f / 64.0f);
@@ -679,13 +686,13 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         const float partner = __shfl_xor(y, half, 64);
         if (lane < f.rot) y = y * cs + (lane < half ? -partner : partner) * sn;
         if (wave == 0) {
-            sq[lane] = bf2f(f2bf(y * 0.125f));
+            sq[lane] = Op16<F16>::tof(Op16<F16>::cvt(y * 0.125f));
         } else if (wave == 1) {
-            const bf16_t kb = f2bf(y);
-            sk[lane] = bf2f(kb);
+            const bf16_t kb = Op16<F16>::cvt(y);
+            sk[lane] = Op16<F16>::tof(kb);
             const_cast<bf16_t*>(a.K)[(bh * a.Lcap + pos) * 64 + lane] = kb;
         } else if (wave == 2) {
-            sv[lane] = bf2f(xin);
+            sv[lane] = Op16<F16>::tof(xin);
             const_cast<bf16_t*>(a.Vt)[(bh * 64 + lane) * a.Lp + pos] = xin;
         }
         __syncthreads();
@@ -695,7 +702,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         const uint4 u = *reinterpret_cast<const uint4*>(a.Q + bh * 64 + ch * 8);  // Lq = 1
         const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qv[j] = bf2f(e[j]);
+        for (int j = 0; j < 8; ++j) qv[j] = Op16<F16>::tof(e[j]);
     }
     // the new token's key chunk / value dimensions in registers: the selects below stay selects (an LDS read under a per-element
     // condition compiles to a branch per element)
@@ -723,7 +730,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         const bf16_t* e = reinterpret_cast<const bf16_t*>(&kr);
         float sc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sc = fmaf(qv[j], (FUSED && k == pos) ? skv[j] : bf2f(e[j]), sc);
+        for (int j = 0; j < 8; ++j) sc = fmaf(qv[j], (FUSED && k == pos) ? skv[j] : Op16<F16>::tof(e[j]), sc);
         sc += dpp_move<DPP_XOR1>(sc);
         sc += dpp_move<DPP_XOR2>(sc);
         sc += dpp_move<DPP_HALF_MIRROR>(sc);
@@ -760,7 +767,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         if (k < a.Lk) {
             p = __builtin_amdgcn_exp2f((sp[k] - mu) * LOG2E);
             sum += p;
-            p = bf2f(f2bf(p));  // P is rounded to bf16 like the MFMA paths before it multiplies V
+            p = Op16<F16>::tof(Op16<F16>::cvt(p));  // P is rounded to the operand type like the MFMA paths before it multiplies V
         }
         sp[k] = p;
     }
@@ -784,7 +791,7 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
         for (int i = 0; i < 4; ++i) {
             const bf16_t* e = reinterpret_cast<const bf16_t*>(&u[i]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[i] = fmaf(pr[j], j == jn ? svv[i] : (j < nvalid ? bf2f(e[j]) : 0.f), o[i]);
+            for (int j = 0; j < 8; ++j) o[i] = fmaf(pr[j], j == jn ? svv[i] : (j < nvalid ? Op16<F16>::tof(e[j]) : 0.f), o[i]);
         }
     };
     accum(0, vu[0]);
@@ -800,13 +807,13 @@ static __device__ __forceinline__ void attn_decode_body(AttnArgs a, DecPrep f, c
     for (int i = 0; i < 4; ++i) o[i] = wave_sum_swap(o[i]);
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a.O[(int64_t)b * a.ldo + head * 64 + d0 + i] = f2bf(o[i] * inv);
+        for (int i = 0; i < 4; ++i) a.O[(int64_t)b * a.ldo + head * 64 + d0 + i] = Op16<F16>::cvt(o[i] * inv);
     }
 }
 
-template <bool FUSED>
+template <bool FUSED, bool F16 = false>
 __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f) {
-    attn_decode_body<FUSED>(a, f, blockIdx.x, blockIdx.y);
+    attn_decode_body<FUSED, F16>(a, f, blockIdx.x, blockIdx.y);
 }
 
 // Co-scheduled decode launch: blocks [0, nH) are the fused single-query attention (32 latency-bound blocks on a 256-CU chip); the
@@ -845,11 +852,12 @@ static const int* g_decode_pos_dev = nullptr;
 static int g_decode_lk_max = 0;  // upper bound of the key count over the replays of the captured loop (0: cache capacity)
 namespace showo { void attn_set_decode_pos(const int* p, int lk_max) { g_decode_pos_dev = p; g_decode_lk_max = p ? lk_max : 0; } }
 
-extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
-                             const float* kln_b, const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K,
-                             uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
-                             void* stream) {
+extern "C" int showo_qk_prep_op16(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
+                                  const float* kln_b, const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K,
+                                  uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp, int op,
+                                  void* stream) {
     if (B <= 0 || L <= 0) return 0;
+    if (op != SHOWO_OP_BF16 && op != SHOWO_OP_F16) return set_error_msg(1, "qk_prep: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
     if (qln_w && rot != 32 && rot != 16 && rot != 64 && rot != 8) return set_error_msg(1, "qk_prep: rotary dim must be a power of two <= 64");
     if ((Lp % 64) || Lp < pos0 + L || Lcap < pos0 + L) return set_error_msg(1, "qk_prep: bad Lp/Lcap");
     PrepArgs a;
@@ -857,9 +865,16 @@ extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const floa
     a.Q = Q; a.K = K; a.Vt = Vt; a.B = B; a.L = L; a.nH = nH; a.rot = rot; a.pos0 = pos0; a.Lcap = Lcap; a.Lp = Lp;
     a.eps = eps;
     a.pos_dev = (L == 1 && B == 1) ? g_decode_pos_dev : nullptr;
-    qk_prep_kernel<<<dim3((L + 63) / 64, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    if (op) qk_prep_kernel<true><<<dim3((L + 63) / 64, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    else qk_prep_kernel<false><<<dim3((L + 63) / 64, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
+}
+extern "C" int showo_qk_prep(const uint16_t* qkv, const float* qln_w, const float* qln_b, const float* kln_w,
+                             const float* kln_b, const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K,
+                             uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
+                             void* stream) {
+    return showo_qk_prep_op16(qkv, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps, pos0, Lcap, Lp, SHOWO_OP_BF16, stream);
 }
 
 extern "C" int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag, int B, int Lq, int Lk, void* stream) {
@@ -880,10 +895,21 @@ extern "C" int showo_attn_set_impl(int impl) {
 static int g_attn_wpb5 = -1;  // SHOWO_ATTN_WPB5=1: five query tiles per block where that saves a block per (b, head).  Opt-in: measured
                               // SLOWER in one box (attention 214-217 vs 286-294 TF/s, 32.0 vs 33.1 images/s): the fifth wave shares a SIMD
 
+// XCD-aware 1-D grid of the LDS-tiled form (SHOWO_ATTN_XCD=0: the natural 3-D grid)
+static dim3 grid_f16(AttnArgs& a, int nqb, int nH, int B) {
+    static int xcd = -1;
+    if (xcd < 0) { const char* e = getenv("SHOWO_ATTN_XCD"); xcd = e ? (atoi(e) != 0) : 1; }
+    if (xcd) { a.nqb = nqb; return dim3((unsigned)nqb * nH * B); }
+    a.nqb = 0;
+    return dim3(nqb, nH, B);
+}
+
 static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv, const int32_t* flag,
                          const float* dense_mask, uint16_t* O, float* lse, int B, int nH, int Lq, int Lk, int Lcap, int Lp, int ldo,
-                         void* stream) {
+                         void* stream, int op = 0) {
     if (B <= 0 || Lq <= 0 || Lk <= 0) return 0;
+    if (op != SHOWO_OP_BF16 && op != SHOWO_OP_F16) return set_error_msg(1, "attn: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
+    if (op && lse) return set_error_msg(1, "attn: the training forward (lse) has bf16 operands only");
     if ((Lp % 64) || Lp < Lk || Lcap < Lk || (ldo % 4)) return set_error_msg(1, "attn: bad Lp/Lcap/ldo");
     AttnArgs a;
     a.Q = Q; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = flag; a.dense = dense_mask; a.O = O;
@@ -900,10 +926,17 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
         if (g_decode_pos_dev) a.Lk = (g_decode_lk_max > 0 && g_decode_lk_max < Lcap) ? g_decode_lk_max : Lcap;  // load bound, see the kernel
         const size_t smem = (size_t)(((g_decode_pos_dev ? Lcap : Lk) + 511) & ~511) * sizeof(float);  // graph replay: Lk grows
         if (smem <= 60000) {
-            attn_decode_kernel<false><<<dim3(nH, B), dim3(1024), smem, (hipStream_t)stream>>>(a, DecPrep{});
+            if (op) attn_decode_kernel<false, true><<<dim3(nH, B), dim3(1024), smem, (hipStream_t)stream>>>(a, DecPrep{});
+            else attn_decode_kernel<false><<<dim3(nH, B), dim3(1024), smem, (hipStream_t)stream>>>(a, DecPrep{});
             SHOWO_CHECK_HIP(hipGetLastError());
             return 0;
         }
+    }
+    if (op) {  // IEEE-half operands (precision 2): the default tile shapes only (the A/B variants stay bf16)
+        if (tiled) { const dim3 g = grid_f16(a, (qblocks + 3) / 4, nH, B); attn_fwd_lds_kernel<4, 4, true><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
+        else attn_fwd_kernel<true><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+        SHOWO_CHECK_HIP(hipGetLastError());
+        return 0;
     }
     // SHOWO_ATTN_XCD (default 1): XCD-aware 1-D block order (attn_block_coords); 0 = the natural 3-D grid (A/B runs).
     // SHOWO_ATTN_WPB9=1: all (up to 9) query tiles of a (batch, head) in ONE 576-thread block -- every K / V^T tile is staged once per
@@ -918,7 +951,7 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
         const dim3 g = grid((qblocks + 4) / 5);
         attn_fwd_lds_kernel<3, 5><<<g, dim3(320), 0, (hipStream_t)stream>>>(a);
     } else if (tiled) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<4><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
-    else attn_fwd_kernel<<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
+    else attn_fwd_kernel<false><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -927,6 +960,11 @@ extern "C" int showo_attn_fwd(const uint16_t* Q, const uint16_t* K, const uint16
                               const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
                               int Lcap, int Lp, int ldo, void* stream) {
     return attn_fwd_impl(Q, K, Vt, iv, flag, dense_mask, O, nullptr, B, nH, Lq, Lk, Lcap, Lp, ldo, stream);
+}
+extern "C" int showo_attn_fwd_op16(const uint16_t* Q, const uint16_t* K, const uint16_t* Vt, const int32_t* iv,
+                                   const int32_t* flag, const float* dense_mask, uint16_t* O, int B, int nH, int Lq, int Lk,
+                                   int Lcap, int Lp, int ldo, int op, void* stream) {
+    return attn_fwd_impl(Q, K, Vt, iv, flag, dense_mask, O, nullptr, B, nH, Lq, Lk, Lcap, Lp, ldo, stream, op);
 }
 
 // Accuracy mode (showo_engine_set_precision 1): every operand and the output as (hi, lo) bf16 pairs of identical layout; three MFMAs

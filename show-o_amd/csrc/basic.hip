@@ -94,6 +94,7 @@ extern "C" int showo_lfq_unpack_nchw(const int64_t* ids, float* zq, int B, int C
 // LayerNorm: one wave per row, float4 loads, two-pass (mean, then centred variance) in fp32.
 // Row (8 KB at H=2048) stays in L1/L2 between passes; output bf16x4 stores.
 // ------------------------------------------------------------------------------------------------
+template <bool F16>  // F16: the output is IEEE half (common.h Op16)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, bf16_t* __restrict__ y,
                                                         const int32_t* __restrict__ row_index, int rows, int H, float eps) {
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 const float4 g = *reinterpret_cast<const float4*>(w + i);
                 const float4 bb = *reinterpret_cast<const float4*>(b + i);
                 uint2 o;
-                o.x = pack_bf2((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y);
-                o.y = pack_bf2((v.z - mean) * rstd * g.z + bb.z, (v.w - mean) * rstd * g.w + bb.w);
+                o.x = Op16<F16>::pack2((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y);
+                o.y = Op16<F16>::pack2((v.z - mean) * rstd * g.z + bb.z, (v.w - mean) * rstd * g.w + bb.w);
                 *reinterpret_cast<uint2*>(yr + i) = o;
             }
         }
@@ -168,39 +169,64 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float4 g = *reinterpret_cast<const float4*>(w + i);
             float4 bb = *reinterpret_cast<const float4*>(b + i);
             uint2 o;
-            o.x = pack_bf2((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y);
-            o.y = pack_bf2((v.z - mean) * rstd * g.z + bb.z, (v.w - mean) * rstd * g.w + bb.w);
+            o.x = Op16<F16>::pack2((v.x - mean) * rstd * g.x + bb.x, (v.y - mean) * rstd * g.y + bb.y);
+            o.y = Op16<F16>::pack2((v.z - mean) * rstd * g.z + bb.z, (v.w - mean) * rstd * g.w + bb.w);
             *reinterpret_cast<uint2*>(yr + i) = o;
         }
     } else {
-        for (int i = lane; i < H; i += 64) yr[i] = f2bf((xr[i] - mean) * rstd * w[i] + b[i]);
+        for (int i = lane; i < H; i += 64) yr[i] = Op16<F16>::cvt((xr[i] - mean) * rstd * w[i] + b[i]);
     }
 }
 
-extern "C" int showo_layernorm_f32_bf16(const float* x, const float* w, const float* b, uint16_t* y,
-                                        const int32_t* row_index, int rows, int H, float eps, void* stream) {
+extern "C" int showo_layernorm_f32_op16(const float* x, const float* w, const float* b, uint16_t* y,
+                                        const int32_t* row_index, int rows, int H, float eps, int op, void* stream) {
     if (rows <= 0) return 0;
-    layernorm_kernel<<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, w, b, y, row_index, rows, H, eps);
+    if (op == SHOWO_OP_F16) layernorm_kernel<true><<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, w, b, y, row_index, rows, H, eps);
+    else if (op == SHOWO_OP_BF16) layernorm_kernel<false><<<dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, w, b, y, row_index, rows, H, eps);
+    else return set_error_msg(1, "layernorm: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
+extern "C" int showo_layernorm_f32_bf16(const float* x, const float* w, const float* b, uint16_t* y,
+                                        const int32_t* row_index, int rows, int H, float eps, void* stream) {
+    return showo_layernorm_f32_op16(x, w, b, y, row_index, rows, H, eps, SHOWO_OP_BF16, stream);
+}
 
 // ------------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (; i + 3 < n; i += stride) {
         float4 v = *reinterpret_cast<const float4*>(s + i);
         uint2 o;
-        o.x = pack_bf2(v.x, v.y);
-        o.y = pack_bf2(v.z, v.w);
+        o.x = Op16<F16>::pack2(v.x, v.y);
+        o.y = Op16<F16>::pack2(v.z, v.w);
         *reinterpret_cast<uint2*>(d + i) = o;
     }
     // tail (n % 4) handled by the first threads of block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         int64_t j = (n & ~(int64_t)3) + threadIdx.x;
-        d[j] = f2bf(s[j]);
+        d[j] = Op16<F16>::cvt(s[j]);
     }
+}
+// range check of precision 2: elements that read as |x| >= 65504 (a saturated convert leaves exactly 65504) or NaN / inf in IEEE half
+__global__ void count_f16_saturated_kernel(const bf16_t* __restrict__ x, int64_t n, unsigned long long* __restrict__ count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned c = 0;
+    for (; i < n; i += stride) c += (x[i] & 0x7fffu) >= 0x7bffu;  // 0x7bff = 65504; 0x7c00.. = inf / NaN
+    c = (unsigned)wave_sum((float)c);  // < 2^24 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+extern "C" int showo_count_f16_saturated(const uint16_t* x, int64_t n, int64_t* count, void* stream) {
+    if (n <= 0) return 0;
+    if (!x || !count) return set_error_msg(1, "count_f16_saturated: null argument");
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    count_f16_saturated_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(x, n, reinterpret_cast<unsigned long long*>(count));
+    SHOWO_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 // split: x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
 __global__ void split_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n) {
@@ -222,15 +248,20 @@ extern "C" int showo_split_f32_bf16(const float* src, uint16_t* hi, uint16_t* lo
     return 0;
 }
 
-extern "C" int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+extern "C" int showo_cast_f32_op16(const float* src, uint16_t* dst, int64_t n, int op, void* stream) {
     if (n <= 0) return 0;
     if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 7)) return set_error_msg(1, "cast: src must be 16B and dst 8B aligned");
     int64_t groups = (n + 3) / 4;
     int blocks = (int)((groups + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    cast_f32_bf16_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, dst, n);
+    if (op == SHOWO_OP_F16) cast_f32_bf16_kernel<true><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, dst, n);
+    else if (op == SHOWO_OP_BF16) cast_f32_bf16_kernel<false><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, dst, n);
+    else return set_error_msg(1, "cast: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
+}
+extern "C" int showo_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
+    return showo_cast_f32_op16(src, dst, n, SHOWO_OP_BF16, stream);
 }
 
 // embedding gather: one wave per token row, float4 copies.  Out-of-range ids poison the row with NaN so a

@@ -11,8 +11,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-r
 OBJS=""
 PIDS=""
 mkdir -p $BD
-for f in basic gemm gemm2p gemm3w gemm_tn attention attention_bwd train_kernels decode decode_batch prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops precise; do
-  if [ ! -f $BD/$f.o ] || [ $f.hip -nt $BD/$f.o ] || [ common.h -nt $BD/$f.o ] || [ engine.h -nt $BD/$f.o ] || [ gemm_common.h -nt $BD/$f.o ] || [ decode_common.h -nt $BD/$f.o ] || [ prof.h -nt $BD/$f.o ] || [ ../../include/showo_hip.h -nt $BD/$f.o ]; then
+for f in gemm2p gemm2p_f16 gemm3w gemm3w_f16 basic gemm gemm_tn attention attention_bwd train_kernels decode decode_batch prompting sampler vq_kernels engine vq_engine train_engine clip_engine image_ops precise; do
+  if [ ! -f $BD/$f.o ] || [ $f.hip -nt $BD/$f.o ] || [ common.h -nt $BD/$f.o ] || [ engine.h -nt $BD/$f.o ] || [ gemm_common.h -nt $BD/$f.o ] || [ gemm2p_kernel.h -nt $BD/$f.o ] || [ gemm3w_kernel.h -nt $BD/$f.o ] || [ decode_common.h -nt $BD/$f.o ] || [ prof.h -nt $BD/$f.o ] || [ ../../include/showo_hip.h -nt $BD/$f.o ]; then
     rm -f $BD/$f.o
     hipcc $FLAGS -c $f.hip -o $BD/$f.o &
     PIDS="$PIDS $!"

@@ -57,6 +57,56 @@ __device__ inline uint32_t pack_bf2(float lo, float hi) {
 #endif
 }
 
+// ---- the 16-bit OPERAND TYPE of the MFMA / dot2 kernels, as a compile-time property of a kernel instance (round 6) ----------------
+// Op16<false> = bfloat16: the operands of precision 0 (the default) and the (hi, lo) halves of precision 1.
+// Op16<true>  = IEEE binary16 ("fp16", Showo.set_precision(2)): the same instructions at the same rate and peak
+//               (v_mfma_f32_*_f16 / v_dot2_f32_f16, 2.5 PFLOP/s dense) with 11 instead of 8 significand bits -- operand rounding 2^-12
+//               instead of 2^-9, which puts the logits within north_star's 1e-3 of the fp32 reference (oracle/predict_rounding.py)
+//               where bf16 operands sit at 7e-3.  Range 6.1e-5 .. 65504: every convert SATURATES (|x| > 65504 -> +-65504), values below the normal range keep their subnormal encoding (conversions and MFMA operands are not flushed on
+//               gfx950: tools/experiments/probe_f16.hip), and showo_engine_set_range_check counts saturated elements per layer.
+// Buffers stay raw uint16_t (bf16_t) images either way: only the instructions that PRODUCE (pack2 / cvt), CONSUME (mfma16 / mfma32 /
+// dot2) or WIDEN (tof) an element depend on the type; DMA, LDS layouts, swizzles and stores are type-blind.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr float F16_MAX = 65504.0f;
+// one v_med3_f32 per value.  (A NaN comes out as -65504 -- v_med3 returns the minimum when an input is NaN; the fp32 residual stream and
+// the fp32 GEMM accumulators are never converted, so a NaN that reaches x still reaches the logits; the range check counts |x| = 65504.)
+__device__ inline float sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -F16_MAX, F16_MAX); }
+template <bool F16>
+struct Op16;
+template <>
+struct Op16<false> {
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
+    static __device__ __forceinline__ bf16_t cvt(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float tof(bf16_t v) { return bf2f(v); }
+    static __device__ __forceinline__ float lo_of(uint32_t pk) { return __uint_as_float(pk << 16); }          // element 0 / 1 of a packed pair
+    static __device__ __forceinline__ float hi_of(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+    static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float dot2(uint32_t w, uint32_t a, float acc) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, a), acc, false);
+    }
+};
+template <>
+struct Op16<true> {
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        const f32x2_t v = {sat_f16(lo), sat_f16(hi)};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));  // the compiler's own fptrunc (RNE), visible to the hazard recognizer
+    }
+    static __device__ __forceinline__ bf16_t cvt(float f) { return __builtin_bit_cast(bf16_t, (_Float16)sat_f16(f)); }
+    static __device__ __forceinline__ float tof(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ float lo_of(uint32_t pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[0]; }
+    static __device__ __forceinline__ float hi_of(uint32_t pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[1]; }
+    static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t w, uint32_t a, float acc) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w), __builtin_bit_cast(f16x2_t, a), acc, false);
+    }
+};
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -138,6 +188,15 @@ __device__ inline float dot8_bf16(const uint4& w, const uint4& a, float acc) {
     acc = dot2_bf16(w.y, a.y, acc);
     acc = dot2_bf16(w.z, a.z, acc);
     acc = dot2_bf16(w.w, a.w, acc);
+    return acc;
+}
+// the same chain on either operand type (precision 2: v_dot2_f32_f16)
+template <bool F16>
+__device__ inline float dot8_op(const uint4& w, const uint4& a, float acc) {
+    acc = Op16<F16>::dot2(w.x, a.x, acc);
+    acc = Op16<F16>::dot2(w.y, a.y, acc);
+    acc = Op16<F16>::dot2(w.z, a.z, acc);
+    acc = Op16<F16>::dot2(w.w, a.w, acc);
     return acc;
 }
 

@@ -152,7 +152,14 @@ struct showo_engine {
     hipEvent_t ev_pfx = nullptr;
     // accuracy mode (showo_engine_set_precision): 0 = bf16 operands (default, the timed path), 1 = split-bf16 GEMMs + fp32 attention.
     // lo_loaded: GEMM weights whose low halves are current (cleared when somebody rewrites the hi images behind the loader's back).
+    // precision 2 (round 6): IEEE-half ("fp16") operands on the same kernels -- the layer weight images (wqkv / w1 / wd / w2 and the fused
+    // wq1t / wd2) and every 16-bit activation (h, Q, K, V^T, attn, ffn, the KV caches) then hold fp16 bits; img_f16 says which type the
+    // layer images hold RIGHT NOW (set by the loader; a switch between precision 2 and 0 / 1 un-loads the GEMM weights so that the host
+    // uploads them again).  The lm_head stays a split-bf16 product in precision 2 (wlm / wlm_lo / wlm3 + p_hf3, as in precision 1).
     int precision = 0;
+    bool img_f16 = false;
+    bool head3_valid = false;  // wlm3 = [hi | hi | lo] rows of the lm_head matches wlm / wlm_lo
+    int64_t* range_count = nullptr;  // precision 2 range check (showo_engine_set_range_check): device counter of saturated fp16 elements
     std::set<std::string> lo_loaded;
     bf16_t* wlm_lo = nullptr;
     bf16_t *p_hlo = nullptr, *p_actlo = nullptr;                            // low halves of h / hf and of attn | gelu(fc1)

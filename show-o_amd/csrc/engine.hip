@@ -190,14 +190,17 @@ static int copy_f32(float* dst, const float* src, int64_t n, int64_t expect, hip
     return 0;
 }
 // GEMM weight: bf16 image; in accuracy mode also the low half (hi + lo = w to 2^-17; hi is the same RNE rounding either way)
-static int cast_w(showo_engine* e, const std::string& key, bf16_t* dst, bf16_t* dst_lo, const float* src, int64_t n, int64_t expect, hipStream_t s) {
+// Precision 2: the layer weights become IEEE-half images (saturating RNE); the lm_head keeps its (hi, lo) bf16 pair (head_rows_split).
+static int cast_w(showo_engine* e, const std::string& key, bf16_t* dst, bf16_t* dst_lo, const float* src, int64_t n, int64_t expect, hipStream_t s,
+                  bool is_head = false) {
     if (n != expect) return set_error_msg(2, "engine_load: element count mismatch");
-    if (e->precision == 1 && dst_lo) {
+    if ((e->precision == 1 || (e->precision == 2 && is_head)) && dst_lo) {
         int rc = showo_split_f32_bf16(src, dst, dst_lo, n, s);
         if (!rc) e->lo_loaded.insert(key);
         return rc;
     }
-    return showo_cast_f32_bf16(src, dst, n, s);
+    if (!is_head) e->img_f16 = e->precision == 2;
+    return showo_cast_f32_op16(src, dst, n, (e->precision == 2 && !is_head) ? SHOWO_OP_F16 : SHOWO_OP_BF16, s);
 }
 
 extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* src, int64_t n, void* stream) {
@@ -211,7 +214,7 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     if (k == "showo.model.embed_tokens.weight") rc = copy_f32(e->embed, src, n, V * H, s);
     else if (k == "showo.model.final_layernorm.weight") rc = copy_f32(e->fln_w, src, n, H, s);
     else if (k == "showo.model.final_layernorm.bias") rc = copy_f32(e->fln_b, src, n, H, s);
-    else if (k == "showo.lm_head.weight") rc = cast_w(e, k, e->wlm, e->wlm_lo, src, n, V * H, s);
+    else if (k == "showo.lm_head.weight") rc = cast_w(e, k, e->wlm, e->wlm_lo, src, n, V * H, s, true);
     else if (k == "showo.lm_head.bias") rc = copy_f32(e->blm, src, n, V, s);
     else if (k == "rope.cos") rc = copy_f32(e->cosT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
     else if (k == "rope.sin") rc = copy_f32(e->sinT, src, n, (int64_t)e->cfg.max_pos * e->cfg.rotary_dim, s);
@@ -241,6 +244,7 @@ extern "C" int showo_engine_load(showo_engine* e, const char* key, const float* 
     if (rc == 0) e->loaded.insert(k);
     e->fused_valid = false;  // the fused weight images (and with them a cached t2i graph's preconditions) are rebuilt on the next call
     e->px3_valid = false;
+    e->head3_valid = false;
     return rc;
 }
 
@@ -290,7 +294,9 @@ extern "C" int showo_engine_weights_touched(showo_engine* e) {
     if (!e) return set_error_msg(1, "engine: null handle");
     e->fused_valid = false;
     e->px3_valid = false;
+    e->head3_valid = false;
     e->lo_loaded.clear();  // the hi images were rewritten without their low halves: accuracy mode needs a re-upload
+    e->img_f16 = false;    // the trainer writes bf16 images: a precision-2 engine needs a re-upload too (run_layers checks)
     return 0;
 }
 
@@ -474,11 +480,33 @@ static bool precise_fast_shape_ok(const showo_engine* e) {
     return g_precise_fast && e->cfg.rotary_dim == 32 && (3 * e->H) % 256 == 0 && e->H % 64 == 0 && e->F % 64 == 0 && e->H % 4 == 0;
 }
 // ... and its images / workspaces exist (showo_engine_set_precision(e, 1) made them)
-static bool precise_fast_ok(const showo_engine* e) { return precise_fast_shape_ok(e) && e->wlm3 != nullptr; }
+static bool precise_fast_ok(const showo_engine* e) { return precise_fast_shape_ok(e) && e->p_h3 != nullptr; }
 extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
     if (!e) return set_error_msg(1, "engine: null handle");
-    if (precision != 0 && precision != 1) return set_error_msg(1, "engine_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class)");
-    if (precision == 1 && !e->wlm_lo) {  // low halves of every GEMM weight + fp32 workspaces, allocated on first use
+    if (precision < 0 || precision > 2) return set_error_msg(1, "engine_set_precision: 0 = bf16 operands, 1 = split bf16 (fp32-class), 2 = fp16 operands");
+    if (precision == 2 && !e->wlm3) {  // the lm_head of precision 2 is a split-bf16 product: its low half, [hi | hi | lo] image and LayerNorm workspace
+        const int64_t H = e->H, V = e->V, T = e->maxT;
+        int rc = 0;
+        if (!e->wlm_lo) rc |= e->alloc(&e->wlm_lo, V * H);
+        if (!e->p_hf3) rc |= e->alloc(&e->p_hf3, (T + 256) * 3 * H);
+        if (!rc) rc |= e->alloc(&e->wlm3, V * 3 * H);
+        if (rc) { e->release(&e->wlm3); return rc; }
+        e->head3_valid = false;
+    }
+    if ((precision == 2) != (e->precision == 2)) {
+        // the layer weight images change their element type: un-load every GEMM weight so that the host uploads them again
+        // (showo_engine_missing() > 0 until it has); cached t2i graphs are keyed on the precision and simply miss
+        for (auto it = e->loaded.begin(); it != e->loaded.end();) {
+            const std::string& k = *it;
+            const bool gemm_w = k.size() > 7 && k.compare(k.size() - 7, 7, ".weight") == 0 &&
+                                (k.find("_proj.") != std::string::npos || k.find(".dense.") != std::string::npos || k.find(".fc1.") != std::string::npos ||
+                                 k.find(".fc2.") != std::string::npos || k == "showo.lm_head.weight");
+            if (gemm_w) it = e->loaded.erase(it); else ++it;
+        }
+        e->lo_loaded.clear();
+        e->fused_valid = false; e->px3_valid = false; e->head3_valid = false;
+    }
+    if (precision == 1 && !e->p_hlo) {  // low halves of every GEMM weight + fp32 workspaces, allocated on first use
         const int64_t H = e->H, F = e->F, V = e->V, T = e->maxT;
         int rc = 0;
         for (auto& l : e->layers) {
@@ -490,10 +518,10 @@ extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
         rc |= e->alloc(&e->p_hlo, T * H); rc |= e->alloc(&e->p_actlo, T * F);
         rc |= e->alloc(&e->p_qkv, T * 3 * H); rc |= e->alloc(&e->p_f, T * F);
         rc |= e->alloc(&e->p_Q, T * H); rc |= e->alloc(&e->p_K, T * H); rc |= e->alloc(&e->p_V, T * H); rc |= e->alloc(&e->p_a, T * H);
-        rc |= e->alloc(&e->wlm_lo, V * H);
+        if (!e->wlm_lo) rc |= e->alloc(&e->wlm_lo, V * H);
         if (rc) return rc;
     }
-    if (precision == 1 && precise_fast_shape_ok(e) && !e->wlm3) {  // K-concatenated split images + workspaces of the production-kernel path
+    if (precision == 1 && precise_fast_shape_ok(e) && !e->p_h3) {  // K-concatenated split images + workspaces of the production-kernel path
         const int64_t H = e->H, F = e->F, V = e->V, T = e->maxT, HF = H + F;
         const int64_t Lp = ((e->cfg.max_seq + 63) / 64) * 64;
         int rc = 0;
@@ -503,12 +531,18 @@ extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
         }
         const int64_t t1 = (3 * H + F) * 3 * H, t2 = H * 3 * HF;
         rc |= e->alloc(&e->wtmp3, t1 > t2 ? t1 : t2);
-        rc |= e->alloc(&e->p_h3, (T + 256) * 3 * H); rc |= e->alloc(&e->p_hf3, (T + 256) * 3 * H);
+        rc |= e->alloc(&e->p_h3, (T + 256) * 3 * H);
+        if (!e->p_hf3) rc |= e->alloc(&e->p_hf3, (T + 256) * 3 * H);
         rc |= e->alloc(&e->p_act, (T + 256) * 2 * HF);
         rc |= e->alloc(&e->p_Qlo, T * H); rc |= e->alloc(&e->p_Klo, T * H);
         rc |= e->alloc(&e->p_Vtlo, (int64_t)e->cfg.max_batch * H * Lp);
-        rc |= e->alloc(&e->wlm3, V * 3 * H);
-        if (rc) return rc;
+        if (!e->wlm3) rc |= e->alloc(&e->wlm3, V * 3 * H);
+        if (rc) {  // a partial set must not survive (wlm3 == NULL would re-allocate everything at the next call)
+            for (auto& l : e->layers) { e->release(&l.wq1x3); e->release(&l.wd2x3); }
+            e->release(&e->wtmp3); e->release(&e->p_h3); e->release(&e->p_act); e->release(&e->p_Qlo); e->release(&e->p_Klo);
+            e->release(&e->p_Vtlo);
+            return rc;
+        }
         hipMemset(e->p_Vtlo, 0, (size_t)e->cfg.max_batch * H * Lp * sizeof(bf16_t));
         e->px3_valid = false;
     }
@@ -520,7 +554,7 @@ extern "C" int showo_engine_set_precision(showo_engine* e, int precision) {
 extern "C" int showo_engine_precise_fast(const showo_engine* e) { return e && precise_fast_ok(e) ? 1 : 0; }
 // 1 when every GEMM weight has a current low half (q, k, v, dense, fc1, fc2 per layer + lm_head), i.e. precision 1 can run
 extern "C" int showo_engine_precise_ready(const showo_engine* e) {
-    return e && e->wlm_lo && (int)e->lo_loaded.size() == e->nL * 6 + 1;
+    return e && e->wlm_lo && e->p_hlo && (int)e->lo_loaded.size() == e->nL * 6 + 1;
 }
 extern "C" int showo_engine_get_precision(const showo_engine* e) { return e ? e->precision : -1; }
 
@@ -562,6 +596,19 @@ static int head_rows_precise(showo_engine* e, const int32_t* rows, int nrows, in
 }
 
 static int fused_sync(showo_engine* e, hipStream_t s);
+// [hi | hi | lo] rows of the lm_head (precision 1 and 2: the head is a split-bf16 product in both); never inside a capture
+static int head3_sync(showo_engine* e, hipStream_t s) {
+    if (e->head3_valid) return 0;
+    if (!e->wlm3 || !e->wlm_lo || !e->lo_loaded.count("showo.lm_head.weight"))
+        return set_error_msg(4, "engine: the low half of the lm_head is missing or stale (the weights were loaded before "
+                                "showo_engine_set_precision(e, 1 | 2), or rewritten by the trainer): upload the weights again");
+    const int64_t H = e->H, V = e->V;
+    SHOWO_CHECK_HIP(hipMemcpy2DAsync(e->wlm3, (size_t)3 * H * 2, e->wlm, (size_t)H * 2, (size_t)H * 2, (size_t)V, hipMemcpyDeviceToDevice, s));
+    SHOWO_CHECK_HIP(hipMemcpy2DAsync(e->wlm3 + H, (size_t)3 * H * 2, e->wlm, (size_t)H * 2, (size_t)H * 2, (size_t)V, hipMemcpyDeviceToDevice, s));
+    SHOWO_CHECK_HIP(hipMemcpy2DAsync(e->wlm3 + 2 * H, (size_t)3 * H * 2, e->wlm_lo, (size_t)H * 2, (size_t)H * 2, (size_t)V, hipMemcpyDeviceToDevice, s));
+    e->head3_valid = true;
+    return 0;
+}
 // K-concatenated split images of every GEMM weight (see "accuracy mode" above), rebuilt after any weight load; never inside a capture
 static int precise_sync(showo_engine* e, hipStream_t s) {
     if (e->px3_valid) return 0;
@@ -586,9 +633,7 @@ static int precise_sync(showo_engine* e, hipStream_t s) {
         }
         TRY(showo_gemm_tile_weight(cat, (int)(3 * HF), (int)H, (int)(3 * HF), l.wd2x3, s));
     }
-    TRY(cp(e->wlm3, 3 * H, e->wlm, H, H, V));
-    TRY(cp(e->wlm3 + H, 3 * H, e->wlm, H, H, V));
-    TRY(cp(e->wlm3 + 2 * H, 3 * H, e->wlm_lo, H, H, V));
+    TRY(head3_sync(e, s));
     e->px3_valid = true;
     return 0;
 }
@@ -623,15 +668,34 @@ static int run_layers_precise_fast(showo_engine* e, int B, int L, int pos0, cons
     }
     return 0;
 }
+// final LayerNorm -> [hi | lo | hi], lm_head rows [hi | hi | lo]: ONE bf16 GEMM over 3H (precision 1 on the production kernels, and the
+// head of precision 2: final hidden state and lm_head weight are then not rounding points at all, oracle/predict_rounding.py)
 static int head_rows_precise_fast(showo_engine* e, const int32_t* rows, int nrows, int col0, int ncols, float* logits, hipStream_t s) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cs);
-    if (!e->px3_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine (precision 1): split weight images must be built before a stream capture");
-    TRY(precise_sync(e, s));
+    if (e->precision == 2) {
+        if (!e->head3_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine (precision 2): the lm_head image must be built before a stream capture");
+        TRY(head3_sync(e, s));
+    } else {
+        if (!e->px3_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine (precision 1): split weight images must be built before a stream capture");
+        TRY(precise_sync(e, s));
+    }
     const int H = e->H;
     TRY(showo::precise_ln_split3(e->x, e->fln_w, e->fln_b, rows, e->p_hf3, nrows, H, e->cfg.ln_eps, s));
     return showo_gemm_bf16(e->p_hf3, 3 * H, e->wlm3 + (int64_t)col0 * 3 * H, 3 * H, e->blm + col0, 0, logits, ncols, nullptr, 0, nrows, ncols,
                            3 * H, SHOWO_EPI_F32, s);
+}
+
+// precision 2 range check (showo_engine_set_range_check): count the elements of a freshly written 16-bit activation that sit at the
+// fp16 saturation value (or are inf / NaN).  Off (one pointer test) unless a counter is registered; never inside the timed path.
+static int range_check(showo_engine* e, const bf16_t* x, int64_t n, hipStream_t s) {
+    if (!e->range_count || e->precision != 2) return 0;
+    return showo_count_f16_saturated(x, n, e->range_count, s);
+}
+extern "C" int showo_engine_set_range_check(showo_engine* e, int64_t* count) {
+    if (!e) return set_error_msg(1, "engine: null handle");
+    e->range_count = count;
+    return 0;
 }
 
 static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv, const int32_t* iv, const int32_t* flag,
@@ -643,10 +707,16 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         if (pos0 != 0 || kv.k != e->K) return set_error_msg(1, "engine (precision 1): KV-cached calls need the production-kernel form of accuracy mode (showo_engine_precise_fast)");
         return run_layers_precise(e, B, L, iv, flag, dense, s);
     }
+    // precision 2: the same launches with IEEE-half operands (op = SHOWO_OP_F16 on every 16-bit operand, weight image and activation)
+    const int op = e->precision == 2 ? SHOWO_OP_F16 : SHOWO_OP_BF16;
+    if ((op == SHOWO_OP_F16) != e->img_f16)
+        return set_error_msg(4, "engine: the weight images hold the other 16-bit type (loaded under another precision, or rewritten by the "
+                                "trainer): upload the weights again");
     TRY(collect_x(e, 0, T, s));
     const int Lk = pos0 + L;
     const int Lcap = kv.Lcap, Lp = kv.Lp;
-    if (T == 1 && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
+    // (the fused three-launch decode layer of decode.hip has bf16 instances only: precision 2 decodes on the general path below)
+    if (T == 1 && !op && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
         // AR decode step (decode.hip): three launches per layer.  Forked layer (opt-in, SHOWO_DECODE_FORK=1; measured SLOWER: 705-711 vs
         // 843-846 tokens/s in one box, gpurun_out/bench_mmu_r2k_*: every fork / join edge of the per-token graph costs more than the
         // overlap buys, like the side-stream weight prefetch of round 1): fc1 and fc2 do not depend on the attention, so their 67 MB
@@ -748,17 +818,21 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             showo::Layer& l = e->layers[li];
             bf16_t* Kd = kv.k + li * kv.k_lstride;
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
-            TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
+            TRY(showo_layernorm_f32_op16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, op, s));
+            TRY(range_check(e, e->h, (int64_t)T * H, s));
             if (pf & 1) {
                 SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
                 SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
                 TRY(showo::mall_warm(l.wd2, wd2_bytes, mall_blocks, nullptr, e->side));
                 SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
             }
-            TRY(showo_gemm_qkv_fc1_bf16(e->h, H, e->fused_tiled ? l.wq1t : l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT,
+            TRY(showo_gemm_qkv_fc1_op16(e->h, H, e->fused_tiled ? l.wq1t : l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT,
                                         e->sinT, e->Q, Kd, Vd, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp,
-                                        e->fused_tiled ? 1 : 0, s));
-            TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
+                                        e->fused_tiled ? 1 : 0, op, s));
+            TRY(range_check(e, e->Q, (int64_t)T * H, s));
+            TRY(range_check(e, e->ffn, (int64_t)T * F, s));
+            TRY(showo_attn_fwd_op16(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, op, s));
+            TRY(range_check(e, e->attn, (int64_t)T * H, s));
             if (pf & 1) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
             const bool pf2 = (pf & 2) && li + 1 < e->nL;
             if (pf2) {
@@ -768,8 +842,8 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
                 TRY(showo::mall_warm(e->fused_tiled ? nx.wq1t : nx.wqkv, wq1_bytes, mall_blocks, nullptr, e->side));
                 SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
             }
-            TRY(showo_gemm_kcat_bf16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32,
-                                     e->fused_tiled ? 1 : 0, s));
+            TRY(showo_gemm_kcat_op16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32,
+                                     e->fused_tiled ? 1 : 0, op, s));
             if (pf2) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
             TRY(collect_x(e, li + 1, T, s));
         }
@@ -789,7 +863,8 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         showo::Layer& l = e->layers[li];
         bf16_t* Kd = kv.k + li * kv.k_lstride;
         bf16_t* Vd = kv.vt + li * kv.v_lstride;
-        TRY(showo_layernorm_f32_bf16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, s));
+        TRY(showo_layernorm_f32_op16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, op, s));
+        TRY(range_check(e, e->h, (int64_t)T * H, s));
         // Phi's block is parallel (phi.py:774-790): the attention branch (qkv -> attention -> dense) and fc1 both read the
         // same LayerNorm output.  fc1 goes to a second stream so that its tiles fill the CUs the other branch leaves idle
         // (partial last rounds of the GEMMs, the latency-bound attention kernel); fc2 follows on the main stream once both
@@ -798,23 +873,26 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         if (fork) {
             SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
             SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-            TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, e->side));
+            TRY(showo_gemm_op16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, op, e->side));
             SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
         }
         if (T >= 256 && e->cfg.rotary_dim == 32) {
             // prefill / t2i: one kernel (the projection's epilogue normalises, rotates and relayouts the fp32 accumulators)
-            TRY(showo_gemm_qkv_bf16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
-                                    B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+            TRY(showo_gemm_qkv_fc1_op16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
+                                        nullptr, 0, 0, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, 0, op, s));
         } else {
-            TRY(showo_gemm_bf16(e->h, H, l.wqkv, H, l.bqkv, 0, e->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, s));
-            TRY(showo_qk_prep(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd, B, L, nH,
-                              e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+            TRY(showo_gemm_op16(e->h, H, l.wqkv, H, l.bqkv, 0, e->qkv, 3 * H, nullptr, 0, T, 3 * H, H, SHOWO_EPI_BF16, op, s));
+            TRY(range_check(e, e->qkv, (int64_t)T * 3 * H, s));
+            TRY(showo_qk_prep_op16(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd, B, L, nH,
+                                   e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, op, s));
         }
-        TRY(showo_attn_fwd(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, s));
-        TRY(showo_gemm_bf16(e->attn, H, l.wd, H, l.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, s));
+        TRY(showo_attn_fwd_op16(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, op, s));
+        TRY(range_check(e, e->attn, (int64_t)T * H, s));
+        TRY(showo_gemm_op16(e->attn, H, l.wd, H, l.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, op, s));
         if (fork) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
-        else TRY(showo_gemm_bf16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, s));
-        TRY(showo_gemm_bf16(e->ffn, F, l.w2, F, l.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, s));
+        else TRY(showo_gemm_op16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, op, s));
+        TRY(range_check(e, e->ffn, (int64_t)T * F, s));
+        TRY(showo_gemm_op16(e->ffn, F, l.w2, F, l.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, op, s));
         TRY(collect_x(e, li + 1, T, s));
     }
     return 0;
@@ -852,6 +930,7 @@ static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, 
     if (col0 < 0 || ncols <= 0 || col0 + ncols > e->V) return set_error_msg(1, "engine: bad vocabulary slice");
     if (e->precision == 1) return precise_fast_ok(e) ? head_rows_precise_fast(e, rows, nrows, col0, ncols, logits, s)
                                                        : head_rows_precise(e, rows, nrows, col0, ncols, logits, s);
+    if (e->precision == 2) return head_rows_precise_fast(e, rows, nrows, col0, ncols, logits, s);  // the split-bf16 head (any shape)
     if (nrows == 1 && !rows && showo::g_decode_impl == 0 && showo::decode_fused_shapes_ok(e->H, e->F))  // decode step: LN + lm_head in one launch
         return showo::decode_ln_gemv2(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, e->H, e->wlm + (int64_t)col0 * e->H, e->blm + col0,
                                       nullptr, logits, ncols, nullptr, nullptr, nullptr, 0, s);
@@ -915,12 +994,13 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     const int La = L - prefix;
     const int LpC = ((L + 63) / 64) * 64;
     const bool pfast = e->precision == 1 && precise_fast_ok(e);
-    const bool reuse_ok = (e->precision == 0 || pfast) && !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
+    const bool reuse_ok = (e->precision == 0 || e->precision == 2 || pfast) && !(use_graph & 2) && steps > 1 && prefix >= 1 && La >= N + 1 && nseq * La >= 1;
     hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cs0);
     if (cs0 != hipStreamCaptureStatusNone) return set_error_msg(7, "t2i_generate: the call captures its own graph; do not call it inside a stream capture");
     TRY(fused_sync(e, s));  // weight images of the fused launches: rebuilt here (never inside a capture), so cached graphs stay valid
     if (pfast) TRY(precise_sync(e, s));
+    if (e->precision == 2) TRY(head3_sync(e, s));
     if (reuse_ok && !e->pfx_flag) {
         TRY(e->alloc(&e->pfx_flag, 4));
         SHOWO_CHECK_HIP(hipHostMalloc((void**)&e->pfx_host, 64, hipHostMallocDefault));
@@ -991,7 +1071,7 @@ extern "C" int showo_engine_t2i_generate(showo_engine* e, int64_t* ids_cond, int
     // once (first-use attributes, GEMM tile tuning) outside the capture; step 0 always runs eagerly.  Not combined with per-launch
     // event timing.
     const int n_eager = reuse ? 2 : 1;
-    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query() && (e->precision == 0 || pfast);
+    const bool graph = (use_graph & 1) && steps > n_eager && !showo::g_prof_on_query() && (e->precision == 0 || e->precision == 2 || pfast);
     if (!graph) {
         for (int step = 0; step < steps; ++step) TRY(denoise_step(step, step == 0 || !reuse));
     } else {

@@ -104,7 +104,7 @@ struct ConvLoader {
 // SPLIT: both operands come as (hi, lo) bf16 pairs with x = hi + lo to ~2^-17; the product is accumulated as
 // hi*hi + hi*lo + lo*hi in the fp32 MFMA accumulators (3 MFMAs per tile pair, ~fp32-class accuracy at 3/16 of the
 // fp32-MFMA cost).  Used by the VQGAN path, whose token ids must track the fp32 reference (SURVEY.md §7 hard parts).
-template <int EPI, class Loader, bool SPLIT>
+template <int EPI, class Loader, bool SPLIT, bool F16 = false>  // F16: IEEE-half operands (common.h Op16; plain form only)
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
     Loader ld = ld_in;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = Op16<F16>::mfma16(wf[i], af[j], acc[i][j]);
             if (SPLIT) {
                 const bf16_t* bWl = sWl + cur * LDS_TILE;
                 const bf16_t* bAl = sAl + cur * LDS_TILE;
@@ -244,16 +244,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, Loader ld_in) {
         float bn[4];
         load_bias4(g, n, bn);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) store_frag<EPI>(g, acc[i][j], m0 + wm * 64 + j * 16 + fr, n, bn);
+        for (int j = 0; j < 4; ++j) store_frag<EPI, F16>(g, acc[i][j], m0 + wm * 64 + j * 16 + fr, n, bn);
     }
 }
 
 constexpr int SMEM_BYTES = 4 * LDS_TILE * 2;  // 64 KiB
 
-template <int EPI, class Loader, bool SPLIT = false>
+template <int EPI, class Loader, bool SPLIT = false, bool F16 = false>
 int launch(const GemmArgs& g, const Loader& ld, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm_kernel<EPI, Loader, SPLIT>;
+    auto kfn = gemm_kernel<EPI, Loader, SPLIT, F16>;
     const int smem = SMEM_BYTES;  // 64 KiB in both modes (SPLIT: 4 single-buffered images)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -265,6 +265,17 @@ int launch(const GemmArgs& g, const Loader& ld, hipStream_t s) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "gemm launch", __FILE__, __LINE__);
     return 0;
+}
+
+// IEEE-half operands (precision 2) on the 128^2 kernel: linear loader only (the convolutions have their own split-precision path)
+int dispatch_f16(const GemmArgs& g, const LinearLoader& ld, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case SHOWO_EPI_BF16: return launch<SHOWO_EPI_BF16, LinearLoader, false, true>(g, ld, s);
+        case SHOWO_EPI_GELU_BF16: return launch<SHOWO_EPI_GELU_BF16, LinearLoader, false, true>(g, ld, s);
+        case SHOWO_EPI_F32: return launch<SHOWO_EPI_F32, LinearLoader, false, true>(g, ld, s);
+        case SHOWO_EPI_RESID_F32: return launch<SHOWO_EPI_RESID_F32, LinearLoader, false, true>(g, ld, s);
+    }
+    return set_error_msg(1, "gemm: unknown epilogue");
 }
 
 template <class Loader>
@@ -476,7 +487,7 @@ unsigned long long* g_gemm_dbg = nullptr;
 // epilogues as the tile kernels.  HBM-bound: N*K*2 bytes per launch (2.9 GB per decoded token over the whole model).
 // =====================================================================================================
 constexpr int GV_COLS = 1;  // output columns per wave (1: most waves in flight -- the kernel is latency x concurrency bound)
-template <int EPI, int MR>
+template <int EPI, int MR, bool F16 = false>
 __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = (blockIdx.x * 4 + wave) * GV_COLS;
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
                 if (m >= g.M) break;
                 const uint4 av = *reinterpret_cast<const uint4*>(g.A + (int64_t)m * g.lda + k);
 #pragma unroll
-                for (int c = 0; c < GV_COLS; ++c) acc[m][c] = dot8_bf16(wv[u][c], av, acc[m][c]);  // common.h: the decode GEMVs' order
+                for (int c = 0; c < GV_COLS; ++c) acc[m][c] = dot8_op<F16>(wv[u][c], av, acc[m][c]);  // common.h: the decode GEMVs' order
             }
         }
     }
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
                 if (g.bias) v += g.bias_per_row ? g.bias[m] : g.bias[n];
                 if (EPI == SHOWO_EPI_GELU_BF16) v = gelu_new_fast(v);
                 if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
-                    reinterpret_cast<bf16_t*>(g.out)[(int64_t)m * g.ldo + n] = f2bf(v);
+                    reinterpret_cast<bf16_t*>(g.out)[(int64_t)m * g.ldo + n] = Op16<F16>::cvt(v);
                 } else {
                     if (EPI == SHOWO_EPI_RESID_F32) v += g.resid[(int64_t)m * g.ldr + n];
                     reinterpret_cast<float*>(g.out)[(int64_t)m * g.ldo + n] = v;
@@ -537,17 +548,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemmArgs g) {
     }
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 int launch_gemv(const GemmArgs& g, hipStream_t s) {
     const int blocks = (g.N + 4 * GV_COLS - 1) / (4 * GV_COLS);
-    if (g.M <= 1) gemv_kernel<EPI, 1><<<dim3(blocks), dim3(256), 0, s>>>(g);
-    else if (g.M <= 4) gemv_kernel<EPI, 4><<<dim3(blocks), dim3(256), 0, s>>>(g);
-    else gemv_kernel<EPI, 8><<<dim3(blocks), dim3(256), 0, s>>>(g);
+    if (g.M <= 1) gemv_kernel<EPI, 1, F16><<<dim3(blocks), dim3(256), 0, s>>>(g);
+    else if (g.M <= 4) gemv_kernel<EPI, 4, F16><<<dim3(blocks), dim3(256), 0, s>>>(g);
+    else gemv_kernel<EPI, 8, F16><<<dim3(blocks), dim3(256), 0, s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "gemv launch", __FILE__, __LINE__);
     return 0;
 }
 int dispatch_gemv(const GemmArgs& g, int epilogue, hipStream_t s) {
+    if (g.op) {
+        switch (epilogue) {
+            case SHOWO_EPI_BF16: return launch_gemv<SHOWO_EPI_BF16, true>(g, s);
+            case SHOWO_EPI_GELU_BF16: return launch_gemv<SHOWO_EPI_GELU_BF16, true>(g, s);
+            case SHOWO_EPI_F32: return launch_gemv<SHOWO_EPI_F32, true>(g, s);
+            case SHOWO_EPI_RESID_F32: return launch_gemv<SHOWO_EPI_RESID_F32, true>(g, s);
+        }
+        return set_error_msg(1, "gemm: unknown epilogue");
+    }
     switch (epilogue) {
         case SHOWO_EPI_BF16: return launch_gemv<SHOWO_EPI_BF16>(g, s);
         case SHOWO_EPI_GELU_BF16: return launch_gemv<SHOWO_EPI_GELU_BF16>(g, s);
@@ -593,10 +613,11 @@ extern "C" int showo_gemm_tune(int gn, int flags, unsigned long long* dbg) {
     return 0;
 }
 
-extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
-                               void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue,
-                               void* stream) {
+static int gemm_op16_impl(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
+                          void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, int op,
+                          void* stream) {
     if (M <= 0 || N <= 0) return 0;
+    if (op != SHOWO_OP_BF16 && op != SHOWO_OP_F16) return set_error_msg(1, "gemm: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
     if (K <= 0 || (K % BK) != 0) return set_error_msg(1, "gemm: K must be a positive multiple of 64");
     if ((lda % 8) || (ldw % 8) || (((uintptr_t)A) & 15) || (((uintptr_t)W) & 15))
         return set_error_msg(1, "gemm: A/W must be 16B aligned with lda,ldw multiples of 8");
@@ -605,6 +626,7 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.Wlo = nullptr; g.bias = bias; g.bias_per_row = bias_per_row;
     g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
     g.gn = 1; g.flags = 0; g.dbg = nullptr;
+    g.op = op;
     bool f32 = (epilogue == SHOWO_EPI_F32 || epilogue == SHOWO_EPI_RESID_F32);
     uintptr_t align = f32 ? 15 : 7;
     g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & align) == 0);
@@ -618,12 +640,25 @@ extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, in
     if (impl == 6 && M <= 8 && (K % 8) == 0) return dispatch_gemv(g, epilogue, (hipStream_t)stream);
     if (impl == 6) impl = 1;
     if (impl == 5) return gemm2p_dispatch(g, epilogue, (hipStream_t)stream);
-    if (impl == 2) {
+    if (impl == 2 && !op) {  // (the 256^2 A/B rung has bf16 instances only)
         LinearPtr lp;
         lp.A = A; lp.lda = lda; lp.M = M;
         return dispatch2(g, lp, epilogue, (hipStream_t)stream);
     }
+    if (op) return dispatch_f16(g, ld, epilogue, (hipStream_t)stream);
     return dispatch(g, ld, epilogue, (hipStream_t)stream);
+}
+
+extern "C" int showo_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
+                               void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue,
+                               void* stream) {
+    return gemm_op16_impl(A, lda, W, ldw, bias, bias_per_row, out, ldo, resid, ldr, M, N, K, epilogue, SHOWO_OP_BF16, stream);
+}
+// the same GEMM on either 16-bit operand type (op = SHOWO_OP_BF16 | SHOWO_OP_F16: A, W and a 16-bit output are of that type)
+extern "C" int showo_gemm_op16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int bias_per_row,
+                               void* out, int ldo, const float* resid, int ldr, int M, int N, int K, int epilogue, int op,
+                               void* stream) {
+    return gemm_op16_impl(A, lda, W, ldw, bias, bias_per_row, out, ldo, resid, ldr, M, N, K, epilogue, op, stream);
 }
 
 // ---- tiled weight layout of the production kernel: [ceil(N/256)][K/64][256][64] bf16; inside a 32 KiB block row r holds its
@@ -666,7 +701,7 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
                          uint16_t* Q, uint16_t* K, uint16_t* Vt, int B, int L, int nH, int rot, float eps, int pos0, int Lcap, int Lp,
                          uint16_t* ffn_out, int ldf, int F, int w_tiled, void* stream, uint16_t* raw_qkv = nullptr, int ldraw = 0,
                          uint16_t* ffn_pre = nullptr, int Kcat = 0, uint16_t* Qlo = nullptr, uint16_t* Klo = nullptr, uint16_t* Vtlo = nullptr,
-                         uint16_t* ffn_lo = nullptr) {
+                         uint16_t* ffn_lo = nullptr, int op = 0) {
     const int M = B * L, Nq = 3 * nH * 64, Kd = Kcat > 0 ? Kcat : nH * 64;
     const bool split = Qlo != nullptr;
     const int N = Nq + (ffn_out ? F : 0);
@@ -696,6 +731,9 @@ static int gemm_qkv_impl(const uint16_t* A, int lda, const uint16_t* Wqkv, int l
         g.pre = ffn_pre;
     }
     g.wtiled = w_tiled ? 1 : 0;
+    if (op != SHOWO_OP_BF16 && op != SHOWO_OP_F16) return set_error_msg(1, "gemm_qkv: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
+    if (op && (split || raw_qkv || ffn_pre)) return set_error_msg(1, "gemm_qkv: the (hi, lo) and save-for-backward forms have bf16 operands only");
+    g.op = op;
     if (split) {
         if (!Klo || !Vtlo || !ffn_lo || !ffn_out || raw_qkv || ffn_pre || (((uintptr_t)ffn_lo) & 7))
             return set_error_msg(1, "gemm_qkv_fc1_split: Qlo, Klo, Vtlo, ffn_lo (8B aligned) and ffn_out required; no save-for-backward outputs");
@@ -721,6 +759,17 @@ extern "C" int showo_gemm_qkv_fc1_bf16(const uint16_t* A, int lda, const uint16_
     if (!ffn_out) return set_error_msg(1, "gemm_qkv_fc1: ffn_out required");
     return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
                          pos0, Lcap, Lp, ffn_out, ldf, F, w_tiled, stream);
+}
+
+// showo_gemm_qkv_bf16 / showo_gemm_qkv_fc1_bf16 on either 16-bit operand type (ffn_out == NULL: the projection alone)
+extern "C" int showo_gemm_qkv_fc1_op16(const uint16_t* A, int lda, const uint16_t* Wqkv_fc1, int ldw, const float* bias,
+                                       const float* qln_w, const float* qln_b, const float* kln_w, const float* kln_b,
+                                       const float* cos_tab, const float* sin_tab, uint16_t* Q, uint16_t* K, uint16_t* Vt,
+                                       uint16_t* ffn_out, int ldf, int F, int B, int L, int nH, int rot, float eps, int pos0,
+                                       int Lcap, int Lp, int w_tiled, int op, void* stream) {
+    return gemm_qkv_impl(A, lda, Wqkv_fc1, ldw, bias, qln_w, qln_b, kln_w, kln_b, cos_tab, sin_tab, Q, K, Vt, B, L, nH, rot, eps,
+                         pos0, Lcap, Lp, ffn_out, ffn_out ? ldf : 0, ffn_out ? F : 0, ffn_out ? w_tiled : 0, stream, nullptr, 0, nullptr, 0,
+                         nullptr, nullptr, nullptr, nullptr, op);
 }
 
 // Accuracy-mode form of the same launch (showo_engine_set_precision 1 on the production kernel).  The operands are K-CONCATENATED
@@ -758,10 +807,11 @@ extern "C" int showo_gemm_qkv_fc1_save_bf16(const uint16_t* A, int lda, const ui
 // K-concatenated GEMM: out[M,N] = epilogue([A0 | A1] [W0 | W1]^T + bias), A0 [M,K0] (lda0), A1 [M,K1] (lda1), weight rows
 // [W0[n,:] | W1[n,:]] (ldw >= K0 + K1).  Phi's parallel block adds dense(attn) and fc2(ffn) into the same residual row
 // (models/phi.py:774-790): x += [attn | ffn] [Wd | W2]^T + (bd + b2) is ONE launch with one residual read-modify-write.
-extern "C" int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W,
-                                    int ldw, const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N,
-                                    int epilogue, int w_tiled, void* stream) {
+static int gemm_kcat_impl(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W,
+                          int ldw, const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N,
+                          int epilogue, int w_tiled, int op, void* stream) {
     if (M <= 0 || N <= 0) return 0;
+    if (op != SHOWO_OP_BF16 && op != SHOWO_OP_F16) return set_error_msg(1, "gemm_kcat: op must be SHOWO_OP_BF16 or SHOWO_OP_F16");
     if (K0 <= 0 || K1 <= 0 || (K0 % BK) || (K1 % BK)) return set_error_msg(1, "gemm_kcat: K0, K1 must be positive multiples of 64");
     if (!A0 || !A1 || !W) return set_error_msg(1, "gemm_kcat: null operand");
     if ((lda0 % 8) || (lda1 % 8) || (ldw % 8) || (((uintptr_t)A0) & 15) || (((uintptr_t)A1) & 15) || (((uintptr_t)W) & 15))
@@ -776,12 +826,23 @@ extern "C" int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const 
     g.gn = 1; g.flags = 0; g.dbg = nullptr;
     g.A2 = A1; g.lda2 = lda1; g.Ksplit = K0;
     g.wtiled = w_tiled ? 1 : 0;
+    g.op = op;
     if (w_tiled && ldw != K0 + K1) return set_error_msg(1, "gemm_kcat: a tiled weight has ldw == K0 + K1");
     const bool f32 = (epilogue == SHOWO_EPI_F32 || epilogue == SHOWO_EPI_RESID_F32);
     g.vec_out = ((ldo % 4) == 0) && ((((uintptr_t)out) & (f32 ? 15 : 7)) == 0);
     if (epilogue == SHOWO_EPI_RESID_F32) g.vec_out = g.vec_out && ((ldr % 4) == 0) && ((((uintptr_t)resid) & 15) == 0);
     ProfScope prof(PROF_GEMM, 2.0 * M * N * (K0 + K1), (hipStream_t)stream);
     return gemm2p_dispatch(g, epilogue, (hipStream_t)stream);
+}
+extern "C" int showo_gemm_kcat_bf16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W,
+                                    int ldw, const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N,
+                                    int epilogue, int w_tiled, void* stream) {
+    return gemm_kcat_impl(A0, lda0, K0, A1, lda1, K1, W, ldw, bias, out, ldo, resid, ldr, M, N, epilogue, w_tiled, SHOWO_OP_BF16, stream);
+}
+extern "C" int showo_gemm_kcat_op16(const uint16_t* A0, int lda0, int K0, const uint16_t* A1, int lda1, int K1, const uint16_t* W,
+                                    int ldw, const float* bias, void* out, int ldo, const float* resid, int ldr, int M, int N,
+                                    int epilogue, int w_tiled, int op, void* stream) {
+    return gemm_kcat_impl(A0, lda0, K0, A1, lda1, K1, W, ldw, bias, out, ldo, resid, ldr, M, N, epilogue, w_tiled, op, stream);
 }
 
 extern "C" int showo_conv3x3_bf16(const uint16_t* x, const uint16_t* w, const float* bias, const float* resid, float* out,

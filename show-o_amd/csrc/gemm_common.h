@@ -50,6 +50,9 @@ struct GemmArgs {
     // EPI_QKV_SPLIT only (accuracy mode on the production kernel): every bf16 output also gets its LOW half -- value - bf16(value),
     // rounded to bf16 -- at the same index of a second image, so that hi + lo carries the fp32 accumulator to 2^-17
     bf16_t *Qlo = nullptr, *Klo = nullptr, *Vtlo = nullptr, *out2lo = nullptr;
+    // 16-bit operand type of A, W and of every 16-bit output (common.h Op16): 0 = bfloat16, 1 = IEEE half (SHOWO_OP_F16).  Host-side
+    // selector of the kernel instance; the device code carries it as the template parameter F16.
+    int op = 0;
 };
 
 constexpr int EPI_QKV = 4;  // internal epilogue code of showo_gemm_qkv_bf16
@@ -69,7 +72,7 @@ static __device__ inline void load_bias4(const GemmArgs& g, int n, float (&bn)[4
 }
 
 // one MFMA C fragment: this lane holds out[m][n .. n+3]
-template <int EPI>
+template <int EPI, bool F16 = false>
 static __device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, int m, int n, const float (&bn)[4]) {
     if (m >= g.M || n >= g.N) return;
     float v[4];
@@ -85,13 +88,13 @@ static __device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, in
         bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
         if (full) {
             uint2 pk;
-            pk.x = pack_bf2(v[0], v[1]);
-            pk.y = pack_bf2(v[2], v[3]);
+            pk.x = Op16<F16>::pack2(v[0], v[1]);
+            pk.y = Op16<F16>::pack2(v[2], v[3]);
             *reinterpret_cast<uint2*>(o) = pk;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (n + r < g.N) o[r] = f2bf(v[r]);
+                if (n + r < g.N) o[r] = Op16<F16>::cvt(v[r]);
         }
     } else {
         float* o = reinterpret_cast<float*>(g.out) + (int64_t)m * g.ldo + n;
@@ -199,7 +202,7 @@ static __device__ __forceinline__ bool splitk_exchange(const GemmArgs& g, f32x4 
 // Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> vmcnt(0) -> barrier -> one lane: agent release fence ->
 // arrival ticket; then ONE relaxed poll loop -> ONE agent acquire fence -> barrier -> plain loads.  tick[tile] counts arrivals,
 // tick[2048 + tile] departures; the last block to leave zeroes both for the next launch on this stream.
-template <int EPI, int MF, int NFS>
+template <int EPI, int MF, int NFS, bool F16 = false>
 static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int split, int n0, int wn, int mrow0,
                                                           int fr, int fg) {
     const int tid = threadIdx.x;
@@ -254,7 +257,7 @@ static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32
                 const float4 v = base[(size_t)sp * NFS * 512 + (i * MF + j) * 512 + tid];
                 sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
             }
-            store_frag<EPI>(g, sum, mrow0 + j * 16 + fr, n, bn);
+            store_frag<EPI, F16>(g, sum, mrow0 + j * 16 + fr, n, bn);
         }
     }
     __syncthreads();  // every partial read of this block has been issued and consumed
@@ -269,7 +272,7 @@ static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32
 
 // epilogue of the 256-wide phase-split kernels: the wave holds 4 (n) x MF (m) 16x16 fragments; mrow0 = first row of
 // the wave's m range, n0 + wn*64 = its first column.
-template <int EPI, int MF>
+template <int EPI, int MF, bool F16 = false>
 static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc)[4][8], int n0, int wn, int mrow0, int fr, int fg,
                                                    bf16_t* stg = nullptr) {  // stg: this wave's 16 KiB LDS slice (or nullptr: direct stores)
     const int lane_ = fg * 16 + fr;
@@ -297,11 +300,11 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     for (int j = 0; j < MF; ++j) {
                         const int m = mrow0 + j * 16 + fr;
                         uint2 pk;
-                        pk.x = pack_bf2(acc[i][j][0] + bn[0], acc[i][j][1] + bn[1]);
-                        pk.y = pack_bf2(acc[i][j][2] + bn[2], acc[i][j][3] + bn[3]);
-                        // gelu below sees bf2f(pre) - bias so that (acc + bias) reproduces the rounded value exactly
-                        acc[i][j][0] = bf2f((bf16_t)(pk.x & 0xffffu)); acc[i][j][1] = bf2f((bf16_t)(pk.x >> 16));
-                        acc[i][j][2] = bf2f((bf16_t)(pk.y & 0xffffu)); acc[i][j][3] = bf2f((bf16_t)(pk.y >> 16));
+                        pk.x = Op16<F16>::pack2(acc[i][j][0] + bn[0], acc[i][j][1] + bn[1]);
+                        pk.y = Op16<F16>::pack2(acc[i][j][2] + bn[2], acc[i][j][3] + bn[3]);
+                        // gelu below sees widen(pre) - bias so that (acc + bias) reproduces the rounded value exactly
+                        acc[i][j][0] = Op16<F16>::lo_of(pk.x); acc[i][j][1] = Op16<F16>::hi_of(pk.x);
+                        acc[i][j][2] = Op16<F16>::lo_of(pk.y); acc[i][j][3] = Op16<F16>::hi_of(pk.y);
                         if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
                         else if (m < g.M && n < g.N) *reinterpret_cast<uint2*>(g.pre + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
                     }
@@ -327,8 +330,8 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     const int m = mrow0 + j * 16 + fr;
                     uint2 pk;
                     // (training: acc holds the rounded pre-activation and bn is 0 -> the bits of showo_gelu_bf16 on the saved tensor)
-                    pk.x = pack_bf2(gelu_new_fast(acc[i][j][0] + bn[0]), gelu_new_fast(acc[i][j][1] + bn[1]));
-                    pk.y = pack_bf2(gelu_new_fast(acc[i][j][2] + bn[2]), gelu_new_fast(acc[i][j][3] + bn[3]));
+                    pk.x = Op16<F16>::pack2(gelu_new_fast(acc[i][j][0] + bn[0]), gelu_new_fast(acc[i][j][1] + bn[1]));
+                    pk.y = Op16<F16>::pack2(gelu_new_fast(acc[i][j][2] + bn[2]), gelu_new_fast(acc[i][j][3] + bn[3]));
                     if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
                     else if (m < g.M && n < g.N) *reinterpret_cast<uint2*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
                 }
@@ -354,8 +357,8 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                 for (int j = 0; j < MF; ++j) {
                     const int m = mrow0 + j * 16 + fr;
                     uint2 pk;
-                    pk.x = pack_bf2(acc[i][j][0] + bn[0], acc[i][j][1] + bn[1]);
-                    pk.y = pack_bf2(acc[i][j][2] + bn[2], acc[i][j][3] + bn[3]);
+                    pk.x = Op16<F16>::pack2(acc[i][j][0] + bn[0], acc[i][j][1] + bn[1]);
+                    pk.y = Op16<F16>::pack2(acc[i][j][2] + bn[2], acc[i][j][3] + bn[3]);
                     if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
                     else if (m < g.M) *reinterpret_cast<uint2*>(g.raw + (int64_t)m * g.ldraw + n) = pk;
                 }
@@ -399,10 +402,10 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         uint2 pk;
-                        pk.x = pack_bf2(x[i][0], x[i][1]);
-                        pk.y = pack_bf2(x[i][2], x[i][3]);
-                        x[i][0] = bf2f((bf16_t)(pk.x & 0xffffu)); x[i][1] = bf2f((bf16_t)(pk.x >> 16));
-                        x[i][2] = bf2f((bf16_t)(pk.y & 0xffffu)); x[i][3] = bf2f((bf16_t)(pk.y >> 16));
+                        pk.x = Op16<F16>::pack2(x[i][0], x[i][1]);
+                        pk.y = Op16<F16>::pack2(x[i][2], x[i][3]);
+                        x[i][0] = Op16<F16>::lo_of(pk.x); x[i][1] = Op16<F16>::hi_of(pk.x);
+                        x[i][2] = Op16<F16>::lo_of(pk.y); x[i][3] = Op16<F16>::hi_of(pk.y);
                         if (valid) *reinterpret_cast<uint2*>(g.raw + (int64_t)m * g.ldraw + nbase + i * 16 + fg * 4) = pk;
                     }
                 }
@@ -411,13 +414,13 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) stg_v[(i * 16 + fg * 4 + r) * VRS + j * 16 + fr] = f2bf(x[i][r]);
+                            for (int r = 0; r < 4; ++r) stg_v[(i * 16 + fg * 4 + r) * VRS + j * 16 + fr] = Op16<F16>::cvt(x[i][r]);
                     } else if (valid) {
                         bf16_t* vp = g.Vt + bh * 64 * g.Lp + pos;
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = f2bf(x[i][r]);
+                            for (int r = 0; r < 4; ++r) vp[(int64_t)(i * 16 + fg * 4 + r) * g.Lp] = Op16<F16>::cvt(x[i][r]);
                     }
                     continue;
                 }
@@ -455,8 +458,8 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         uint2 pk;
-                        pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
-                        pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
+                        pk.x = Op16<F16>::pack2(x[i][0] * sc, x[i][1] * sc);
+                        pk.y = Op16<F16>::pack2(x[i][2] * sc, x[i][3] * sc);
                         stage_frag_bf16(stg_qk, j * 16 + fr, i, fg, pk);
                     }
                     continue;
@@ -466,8 +469,8 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     uint2 pk;
-                    pk.x = pack_bf2(x[i][0] * sc, x[i][1] * sc);
-                    pk.y = pack_bf2(x[i][2] * sc, x[i][3] * sc);
+                    pk.x = Op16<F16>::pack2(x[i][0] * sc, x[i][1] * sc);
+                    pk.y = Op16<F16>::pack2(x[i][2] * sc, x[i][3] * sc);
                     *reinterpret_cast<uint2*>(dst + i * 16 + fg * 4) = pk;
                 }
             }
@@ -523,8 +526,8 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                             if (EPI == SHOWO_EPI_GELU_BF16) v[r] = gelu_new_fast(v[r]);
                         }
                         uint2 pk;
-                        pk.x = pack_bf2(v[0], v[1]);
-                        pk.y = pack_bf2(v[2], v[3]);
+                        pk.x = Op16<F16>::pack2(v[0], v[1]);
+                        pk.y = Op16<F16>::pack2(v[2], v[3]);
                         stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
                     }
                 }
@@ -544,7 +547,7 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
             float bn[4];
             load_bias4(g, n, bn);
 #pragma unroll
-            for (int j = 0; j < MF; ++j) store_frag<EPI>(g, acc[i][j], mrow0 + j * 16 + fr, n, bn);
+            for (int j = 0; j < MF; ++j) store_frag<EPI, F16>(g, acc[i][j], mrow0 + j * 16 + fr, n, bn);
         }
     }
 }

@@ -275,6 +275,9 @@ static int train_forward_impl(showo_trainer* t, const int64_t* ids, const float*
     if (showo_engine_missing(e) != 0) return set_error_msg(4, "train: weights missing");
     if (B > t->maxB || L > t->maxL || (int64_t)B * L > t->Tmax) return set_error_msg(5, "train: batch exceeds the trainer workspace");
     if ((e->H % 64) || (e->F % 64)) return set_error_msg(1, "train: hidden/ffn must be multiples of 64");
+    if (e->img_f16 || e->precision == 2)
+        return set_error_msg(4, "train: the engine's weight images hold fp16 (precision 2); training runs on bf16 images -- "
+                                "showo_engine_set_precision(e, 0) and upload the weights again");
     TRY(sync_weights(t, s));
     const int H = e->H, F = e->F, V = e->V, nH = e->nH, T = B * L;
     const int Lp = ((L + 63) / 64) * 64;

@@ -380,13 +380,32 @@ class Showo(PretrainedMixin, nn.Module):
         images, csrc/engine.hip run_layers_precise_fast): same launches as precision 0 with three MFMAs per product, prefix reuse,
         hipGraph replay and the KV-cached decode included; tiny test shapes use the fp32 reference kernels of csrc/precise.hip (and
         mmu_generate then runs the reference's own no-cache algorithm).  Applies to forward() without labels, t2i_generate() and
-        mmu_generate(); training keeps bf16 operands.  Costs 4x the bf16 weight memory.  With w_clip_vit the mm_projector follows."""
-        if int(precision) not in (0, 1):
-            raise ValueError("precision must be 0 (bf16 operands) or 1 (split-bf16, fp32-class)")
+        mmu_generate(); training keeps bf16 operands.  Costs 4x the bf16 weight memory.  With w_clip_vit the mm_projector follows.
+        2: fp16 (IEEE half) operands on the SAME kernels, launches, prefix reuse and hipGraph replay as precision 0 -- the MFMA rate is
+        the same, operand rounding is 2^-12 instead of 2^-9 -- with the final LayerNorm + lm_head as the split-bf16 product of
+        precision 1: logits within 1e-3 of the reference's fp32 inference (rel_rms ~8e-4 at model scale where bf16 operands give
+        7e-3) at the speed of the default path.  Converts saturate at +-65504 (`range_check()` counts saturated activations);
+        the KV-cached decode steps take the general seven-launch layer, mmu_generate_batch falls back to n batch-1 calls, the
+        mm_projector runs in its fp32-class mode (it is one small MLP).  Switching to / from 2 re-uploads the weight images."""
+        if int(precision) not in (0, 1, 2):
+            raise ValueError("precision must be 0 (bf16 operands), 1 (split-bf16, fp32-class) or 2 (fp16 operands)")
         self._precision = int(precision)
         if self.__dict__.get("_modules", {}).get("mm_projector") is not None:
-            self.mm_projector.set_precision(precision)
+            self.mm_projector.set_precision(1 if int(precision) else 0)
         return self
+
+    def range_check(self, fn):
+        """Precision-2 diagnostic: run `fn()` (any forward / generate call of this model) with the engine's range check on and
+        return the number of fp16 activation elements that left a convert saturated (|x| = 65504) or non-finite (csrc/engine.hip
+        range_check; extra launches, not for timed runs).  0 on random-init weights; a deployment on a real checkpoint runs this once."""
+        eng = self.engine()
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.showo.lm_head.weight.device)
+        _lib.call("showo_engine_set_range_check", eng, _lib.ptr(cnt))
+        try:
+            fn()
+        finally:
+            _lib.call("showo_engine_set_range_check", self._engine, None)
+        return int(cnt.item())
 
     def mark_weights_dirty(self):
         """Re-upload every parameter to the HIP engine at the next call.  The engine notices parameter changes by
@@ -432,7 +451,7 @@ class Showo(PretrainedMixin, nn.Module):
 
     def trainer(self):
         """HIP training state (saved activations, transposed weight images, fp32 gradient buffers); created lazily."""
-        eng = self.engine()
+        eng = self.engine(for_training=True)
         if self._trainer is None:
             import ctypes as C
             h = C.c_void_p()
@@ -463,8 +482,9 @@ class Showo(PretrainedMixin, nn.Module):
         emb = torch.cat((freqs, freqs), dim=-1)
         return emb.cos().contiguous().to(device), emb.sin().contiguous().to(device)
 
-    def engine(self):
-        """Create the HIP engine if needed and (re)upload weights whose version changed."""
+    def engine(self, for_training=False):
+        """Create the HIP engine if needed and (re)upload weights whose version changed.  for_training: the trainer works on bf16
+        weight images, so a model in precision 2 (fp16 images) trains on a precision-0 engine (and re-uploads on the way back)."""
         _lib.require_gpu()
         lib = _lib.load()
         dev = self.showo.lm_head.weight.device
@@ -487,10 +507,14 @@ class Showo(PretrainedMixin, nn.Module):
             _lib.call("showo_engine_load", self._engine, b"rope.sin", _lib.ptr(sin), sin.numel(), _lib.stream())
             torch.cuda.current_stream().synchronize()
         want = int(getattr(self, "_precision", 0))
+        if for_training and want == 2:
+            want = 0
         if lib.showo_engine_get_precision(self._engine) != want:
             _lib.call("showo_engine_set_precision", self._engine, want)
         if want == 1 and not lib.showo_engine_precise_ready(self._engine):
             self._engine_versions = {}  # the low halves of the weights are made by the loader: upload everything again
+        if lib.showo_engine_missing(self._engine):
+            self._engine_versions = {}  # first use, or the weight images changed their element type (precision 2 <-> 0 / 1)
         for k, v in self._engine_params():
             ver = (v.data_ptr(), v._version)
             if self._engine_versions.get(k) != ver:

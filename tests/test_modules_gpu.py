@@ -37,6 +37,17 @@ BF16_POINTS_TOL = 1e-3
 # accuracy mode (Showo.set_precision(1): split-bf16 GEMMs, fp32 attention): north_star's "logits within 1e-3", end to end, vs the
 # fp32 reference: max|d| / max|ref| <= 1e-3 (and the rms ratio likewise)
 PRECISE_TOL = 1e-3
+# precision 2 (Showo.set_precision(2): fp16 operands on the production kernels, split-bf16 lm_head -- the speed of the bf16 path):
+# north_star's "logits within 1e-3" END TO END against the fp32 reference, the same two statistics.  Predicted by the rounding-point
+# oracle with fp16 rounding (oracle/predict_rounding.py, profiles/r6_fp16_predict*.txt): rel_rms 8.0e-4, rel_max 9.5e-4 at [2,387].
+FP16_TOL = 1e-3
+
+
+def _check_fp16(got, ref, what):
+    rmax, rrms = util.relerr(got, ref)
+    print(f"[parity] precision 2 (fp16 operands), {what}: rel_max={rmax:.3e} rel_rms={rrms:.3e}")
+    assert rmax <= FP16_TOL and rrms <= FP16_TOL, (what, rmax, rrms)
+    return rmax
 
 
 def _check_logits(got, ref, what):
@@ -456,6 +467,14 @@ def test_full_size_logits_vs_reference_subset():
           f"rel_rms={prms:.3e} (bf16 operands: rel_max={rmax:.3e} rel_rms={rrms:.3e})")
     assert pmax <= PRECISE_TOL and prms <= PRECISE_TOL
     del lgp, subp
+    # precision 2 at full size, END TO END against the fp32 reference: the 1e-3 at the speed of the timed path
+    m.set_precision(2)
+    lgh = m(ids, attention_mask=mask)
+    _check_fp16(lgh[:, torch.from_numpy(g["rows"]).cuda()][:, :, torch.from_numpy(g["cols"]).cuda()], ref, "full-size [2,387] logits vs the fp32 reference subset")
+    n_sat = m.range_check(lambda: m(ids, attention_mask=mask))
+    print(f"[parity] precision 2 range check, full size [2,387]: {n_sat} saturated fp16 activations (random-init weights)")
+    assert n_sat == 0
+    del lgh
     m.set_precision(0)
     assert torch.equal(m(ids, attention_mask=mask), lg)  # back on the bf16 path: the same bits as before
     # north_star's 1e-3, block by block at full size: ALL 24 blocks and the head, each on the GPU's own block input, and
@@ -528,6 +547,11 @@ def test_full_size_cfg3_inpainting_batch_logits_vs_reference_subset():
     print(f"[parity] full-size cfg3 [8,1155] logits, accuracy mode vs the fp32 reference subset: rel_max={pmax:.3e} rel_rms={prms:.3e}")
     assert pmax <= PRECISE_TOL and prms <= PRECISE_TOL
     del lgp
+    m.set_precision(2)
+    lgh = m(ids, attention_mask=mask)
+    _check_fp16(_subset(lgh, g["rows"], g["cols"]), ref, "full-size cfg3 [8,1155] logits vs the fp32 reference subset")
+    assert torch.equal(m(ids, attention_mask=iv), lgh)  # interval mask == dense mask in this mode too
+    del lgh
     m.set_precision(0)
     # 2 of the 8 sequences (one conditional, one unconditional) keep the CPU side of the per-block gate to about a minute
     pick = torch.tensor([1, 5])
@@ -632,6 +656,27 @@ def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
     finally:
         for k, v in defaults.items():
             L.call("showo_decode_set_tuning", k.encode(), v)
+    # ---- precision 2 (fp16 operands, split-bf16 head; the projector in its fp32-class mode): prefill logits and every KV-cached
+    # decode step within 1e-3 of what the reference drew its tokens from, the 8 greedy tokens identical through the cache
+    m.set_precision(2)
+    imgh, embh = splice()
+    lgh = m(None, input_embeddings=embh, attention_mask=am)
+    _check_fp16(lgh[0][torch.from_numpy(g["rows"]).cuda()][:, cols], pre_ref, "full-size cfg4 prefill logits vs the fp32 reference subset")
+    del lgh
+    toks_h = [int(t) for t in m.mmu_generate(input_embeddings=embh, attention_mask=am[0], max_new_tokens=len(toks_ref), top_k=1)]
+    print(f"[parity] full-size cfg4 greedy tokens, precision 2 through the KV cache: {toks_h} vs reference {toks_ref}")
+    assert toks_h == toks_ref
+    L.call("showo_engine_prefill", eng, None, L.ptr(embh.float().contiguous()), L.ptr(maskc), 631, L.ptr(logits), L.stream())
+    for j, t in enumerate(toks_ref):
+        _check_fp16(logits[cols], last_ref[j], f"full-size cfg4 KV-cached decode step {j}")
+        if j + 1 < len(toks_ref):
+            tok = torch.tensor([t], dtype=torch.int64, device="cuda")
+            L.call("showo_engine_decode_step", eng, L.ptr(tok), None, L.ptr(logits), L.stream())
+    # the batched entry point serves precision 2 as n batch-1 calls (its kernels have bf16 instances only): same tokens
+    got2 = [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=[embh, embh[:, :620].contiguous()],
+                                                              attention_mask=[am[0], P.create_attention_mask_for_mmu_vit(embh[:, :620], system_prompt_len=28)[0]],
+                                                              max_new_tokens=8, top_k=1)]
+    assert got2[0] == toks_ref
     # ---- accuracy mode (projector + transformer): 1e-3 against the fp32 reference, tokens identical
     m.set_precision(1)
     imgp, embp = splice()
