@@ -370,7 +370,7 @@ def main():
     torch.manual_seed(0)
     model = synthetic.random_init_showo(max_batch=2 * B, max_seq=387, ln_jitter=True).eval()
     if a.precision:
-        model.set_precision(1)
+        model.set_precision(a.precision)
     log("showo params on GPU")
     vq = showo_amd.MAGVITv2(max_batch=B, max_res=256).cuda().eval()
     log("vq params on GPU")
@@ -444,6 +444,7 @@ def main():
     # with prefix reuse and hipGraph replay: timed like the headline (warm-up incl. the capture, then 3 steps), plus one eager step with
     # HIP events for its own roofline (EXECUTED MFMA flops -- 3x the algorithmic ones -- over time, against the same 2.5 PF/s).
     accuracy = None
+    fp16_mode = None
     if rank == 0 and not a.no_accuracy_leg and not a.precision:
         try:
             ids2 = torch.cat([ic_d[:1], iu_d[:1]]).contiguous()
@@ -482,6 +483,61 @@ def main():
                             "achieved": ach_g, "peak": 2500.0, "unit": "TFLOP/s executed (3 MFMA products per algorithmic product)", "frac": ach_g / 2500.0,
                             "algorithmic_tflops": ach_g / 3.0, "timed_launches": int(n_g.value), "avg_launch_ms": ms_g.value / max(1, n_g.value),
                             "attention": {"achieved_executed_tflops": fl_a.value / max(1e-9, ms_a.value * 1e-3) / 1e12}}
+            # ---- fp16-operand leg (precision 2): the SAME launches as the timed path with IEEE-half operands (same MFMA rate and peak)
+            # and the split-bf16 lm_head -- the configuration in which the 1e-3 and the headline's speed are one sentence.  Its logits are
+            # compared in-run with the accuracy-mode logits above (themselves ~1e-5 from the fp32 reference: the in-run stand-in for it; the
+            # reference fixtures are gated in tests/test_modules_gpu.py), its tokens with the accuracy-mode tokens under identical noise.
+            try:
+                gen_a = torch.Generator(device="cuda").manual_seed(77)
+                toks_acc = model.t2i_generate(input_ids=ic_d.clone(), uncond_input_ids=iu_d, attention_mask=mask_d, temperature=1.0, timesteps=18,
+                                              guidance_scale=5.0, generator=gen_a, config=cfg)
+                lg1 = model(ids2, attention_mask=mk2)
+                model.set_precision(2)
+                lg2 = model(ids2, attention_mask=mk2)
+                dd = (lg2 - lg1).double()
+                h_max, h_rms = float(dd.abs().max() / lg1.double().abs().max()), float(dd.pow(2).mean().sqrt() / lg1.double().pow(2).mean().sqrt())
+                del lg1, lg2, dd
+                gen_a = torch.Generator(device="cuda").manual_seed(77)
+                toks_h = model.t2i_generate(input_ids=ic_d.clone(), uncond_input_ids=iu_d, attention_mask=mask_d, temperature=1.0, timesteps=18,
+                                            guidance_scale=5.0, generator=gen_a, config=cfg)
+                agree_h = float((toks_h == toks_acc).float().mean())
+                step()
+                torch.cuda.synchronize()
+                n_h = max(3, min(a.steps, 10))
+                t1 = time.perf_counter()
+                for _ in range(n_h):
+                    step()
+                torch.cuda.synchronize()
+                dth = (time.perf_counter() - t1) / n_h
+                h_roof = None
+                if not a.no_events:
+                    L.call("showo_prof_reset")
+                    L.call("showo_prof_set_stride", a.event_stride)
+                    L.call("showo_prof_enable", 1)
+                    step()
+                    torch.cuda.synchronize()
+                    L.call("showo_prof_enable", 0)
+                    ms_g, n_g, fl_g = C.c_double(), C.c_int64(), C.c_double()
+                    L.call("showo_prof_read", 0, C.byref(ms_g), C.byref(n_g), C.byref(fl_g))
+                    ms_a, n_a, fl_a = C.c_double(), C.c_int64(), C.c_double()
+                    L.call("showo_prof_read", 1, C.byref(ms_a), C.byref(n_a), C.byref(fl_a))
+                    L.call("showo_prof_reset")
+                    ach_h = fl_g.value / max(1e-9, ms_g.value * 1e-3) / 1e12
+                    h_roof = {"bound": "mfma", "kernel": "gemm3w_kernel / gemm2p_kernel, fp16 instances (v_mfma_f32_16x16x32_f16)", "achieved": ach_h, "peak": 2500.0,
+                              "unit": "TFLOP/s", "frac": ach_h / 2500.0, "timed_launches": int(n_g.value), "avg_launch_ms": ms_g.value / max(1, n_g.value),
+                              "attention_tflops": fl_a.value / max(1e-9, ms_a.value * 1e-3) / 1e12}
+                fp16_mode = {"images_per_s": B / dth, "ms_per_step": dth * 1e3, "steps": n_h, "speed_vs_timed_path": (dt / a.steps) / dth,
+                             "mode": "Showo.set_precision(2): fp16 (IEEE half) operands on the production kernels -- same launches, prefix reuse and hipGraph replay as "
+                                     "the timed path; saturating converts; final LayerNorm + lm_head as a split-bf16 product",
+                             "rel_max_vs_fp32_reference": "<= 1e-3, gated by tests/test_modules_gpu.py on the reference fixtures (full size [2,387], cfg3 [8,1155], cfg4 prefill + "
+                                                          "KV-cached decode, greedy tokens identical)",
+                             "logits_vs_accuracy_mode_in_this_run": {"rel_max": h_max, "rel_rms": h_rms, "sample": "[2,387] slice of this batch, full vocabulary",
+                                                                     "timed_bf16_path_same_sample": {"rel_max": rel_max, "rel_rms": rel_rms}},
+                             "t2i_token_agreement_with_accuracy_mode_same_noise": agree_h, "roofline": h_roof}
+                log(f"fp16 leg: {B / dth:.2f} images/s ({(dt / a.steps) / dth:.3f} x the timed path); logits vs accuracy mode rel_max {h_max:.2e} rel_rms {h_rms:.2e}; "
+                    f"token agreement {agree_h:.4f}; roofline {h_roof}")
+            except Exception as ex:
+                fp16_mode = {"error": repr(ex)}
             model.set_precision(0)
             accuracy = {"images_per_s": B / dta, "ms_per_step": dta * 1e3, "steps": n_acc,
                         "mode": ("Showo.set_precision(1) on the production kernels: K-concatenated split-bf16 images (hi*hi + lo*hi + hi*lo in one bf16 GEMM over 3K), "
@@ -546,17 +602,18 @@ def main():
         out = {
             "metric": "t2i images/sec @256x256 (18 denoise steps)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not a.precision else "bf16x3 (split-bf16 hi+lo operands, fp32-class)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {0: "bf16", 1: "bf16x3 (split-bf16 hi+lo operands, fp32-class)", 2: "f16"}[a.precision], "data": "synthetic",
             "config": {"workload": (f"BASELINE cfg{2 if B == 8 else 1}{'' if B in (1, 8) else ' shape'}: configs/showo_demo.yaml t2i 256x256, batch {B} prompt{'s' if B > 1 else ''}, "
                                     f"CFG 5.0 (forward on [{2 * B},387]), 18 mask-predict steps + MAGVITv2.decode_code; random-init Show-o 1.45B + MAGVIT-v2 95M"),
                        "global_batch": B * world, "seq_len": 387, "parallelism": f"replicas x{world}",
                        "launch_mode": ("hipGraph replay of the denoise steps (cached on the engine)" if a.graph else "eager"),
-                       "precision": "accuracy mode (split-bf16 GEMMs, fp32 attention)" if a.precision else "bf16 operands, fp32 accumulation",
+                       "precision": {0: "bf16 operands, fp32 accumulation", 1: "accuracy mode (split-bf16 GEMMs, fp32 attention)",
+                                     2: "fp16 operands, fp32 accumulation, split-bf16 lm_head"}[a.precision],
                        # SURVEY.md §8d counts the REFERENCE's flops (38.4 TFLOP per image: text rows recomputed every step, lm_head over
                        # the full vocabulary); the path skips most of that work (prefix reuse, restricted head), so this rate is NOT MFMA
                        # utilisation -- `roofline.frac` is
                        "algorithmic_tflop_per_image": 38.4, "reference_flops_rate_tflops_skipped_work_included": value * 38.4},
-            "roofline": {"bound": "mfma", "kernel": "gemm2p_kernel (bf16 MFMA GEMM; per layer ONE [Wqkv;W1] projection with the QKV / GELU split epilogue and ONE K-concatenated dense|fc2 residual GEMM; lm_head rows)",
+            "roofline": {"bound": "mfma", "kernel": "gemm3w_kernel / gemm2p_kernel (one template family; the tuner picks the weight-ring form gemm3w for both layer launches at this shape) -- 16-bit MFMA GEMM; per layer ONE [Wqkv;W1] projection with the QKV / GELU split epilogue and ONE K-concatenated dense|fc2 residual GEMM; lm_head rows)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "measured_peak": measured_peak, "mfma_busy_pmc_from_profiles_not_this_run": mfma_pmc, "traffic": traffic, "traffic_measured_in": "a separate rocprofv3 --pmc pass of this command on the builder's box (profiles/pmc/), NOT this run; null when the GEMM sources changed since", "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "launches": int(n_all.value), "timed_launches": int(n_gemm.value),
@@ -582,6 +639,8 @@ def main():
         train_step = train_leg(world, rank)
     if rank == 0:
         out["accuracy_mode"] = accuracy
+        if fp16_mode is not None:
+            out["fp16_mode"] = fp16_mode
         out["vq_hbm"] = vq_hbm
         # every BASELINE config in the driver's record: cfg3 / cfg4 (and cfg1 = --batch 1) as short child runs under a ~90 s budget
         if world == 1 and not a.no_config_legs:

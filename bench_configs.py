@@ -212,10 +212,16 @@ def mmu(a):
                        "batch1": {"tokens_per_s": NEW / td, "ms_per_image": td * 1e3, "hbm_GBps": ach, "frac_of_8TBps": ach / 8000.0},
                        "clip_projector_splice_ms": tc * 1e3, "prefill_to_first_token_ms": tf * 1e3, "time_to_first_token_ms": (tc + tf) * 1e3,
                        "ms_per_decoded_token": t_tok * 1e3},
-            "roofline": {"bound": "hbm", "kernel": "batch-1 decode step = 24 x (ln_gemv2 + attn_decode + out_gemv2) + lm_head GEMV + arg-max (the batch-4 step "
-                                                   "streams the same bytes for 4 tokens: config.batch4.hbm_GBps)", "achieved": ach,
-                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                         "algorithmic_bytes_per_token": bytes_per_token, "measured_peak_copy_GBps": copy_peak},
+            # the roofline describes the batch the `value` is for (the batch-1 fraction was attached to the batch-4 value):
+            # one decode STEP of 4 tokens streams the same 2.66 GB of weights once; the batch-1 step is next to it
+            "roofline": {"bound": "hbm", "kernel": "batch-4 decode step = 24 x (ln_gemvB<4> + attn_decode_coB<4> + out_dense_y2B<4>) + lm_head + per-sequence arg-max",
+                         "achieved": achB, "peak": 8000.0, "unit": "GB/s", "frac": achB / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_step_of_4_tokens": bytes_per_token, "measured_peak_copy_GBps": copy_peak,
+                         "whole_call_incl_prefills_GBps": bytes_per_token * NEW / tba / 1e9,
+                         "batch1_step": {"kernel": "24 x (ln_gemv2 + attn_decode_co + out_gemv2) + lm_head GEMV + arg-max", "achieved": ach, "frac": ach / 8000.0,
+                                         "algorithmic_bytes_per_token": bytes_per_token}},
+            "metric_history": "rounds 1-4 quoted batch-1 tokens/s under this workload (now config.batch1.tokens_per_s); since round 5 `value` is the aggregate of the "
+                              "4 sequences of BASELINE cfg4 decoded together, whole call incl. the 4 prefills (ADVICE r5): compare like with like",
             "cpu_baseline": None}
 
 

@@ -125,6 +125,10 @@ int showo_colsum_bf16(const uint16_t* x, int ld, int T, int C, float* colpart, f
  * save-for-backward form (showo_gemm_qkv_fc1_save_bf16), out3[2] = launches that split K; reset != 0 zeroes them after reading.
  * Parity tests use it to assert that a training batch ran the T >= 256 kernels that the benchmark times. */
 int showo_gemm_counters(int64_t* out3, int reset);
+/* Cooperative split-K reduction (small-M launches whose tiles x splits blocks are all resident): a block waits for its tile's siblings at
+ * most `polls` polls (default 32 768, ~2 ms; negative restores it), then the tile falls back to the last-arriver sum -- the same bits,
+ * no abort.  0 makes every early block give up at once (test hook). */
+int showo_gemm_set_coop_polls(int polls);
 
 /* Split-precision forms (VQGAN path): every operand is a (hi, lo) bf16 pair, x = hi + lo to ~2^-17; the MFMA
  * accumulates hi*hi + hi*lo + lo*hi in fp32.  fp32 output, optional residual.  Same layouts as the plain calls. */

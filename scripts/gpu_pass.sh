@@ -23,8 +23,9 @@ for step in "$@"; do
     prof-t2i|prof-train|prof-mmu)
       wl=${name#prof-}; extra="--steps 3 --warmup 2 --no-cpu-baseline --no-accuracy-leg --no-config-legs --no-train-leg"; [ $wl = train ] && extra="--workload train --steps 3 --warmup 1"; [ $wl = mmu ] && extra="--workload mmu"
       [ $wl = train ] && export SHOWO_GEMM_TUNE=0
-      (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/${TAG}_prof_$wl -o p -- python $OLDPWD/bench.py $extra $arg > $OLDPWD/gpurun_out/${TAG}_prof_$wl.log 2>&1)
+      (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/${TAG}_prof_$wl -o p -- python $OLDPWD/bench.py $extra $arg > $OLDPWD/gpurun_out/${TAG}_prof_$wl.log 2>&1)
       unset SHOWO_GEMM_TUNE
+      find gpurun_out/${TAG}_prof_$wl -type f ! -name "*stats*" -size +2M -delete
       f=$(find gpurun_out/${TAG}_prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_${wl}_kernel_stats.csv && head -12 "$f" ;;
     pmc) bash scripts/gpu_pmc3.sh ${TAG} ;;
     *) bash -c "$step" > gpurun_out/${TAG}_cmd.log 2>&1; tail -30 gpurun_out/${TAG}_cmd.log ;;

@@ -34,6 +34,7 @@ _PROTOS = {
     "showo_gemm_set_impl": [c_i],
     "showo_gemm_tune": [c_i, c_i, c_p],
     "showo_gemm_counters": [c_p, c_i],
+    "showo_gemm_set_coop_polls": [c_i],
     "showo_attn_set_impl": [c_i],
     "showo_decode_set_impl": [c_i],
     "showo_decode_set_prefetch": [c_i, c_i, c_i],

@@ -196,10 +196,10 @@ __device__ __forceinline__ void attn_block_coords(const AttnArgs& a, int& qb, in
 template <bool F16>
 __device__ inline bf16x8 pack8(const float* p) {
     uint4 u;
-    u.x = Op16<F16>::pack2(p[0], p[1]);
-    u.y = Op16<F16>::pack2(p[2], p[3]);
-    u.z = Op16<F16>::pack2(p[4], p[5]);
-    u.w = Op16<F16>::pack2(p[6], p[7]);
+    u.x = Op16<F16>::pack2_bounded(p[0], p[1]);
+    u.y = Op16<F16>::pack2_bounded(p[2], p[3]);
+    u.z = Op16<F16>::pack2_bounded(p[4], p[5]);
+    u.w = Op16<F16>::pack2_bounded(p[6], p[7]);
     return __builtin_bit_cast(bf16x8, u);
 }
 
@@ -304,10 +304,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w0, w1;
-            w0.x = Op16<F16>::pack2(o0[4 * g] * inv, o0[4 * g + 1] * inv);
-            w0.y = Op16<F16>::pack2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            w1.x = Op16<F16>::pack2(o1[4 * g] * inv, o1[4 * g + 1] * inv);
-            w1.y = Op16<F16>::pack2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            w0.x = Op16<F16>::pack2_bounded(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = Op16<F16>::pack2_bounded(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = Op16<F16>::pack2_bounded(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = Op16<F16>::pack2_bounded(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(op + 8 * g) = w0;        // d = 8g + 4hh + {0..3}
             *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;   // d = 32 + 8g + 4hh + {0..3}
         }
@@ -335,7 +335,7 @@ constexpr float AT_DEFER = 8.0f;   // deferred-rescale threshold (natural-log un
 // asm block -- in the split + dense-mask variant an asm-written P fragment was consumed by the next-but-one MFMA and the products
 // came out at bf16 accuracy (round 5: tools/diag_split_attn.py, 4e-3 instead of 3e-5 against the fp64 SDPA).
 template <bool F16 = false>
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return Op16<F16>::pack2(lo, hi); }
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return Op16<F16>::pack2_bounded(lo, hi); }  // P <= e^AT_DEFER, O = a convex combination of V
 
 // WPB = waves (32-row query tiles) per block: 4, or 5 when that saves a block per (batch, head) -- at Lq = 258 (the 18-step t2i
 // loop: <soi> + 256 image tokens + <eoi>) the ninth query tile would otherwise get a block of its own that streams every K / V^T

@@ -71,12 +71,17 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 constexpr float F16_MAX = 65504.0f;
 // one v_med3_f32 per value.  (A NaN comes out as -65504 -- v_med3 returns the minimum when an input is NaN; the fp32 residual stream and
 // the fp32 GEMM accumulators are never converted, so a NaN that reaches x still reaches the logits; the range check counts |x| = 65504.)
+#if defined(SHOWO_F16_NOSAT)  // A/B build only (what the saturation costs); never the shipped library
+__device__ inline float sat_f16(float x) { return x; }
+#else
 __device__ inline float sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -F16_MAX, F16_MAX); }
+#endif
 template <bool F16>
 struct Op16;
 template <>
 struct Op16<false> {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf2(lo, hi); }
+    static __device__ __forceinline__ uint32_t pack2_bounded(float lo, float hi) { return pack_bf2(lo, hi); }
     static __device__ __forceinline__ bf16_t cvt(float f) { return f2bf(f); }
     static __device__ __forceinline__ float tof(bf16_t v) { return bf2f(v); }
     static __device__ __forceinline__ float lo_of(uint32_t pk) { return __uint_as_float(pk << 16); }          // element 0 / 1 of a packed pair
@@ -92,6 +97,12 @@ struct Op16<true> {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         const f32x2_t v = {sat_f16(lo), sat_f16(hi)};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));  // the compiler's own fptrunc (RNE), visible to the hazard recognizer
+    }
+    // values bounded by construction (soft-max numerators <= e^8, convex combinations of already converted values): no clamp --
+    // in the attention kernels the clamp of P cost 5 % of the kernel (profiles/r6_f16_saturation_ab.txt)
+    static __device__ __forceinline__ uint32_t pack2_bounded(float lo, float hi) {
+        const f32x2_t v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
     }
     static __device__ __forceinline__ bf16_t cvt(float f) { return __builtin_bit_cast(bf16_t, (_Float16)sat_f16(f)); }
     static __device__ __forceinline__ float tof(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

@@ -12,7 +12,7 @@
 //
 // A wave owns whole output columns and splits K over its lanes EXACTLY like the batch-1 kernels of decode.hip (same lane split, same
 // accumulation order per sequence, same epilogue expressions), so every sequence gets the bits its batch-1 run gets: tokens AND
-// logits of showo_engine_batch_decode_greedy equal NB separate showo_engine_decode_greedy runs (tests/test_batch_gpu.py).
+// logits of showo_engine_batch_decode_greedy equal NB separate showo_engine_decode_greedy runs (tests/test_decode_batch_gpu.py).
 // The whole step replays as a hipGraph with the NB positions in device memory.
 #include "engine.h"
 #include "decode_common.h"

@@ -106,6 +106,7 @@ struct showo_engine {
     // decode (KV cache) state: per-layer caches, capacity cap tokens
     bf16_t *kcache = nullptr, *vtcache = nullptr;
     int cache_cap = 0, cache_len = 0, prompt_len = 0;
+    int cache_precision = 0;  // the precision the decode cache was prefilled under (its element type and which halves exist): decode steps must match
     int last_iv[4] = {0, 0, 0, 0};
     int32_t* iv1 = nullptr;
     int64_t* tok1 = nullptr;

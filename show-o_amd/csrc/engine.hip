@@ -1237,12 +1237,23 @@ extern "C" int showo_engine_prefill(showo_engine* e, const int64_t* ids, const f
                                    kv.k_lo, kv.vt_lo));
     e->prompt_len = L;
     e->cache_len = L;
+    e->cache_precision = e->precision;
+    return 0;
+}
+
+// a cache prefilled under one precision must not be decoded under another -- precision 1 would attend with zero low halves
+// (bf16-grade results while get_precision() says 1), precision 2 would read bf16 keys as fp16
+static int check_cache_precision(const showo_engine* e) {
+    if (e->cache_precision != e->precision)
+        return set_error_msg(1, "decode: the KV cache was prefilled under another precision (showo_engine_set_precision changed since "
+                                "showo_engine_prefill): prefill again");
     return 0;
 }
 
 extern "C" int showo_engine_decode_step(showo_engine* e, const int64_t* id, const float* embed, float* logits_last, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!e || e->cache_len <= 0) return set_error_msg(1, "decode_step: prefill first");
+    TRY(check_cache_precision(e));
     const int P = e->cache_len;  // position of the new token
     if (P + 1 > e->cache_cap || P + 1 > e->cfg.max_pos) return set_error_msg(5, "decode_step: cache full");
     TRY(embed_in(e, id, embed, 1, s));
@@ -1281,6 +1292,7 @@ static int decode_loop(showo_engine* e, int64_t* tok, int n_steps, int64_t* out_
     hipStream_t s = (hipStream_t)stream;
     if (!e || e->cache_len <= 0) return set_error_msg(1, "decode_greedy: prefill first");
     if (!tok || !out_tokens || !logits_ws || n_steps < 1) return set_error_msg(1, "decode_greedy: bad arguments");
+    TRY(check_cache_precision(e));
     const int P0 = e->cache_len;
     if (P0 + n_steps > e->cache_cap || P0 + n_steps > e->cfg.max_pos) return set_error_msg(5, "decode_greedy: cache full");
     {   // the decode_step precondition: the mask row must stay a two-interval row

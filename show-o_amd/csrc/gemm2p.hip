@@ -169,6 +169,7 @@ int gemm2p_variant_bf16(const GemmArgs& g, int epilogue, int h, hipStream_t s) {
     return set_error_msg(1, "gemm: unknown epilogue");
 }
 
+int g_gemm_coop_polls = 1 << 15;  // showo_gemm_set_coop_polls
 int g_gemm_gn = 4;  // n-panels per XCD tile group (same-process sweep on the bench workload: 8 -> 24.6-24.7, 4 -> 25.1, 2 -> 25.1, 1 -> 24.7, 16 -> 24.5 images/s)
 int g_gemm_bm = 0;  // 0 = read SHOWO_GEMM_BM once; -1 = choose per shape; a variant code = force it
 int g_gemm_splitk = -1;  // SHOWO_GEMM_SPLITK: 0 = off, 1 (default) = launches with <= 128 tiles split K until ~256 blocks exist
@@ -310,14 +311,6 @@ bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick) {
     return splitk_ws(s, need, ws, tick);
 }
 int gemm_splitk_ticks() { return SPLITK_TICKS; }
-bool gemm_splitk_coop_ok(int blocks, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_gemm_mu);
-    return splitk_coop_ok(blocks, s);
-}
-void gemm_splitk_coop_launched(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_gemm_mu);
-    splitk_coop_launched(s);
-}
 void gemm_count_launch(bool split) {
     std::lock_guard<std::mutex> lock(g_gemm_mu);
     g_cnt_gemm2p++;
@@ -333,6 +326,7 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
     if (g_gemm_stage < 0) { const char* e = getenv("SHOWO_GEMM_STAGE"); g_gemm_stage = e ? atoi(e) : 1; }
     g.flags = (g_gemm_pf ? 2 : 0) | (g_gemm_stage ? 0 : 8) | (g_gemm_stage == 2 ? 32 : 0) | (g_gemm_stage == 3 ? 64 : 0);  // SHOWO_GEMM_STAGE: 0 direct stores, 1 (default) staged except Q / K, 2 all, 3 = 1 with V^T direct
     g.dbg = nullptr;
+    g.coop_polls = g_gemm_coop_polls;
     if (g.op && epilogue == EPI_QKV && (g.raw || g.pre)) return set_error_msg(1, "gemm: the save-for-backward projection has bf16 operands only");
     if (g.op && epilogue == EPI_QKV_SPLIT) return set_error_msg(1, "gemm: the (hi, lo) projection epilogue has bf16 operands only");
     if (epilogue >= 0 && epilogue <= EPI_QKV_SPLIT) return launch2p_bm(g, epilogue, s);
@@ -344,6 +338,14 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s) {
 // Launch counters of the production GEMM family (tests assert that a batch took the T >= 256 branch the bench times):
 // out[0] = launches through gemm2p_dispatch (gemm2p / gemm3w kernels), out[1] = of those, the fused [Wqkv ; W1] save-for-backward form
 // (showo_gemm_qkv_fc1_save_bf16), out[2] = launches that split K.  reset != 0 zeroes them after reading.
+// test hook of the cooperative split-K reduction: polls before a waiting block switches its tile to the last-arriver sum
+// (default 32 768, ~2 ms; 0 = every block that is not the last to arrive gives up at once).  Results never depend on it.
+extern "C" int showo_gemm_set_coop_polls(int polls) {
+    std::lock_guard<std::mutex> lock(showo::g_gemm_mu);
+    showo::g_gemm_coop_polls = polls < 0 ? (1 << 15) : polls;
+    return 0;
+}
+
 extern "C" int showo_gemm_counters(int64_t* out3, int reset) {
     std::lock_guard<std::mutex> lock(showo::g_gemm_mu);
     if (out3) { out3[0] = showo::g_cnt_gemm2p; out3[1] = showo::g_cnt_qkv_save; out3[2] = showo::g_cnt_splitk; }

@@ -7,7 +7,7 @@
 namespace showo {
 
 // host state of the family (gemm2p.hip); the caller of launch2p holds g_gemm_mu
-constexpr int SPLITK_TICKS = 4096;
+constexpr int SPLITK_TICKS = 6144;  // arrivals [0, 2048) | departures [2048, 4096) | cooperative-reduction mode [4096, 6144)
 bool splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
 int splitk_count(int M, int N, int K, int cus);
 int splitk_coop_mode();

@@ -45,6 +45,7 @@ struct GemmArgs {
     // time): the `splits` blocks of a tile reduce TOGETHER -- each sums and stores the fragments it owns (splitk_coop_finish) -- instead
     // of the last arriver reading every partial alone at the cross-XCD single-block rate.  Same split order per element: same bits.
     int coop = 0;
+    int coop_polls = 1 << 15;  // cooperative form: polls (~64 ns each) before a block gives up waiting and the tile falls back to the last-arriver sum (showo_gemm_set_coop_polls; 0 = give up at once: tests)
     // gemm_tn only (token-major operands, contraction over rows): rows k >= Klim of both operands read as zero (K = Klim rounded up to 64)
     int Klim = 0;
     // EPI_QKV_SPLIT only (accuracy mode on the production kernel): every bf16 output also gets its LOW half -- value - bf16(value),
@@ -201,7 +202,7 @@ static __device__ __forceinline__ bool splitk_exchange(const GemmArgs& g, f32x4 
 // dense|fc2 launch, 24 tiles x 10 splits) the serial read of 1.8 MB took about half of the launch.
 // Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> vmcnt(0) -> barrier -> one lane: agent release fence ->
 // arrival ticket; then ONE relaxed poll loop -> ONE agent acquire fence -> barrier -> plain loads.  tick[tile] counts arrivals,
-// tick[2048 + tile] departures; the last block to leave zeroes both for the next launch on this stream.
+// tick[2048 + tile] departures, tick[4096 + tile] holds the tile's mode; the last block to leave zeroes all three for the next launch.
 template <int EPI, int MF, int NFS, bool F16 = false>
 static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int split, int n0, int wn, int mrow0,
                                                           int fr, int fg) {
@@ -230,42 +231,57 @@ static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // tick[tile] = arrivals, tick[2048 + tile] = departures, tick[4096 + tile] = the tile's reduction mode: 0 undecided, 1 cooperative
+    // (every sibling was seen), 2 last-arriver (some block gave up waiting).  A block that does not see all its siblings within
+    // g.coop_polls polls (~2 ms: they are not resident -- another process on the GPU, a CU mask the host did not know about) no longer
+    // traps (round 5: __builtin_trap after ~100 s): it switches the TILE to the last-arriver form and leaves; the block whose arrival
+    // completes the count then sums every partial alone.  Same split order per element in both forms: the same bits.
+    __shared__ int s_mode, s_last;
     if (tid == 0) {
         if (g.coop != 2) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __hip_atomic_fetch_add(g.tick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(g.tick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(g.tick + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.splits) {
+        bool all = false;
+        while (!(all = __hip_atomic_load(g.tick + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)g.splits) && ++spins <= (unsigned)g.coop_polls)
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 26)) __builtin_trap();  // a sibling split never arrived: the host's residency condition was violated
-        }
+        unsigned expect = 0u;
+        const unsigned want = all ? 1u : 2u;
+        // the first block to decide fixes the tile's mode; everybody else adopts it (mode 1 implies that all siblings have arrived)
+        const bool won = __hip_atomic_compare_exchange_strong(g.tick + 4096 + tile, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_mode = won ? (int)want : (int)expect;
+        s_last = old == (unsigned)(g.splits - 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    const bool coop_mode = s_mode == 1;
+    if (coop_mode || s_last) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + fg * 4;
-        float bn[4];
-        load_bias4(g, n, bn);
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4;
+            float bn[4];
+            load_bias4(g, n, bn);
 #pragma unroll
-        for (int j = 0; j < MF; ++j) {
-            if ((i * MF + j) % g.splits != split) continue;  // block-uniform
-            f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int sp = 0; sp < g.splits; ++sp) {
-                const float4 v = base[(size_t)sp * NFS * 512 + (i * MF + j) * 512 + tid];
-                sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+            for (int j = 0; j < MF; ++j) {
+                if (coop_mode && (i * MF + j) % g.splits != split) continue;  // block-uniform: cooperative = the fragments this split owns
+                f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int sp = 0; sp < g.splits; ++sp) {
+                    const float4 v = base[(size_t)sp * NFS * 512 + (i * MF + j) * 512 + tid];
+                    sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+                }
+                store_frag<EPI, F16>(g, sum, mrow0 + j * 16 + fr, n, bn);
             }
-            store_frag<EPI, F16>(g, sum, mrow0 + j * 16 + fr, n, bn);
         }
     }
     __syncthreads();  // every partial read of this block has been issued and consumed
     if (tid == 0) {
         const unsigned left = __hip_atomic_fetch_add(g.tick + 2048 + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (left == (unsigned)(g.splits - 1)) {  // every sibling has seen the full arrival count and finished reading
+        if (left == (unsigned)(g.splits - 1)) {  // the last block to leave (in either mode) readies the three words for the next launch
             __hip_atomic_store(g.tick + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g.tick + 2048 + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.tick + 4096 + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -737,8 +753,8 @@ int gemm2p_dispatch(GemmArgs g, int epilogue, hipStream_t s);  // epilogue: SHOW
 int gemm_splitk_count(int M, int N, int K, int cus);  // cus = showo_cu_usable(stream)
 bool gemm_splitk_ws(hipStream_t s, size_t need, float4** ws, unsigned** tick);
 int gemm_splitk_ticks();
-bool gemm_splitk_coop_ok(int blocks, hipStream_t s);  // tiles x splits blocks can all be resident on the CUs `s` may use AND `s` owns the cooperative form
-void gemm_splitk_coop_launched(hipStream_t s);
+// (the cooperative split-K reduction is used by gemm2p's launches only -- check, launch and record under ONE hold of its mutex
+//  (gemm2p_kernel.h launch2p, called from gemm2p_dispatch); the wrappers gemm_tn once used were removed in round 6: ADVICE r5)
 void gemm_count_launch(bool split);
 extern int g_gemm_gn, g_gemm_bm, g_gemm_pf, g_gemm_stage, g_gemm_splitk;
 // m-split kernel with a 3-deep weight ring (gemm3w.hip); rows = 256 | 240 | 224 | 208

@@ -664,12 +664,15 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     if (threadIdx.x == 0) {
         const float total = (float)sqrt(sh[0]);
         out2[0] = total;
-        out2[1] = fminf(max_norm / (total + 1e-6f), 1.0f);  // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max = 1)
+        // torch.nn.utils.clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max = 1).  A NaN norm gives a NaN coefficient there (clamp keeps
+        // NaN) and every gradient becomes NaN; fminf would return 1 and let AdamW update from the finite part of a poisoned gradient
+        // (ADVICE r5): propagate it.  (An infinite norm gives 0 like the reference: max_norm / inf.)
+        out2[1] = (total != total) ? total : fminf(max_norm / (total + 1e-6f), 1.0f);
     }
 }
 __global__ __launch_bounds__(256) void scale_by_dev_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ coef) {
     const float c = *coef;
-    if (c >= 1.0f) return;
+    if (c >= 1.0f) return;  // (false for a NaN coefficient: the scale pass then runs and poisons every gradient, as the reference does)
     const int64_t stride = (int64_t)gridDim.x * 1024;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < n; i += stride) {
         float4 v = *reinterpret_cast<float4*>(g + i);

@@ -1180,3 +1180,31 @@ def test_split_conv_three_tap_reuse_kernel_tracks_fp64_and_gn_statistics():
         L().call("showo_gn_stats", L().ptr(out), L().ptr(st0), B, Ho * Wo, Cout, S())
         a, b = st1[:B * 64].cpu(), st0[:B * 64].cpu()
         assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=1e-12, atol=1e-9), (B, H, Wd, Cin, Cout, mode, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("polls", [0, 3])
+def test_cooperative_split_k_falls_back_to_the_last_arriver_without_aborting(polls):
+    """a block of a cooperative split-K launch that does not see its tile's siblings in time no longer ends in
+    __builtin_trap(): the TILE switches to the last-arriver reduction (gemm_common.h splitk_coop_finish, mode word per tile) and the
+    blocks leave.  With the poll budget forced to 0 / 3 almost every tile takes the fallback; the residual epilogue (in-place x += ..,
+    the one where a double reduction would show) and the fp32 epilogue give the bits of the default (cooperative) launch, launch after
+    launch on the same workspace (the three words of a tile are left zeroed whichever mode it took)."""
+    torch.manual_seed(11)
+    M, N, K = 516, 2048, 10240  # cfg1's dense|fc2 launch: 24 tiles x 10 splits, all resident
+    A, W, bias, resid = torch.randn(M, K), torch.randn(N, K) * 0.03, torch.randn(N), torch.randn(M, N)
+    base = (_gemm(A, W, bias, 3, resid=resid), _gemm(A, W, bias, 2))
+    cnt = (C.c_int64 * 3)()
+    L().call("showo_gemm_counters", cnt, 1)
+    try:
+        L().call("showo_gemm_set_coop_polls", polls)
+        for _ in range(3):
+            got = (_gemm(A, W, bias, 3, resid=resid), _gemm(A, W, bias, 2))
+            assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
+    finally:
+        L().call("showo_gemm_set_coop_polls", -1)
+    L().call("showo_gemm_counters", cnt, 0)
+    assert cnt[2] >= 6  # the launches above did split K
+    again = (_gemm(A, W, bias, 3, resid=resid), _gemm(A, W, bias, 2))  # cooperative again, same workspace: same bits
+    assert torch.equal(again[0], base[0]) and torch.equal(again[1], base[1])
+    ref = bf16_round(A).double() @ bf16_round(W).double().T + bias.double()
+    assert (base[1].double() - ref).abs().max() < 2e-5 * float(ref.abs().max())
