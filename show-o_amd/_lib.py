@@ -36,6 +36,7 @@ _PROTOS = {
     "showo_gemm_counters": [c_p, c_i],
     "showo_gemm_set_coop_polls": [c_i],
     "showo_attn_set_impl": [c_i],
+    "showo_attn_set_variant": [c_i],
     "showo_decode_set_impl": [c_i],
     "showo_decode_set_prefetch": [c_i, c_i, c_i],
     "showo_decode_set_tuning": [C.c_char_p, c_i],

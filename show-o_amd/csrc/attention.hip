@@ -820,30 +820,31 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a, DecPrep f
 // remaining blocks stream the fc2 weights (33.5 MB at Phi-1.5's shape) and write y2 = fc2(gelu(fc1)) + b2, which does not depend on
 // the attention (Phi's block is parallel-residual, models/phi.py:806-835).  No synchronisation between the roles: the following
 // out_gemv2_kernel<1, 2> launch adds dense(attn) and y2 into the residual row.  One launch instead of a stream fork / join.
+template <bool F16 = false>
 __global__ __launch_bounds__(1024) void attn_decode_co_kernel(AttnArgs a, DecPrep f, showo::OutGemvArgs g, showo::DecodePrefetch pf) {
     if ((int)blockIdx.x >= a.nH) {
         extern __shared__ float sp[];
         const int nrole = gridDim.x - a.nH - pf.blocks;
         if ((int)blockIdx.x >= a.nH + nrole) showo::prefetch_role(pf, blockIdx.x - a.nH - nrole, pf.blocks, sp);
-        else showo::fc2_columns_role<4>(g, blockIdx.x - a.nH, nrole, 16, reinterpret_cast<bf16_t*>(sp));
+        else showo::fc2_columns_role<4, F16>(g, blockIdx.x - a.nH, nrole, 16, reinterpret_cast<bf16_t*>(sp));
         return;
     }
-    attn_decode_body<true>(a, f, blockIdx.x, 0);
+    attn_decode_body<true, F16>(a, f, blockIdx.x, 0);
 }
 
 // Batched form of the co-scheduled launch (decode_batch.hip): blocks [0, nH * B) = the (sequence, head) attention blocks, the rest
 // stream the fc2 weights ONCE for all NB sequences (fc2_columns_roleB: the NB activation rows as bf16 in LDS).
-template <int NB>
+template <int NB, bool F16 = false>
 __global__ __launch_bounds__(1024) void attn_decode_coB_kernel(AttnArgs a, DecPrep f, showo::OutGemvBArgs g, showo::DecodePrefetch pf) {
     const int nab = a.nH * a.B;
     if ((int)blockIdx.x >= nab) {
         extern __shared__ float sp[];
         const int nrole = gridDim.x - nab - pf.blocks;
         if ((int)blockIdx.x >= nab + nrole) showo::prefetch_role(pf, blockIdx.x - nab - nrole, pf.blocks, sp);
-        else showo::fc2_columns_roleB<4, NB>(g, blockIdx.x - nab, nrole, 16, reinterpret_cast<bf16_t*>(sp));
+        else showo::fc2_columns_roleB<4, NB, F16>(g, blockIdx.x - nab, nrole, 16, reinterpret_cast<bf16_t*>(sp));
         return;
     }
-    attn_decode_body<true>(a, f, blockIdx.x % a.nH, blockIdx.x / a.nH);
+    attn_decode_body<true, F16>(a, f, blockIdx.x % a.nH, blockIdx.x / a.nH);
 }
 
 // decode-step graph replay (engine-internal): when set, single-token qk_prep / attention launches take the position from
@@ -889,6 +890,12 @@ static int g_attn_forced = -1;
 
 extern "C" int showo_attn_set_impl(int impl) {
     g_attn_forced = (impl >= 1 && impl <= 3) ? impl : 0;  // 1 gather, 2 LDS double-buffered, 3 the same with 3 blocks per CU
+    return 0;
+}
+
+static int g_attn_variant = 0;
+extern "C" int showo_attn_set_variant(int variant) {
+    g_attn_variant = variant;
     return 0;
 }
 
@@ -1009,7 +1016,7 @@ namespace showo {
 // replays of the captured loop (load predicate, see attn_decode_body).  Same kernel and arithmetic as the batch-1 launch per sequence.
 int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                             const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
-                            const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s) {
+                            const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s, int op) {
     if ((Lp % 64) || !pos_dev || B < 1) return set_error_msg(1, "batched decode attention: bad arguments");
     AttnArgs a;
     a.Q = nullptr; a.K = K; a.Vt = Vt; a.iv = iv; a.flag = nullptr; a.dense = nullptr; a.O = O;
@@ -1019,14 +1026,15 @@ int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb,
     DecPrep f{qkv, qw, qb, kw, kb, cosT, sinT, rot, 0, eps};
     const size_t smem = (size_t)((Lcap + 511) & ~511) * sizeof(float);
     if (smem > 60000) return set_error_msg(5, "decode attention: cache longer than the single-block kernel supports");
-    attn_decode_kernel<true><<<dim3(nH, B), dim3(1024), smem, s>>>(a, f);
+    if (op) attn_decode_kernel<true, true><<<dim3(nH, B), dim3(1024), smem, s>>>(a, f);
+    else attn_decode_kernel<true><<<dim3(nH, B), dim3(1024), smem, s>>>(a, f);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
 }
 int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                          const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
                          const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s,
-                         const DecodePrefetch* pfp) {
+                         const DecodePrefetch* pfp, int op) {
     DecodePrefetch pf{};
     if (pfp) pf = *pfp;
     if ((Lp % 64) || !pos_dev || B < 2 || B > 4 || fc2.K1 != 8192 || !fc2.y2 || co_blocks < 1)
@@ -1042,17 +1050,18 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
     const size_t smem_f = (size_t)B * fc2.K1 * sizeof(bf16_t);
     const size_t smem = smem_a > smem_f ? smem_a : smem_f;
     const dim3 grid(nH * B + co_blocks + pf.blocks);
-    static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};
+    static bool attr[20] = {};
     auto launch = [&](auto kfn) -> int {
-        if (!attr[B]) {
+        if (!attr[B + (op ? 10 : 0)]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(attn_decode_coB)", __FILE__, __LINE__);
-            attr[B] = true;
+            attr[B + (op ? 10 : 0)] = true;
         }
         kfn<<<grid, dim3(1024), smem, s>>>(a, f, fc2, pf);
         return 0;
     };
-    const int rc = B == 2 ? launch(attn_decode_coB_kernel<2>) : B == 3 ? launch(attn_decode_coB_kernel<3>) : launch(attn_decode_coB_kernel<4>);
+    const int rc = op ? (B == 2 ? launch(attn_decode_coB_kernel<2, true>) : B == 3 ? launch(attn_decode_coB_kernel<3, true>) : launch(attn_decode_coB_kernel<4, true>))
+                      : (B == 2 ? launch(attn_decode_coB_kernel<2>) : B == 3 ? launch(attn_decode_coB_kernel<3>) : launch(attn_decode_coB_kernel<4>));
     if (rc) return rc;
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1060,7 +1069,7 @@ int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, co
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s, const bf16_t* W2, const bf16_t* ffn, const float* b2, int F, int Hout, float* y2,
-                      int co_blocks, const DecodePrefetch* pfp) {
+                      int co_blocks, const DecodePrefetch* pfp, int op) {
     if ((Lp % 64) || Lp <= pos || Lcap <= pos) return set_error_msg(1, "decode attention: bad Lp/Lcap");
     DecodePrefetch pf{};
     if (pfp && W2) pf = *pfp;
@@ -1076,7 +1085,10 @@ int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const
         if (F != 8192 || !y2 || !ffn || !b2) return set_error_msg(1, "decode attention: co-scheduled fc2 needs F = 8192 and y2");
         showo::OutGemvArgs g{nullptr, nullptr, nullptr, nullptr, 0, W2, ffn, b2, F, Hout, y2};
         const size_t smem2 = smem > (size_t)F * sizeof(bf16_t) ? smem : (size_t)F * sizeof(bf16_t);
-        attn_decode_co_kernel<<<dim3(nH + co_blocks + pf.blocks, 1), dim3(1024), smem2, s>>>(a, f, g, pf);
+        if (op) attn_decode_co_kernel<true><<<dim3(nH + co_blocks + pf.blocks, 1), dim3(1024), smem2, s>>>(a, f, g, pf);
+        else attn_decode_co_kernel<false><<<dim3(nH + co_blocks + pf.blocks, 1), dim3(1024), smem2, s>>>(a, f, g, pf);
+    } else if (op) {
+        attn_decode_kernel<true, true><<<dim3(nH, 1), dim3(1024), smem, s>>>(a, f);
     } else {
         attn_decode_kernel<true><<<dim3(nH, 1), dim3(1024), smem, s>>>(a, f);
     }

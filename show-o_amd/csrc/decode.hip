@@ -38,7 +38,7 @@ struct LnGemvArgs {
 
 // R = weight rows in flight per wave (2 by default; R = 4 with a grid of Ntot / 16 blocks requests every row of a layer's 58.7 MB at
 // kernel start -- see decode_ln_gemv2 for the measurement); larger matrices (lm_head) loop and refill.
-template <int R>
+template <int R, bool F16 = false>
 __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 2048: one 4-load group covers a weight row
     extern __shared__ bf16_t sh[];  // normalised row, bf16 like showo_layernorm_f32_bf16's output
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: weight-row bases in SGPRs
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
                 const float4 w = *reinterpret_cast<const float4*>(g.lnw + i);
                 const float4 bb = *reinterpret_cast<const float4*>(g.lnb + i);
                 uint2 o;
-                o.x = pack_bf2((v.x - mean) * rstd * w.x + bb.x, (v.y - mean) * rstd * w.y + bb.y);
-                o.y = pack_bf2((v.z - mean) * rstd * w.z + bb.z, (v.w - mean) * rstd * w.w + bb.w);
+                o.x = Op16<F16>::pack2((v.x - mean) * rstd * w.x + bb.x, (v.y - mean) * rstd * w.y + bb.y);
+                o.y = Op16<F16>::pack2((v.z - mean) * rstd * w.z + bb.z, (v.w - mean) * rstd * w.w + bb.w);
                 *reinterpret_cast<uint2*>(sh + i) = o;
             }
         }
@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
             if (c < g.N0) {
                 const float v = acc + g.b0[c];
                 if (g.outf) g.outf[c] = v;
-                else g.out0[c] = f2bf(v);
+                else g.out0[c] = Op16<F16>::cvt(v);
             } else {
-                g.out1[c - g.N0] = f2bf(gelu_new_fast(acc + g.b1[c - g.N0]));
+                g.out1[c - g.N0] = Op16<F16>::cvt(gelu_new_fast(acc + g.b1[c - g.N0]));
             }
         }
     };
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
         for (int r = 0; r < R; ++r) {
             const int c = n + r * stride;
             if (c < Ntot) {
-                const float acc = fma4(br[r], sh, lane * 8, H, 0.f);
+                const float acc = fma4<F16>(br[r], sh, lane * 8, H, 0.f);
                 if (c + R * stride < Ntot) load4(rowp(c + R * stride), lane * 8, H, br[r]);
                 finish(c, acc);
             }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 
 //   MODE 1 (K0 = 0): y2[n] = fc2 + b2            (side stream, next to the attention kernel)
 //   MODE 2 (K1 = 0): x[n] = (x[n] + (dense + bd)) + y2[n]   (after the join)
 // Same lane split, accumulation order and parenthesisation in every mode: the three forms agree bit for bit.
-template <int C, int MODE>
+template <int C, int MODE, bool F16 = false>
 __global__ __launch_bounds__(512) void out_gemv2_kernel(OutGemvArgs g) {
     extern __shared__ bf16_t sa[];  // [K0] attention row, [K1] gelu(fc1) row: read once per block instead of once per wave
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: weight-row bases in SGPRs
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(512) void out_gemv2_kernel(OutGemvArgs g) {
         float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
         for (int t = 0; t < C; ++t) {
-            if (t < c0) acc0 = fma4(buf[t], a0, t * 2048 + lane * 8, g.K0, acc0);
-            else acc1 = fma4(buf[t], a1, (t - c0) * 2048 + lane * 8, g.K1, acc1);
+            if (t < c0) acc0 = fma4<F16>(buf[t], a0, t * 2048 + lane * 8, g.K0, acc0);
+            else acc1 = fma4<F16>(buf[t], a1, (t - c0) * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) issue(nn, t, buf[t]);
         }
         acc0 = wave_sum_swap(acc0);
@@ -182,14 +182,15 @@ bool decode_fused_shapes_ok(int H, int F) { return (H % 8) == 0 && (F % 8) == 0 
 
 // x -> LN(lnw, lnb) -> { out0 = bf16(W0 h + b0) | outf = fp32(W0 h + b0) } and out1 = bf16(gelu(W1 h + b1))  (N1 may be 0)
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
-                    bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s) {
+                    bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s, int op) {
     LnGemvArgs g{x, lnw, lnb, eps, H, W0, b0, out0, outf, N0, W1, b1, out1, N1};
     // rows in flight per wave: 2 (default: 12 rows per block, a wave's third row is requested behind its first FMA) or 4
     // (SHOWO_DECODE_LNR=4: the whole layer matrix requested at kernel start; measured SLOWER on cfg4, 0.983-0.992 vs 0.958-0.969 ms per
     // token in one box, gpurun_out/bench_mmu_r2z_*: 123 VGPRs halve the resident waves and the single burst queues behind itself)
     static int lnr = 0;
     if (!lnr) { const char* e = getenv("SHOWO_DECODE_LNR"); lnr = (e && atoi(e) == 4) ? 4 : 2; }
-    if (lnr == 2) ln_gemv2_kernel<2><<<dim3(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    if (op) ln_gemv2_kernel<2, true><<<dim3(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    else if (lnr == 2) ln_gemv2_kernel<2><<<dim3(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
     else ln_gemv2_kernel<4><<<dim3(pick_blocks(N0 + N1, 16, 1024)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "ln_gemv2 launch", __FILE__, __LINE__);
@@ -198,7 +199,7 @@ int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float ep
 
 // x[n] += (W0[n,:] a0 + b0[n]);  x[n] += (W1[n,:] a1 + b1[n])
 int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* b0, int K0, const bf16_t* W1, const bf16_t* a1,
-                     const float* b1, int K1, int N, hipStream_t s, int mode, float* y2) {
+                     const float* b1, int K1, int N, hipStream_t s, int mode, float* y2, int op) {
     OutGemvArgs g{x, W0, a0, b0, K0, W1, a1, b1, K1, N, y2};
     if (mode == 1) g.K0 = 0;
     if (mode == 2) g.K1 = 0;
@@ -206,6 +207,22 @@ int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* 
     const int C = (g.K0 + 2047) / 2048 + (g.K1 + 2047) / 2048;
     const dim3 grid(pick_blocks(N, 8, showo::decode_tuning().out_blocks));
     const size_t smem = (size_t)(g.K0 + g.K1) * sizeof(bf16_t);
+    if (op) {  // IEEE-half operands (precision 2): the shapes of the fused layer at Phi-1.5's size
+        if (mode == 1 && C == 4) out_gemv2_kernel<4, 1, true><<<grid, dim3(512), smem, s>>>(g);
+        else if (mode == 1 && C >= 1 && C <= 3) out_gemv2_kernel<3, 1, true><<<grid, dim3(512), smem, s>>>(g);
+        else if (mode == 2 && C == 1) out_gemv2_kernel<1, 2, true><<<grid, dim3(512), smem, s>>>(g);
+        else if (mode != 0) return set_error_msg(1, "decode_out_gemv2: unsupported K0/K1 for the forked layer");
+        else switch (C) {
+            case 2: out_gemv2_kernel<2, 0, true><<<grid, dim3(512), smem, s>>>(g); break;
+            case 3: out_gemv2_kernel<3, 0, true><<<grid, dim3(512), smem, s>>>(g); break;
+            case 4: out_gemv2_kernel<4, 0, true><<<grid, dim3(512), smem, s>>>(g); break;
+            case 5: out_gemv2_kernel<5, 0, true><<<grid, dim3(512), smem, s>>>(g); break;
+            default: return set_error_msg(1, "decode_out_gemv2: unsupported K0/K1 (decode_fused_shapes_ok)");
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return set_error_hip(e, "out_gemv2 launch", __FILE__, __LINE__);
+        return 0;
+    }
     if (mode == 1 && C == 4) out_gemv2_kernel<4, 1><<<grid, dim3(512), smem, s>>>(g);
     else if (mode == 1 && C >= 1 && C <= 3) out_gemv2_kernel<3, 1><<<grid, dim3(512), smem, s>>>(g);
     else if (mode == 2 && C == 1) out_gemv2_kernel<1, 2><<<grid, dim3(512), smem, s>>>(g);

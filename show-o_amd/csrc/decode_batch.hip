@@ -24,10 +24,10 @@ namespace showo {
 int attn_decode_co_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                          const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
                          const int* pos_dev, int lk_max, int Lcap, int Lp, const OutGemvBArgs& fc2, int co_blocks, hipStream_t s,
-                         const DecodePrefetch* pf);
+                         const DecodePrefetch* pf, int op = 0);
 int attn_decode_fused_batch(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                             const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int B, int nH, int rot, float eps,
-                            const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s);
+                            const int* pos_dev, int lk_max, int Lcap, int Lp, hipStream_t s, int op = 0);
 }
 
 #define TRY(expr)            \

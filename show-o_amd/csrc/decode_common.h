@@ -12,13 +12,14 @@ static __device__ __forceinline__ void load4(const bf16_t* row, int k0, int K, u
     }
 }
 // acc += sum over the 4 loaded 8-element groups, in gemv_kernel's order (u ascending, pairs ascending: dot8_bf16)
-template <class AP>
+// F16: the operand type of weights and activations (common.h Op16; precision 2 = IEEE half on v_dot2_f32_f16)
+template <bool F16 = false, class AP>
 static __device__ __forceinline__ float fma4(const uint4 (&wv)[4], AP act, int k0, int K, float acc) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * 512;
         if (k >= K) break;
-        acc = dot8_bf16(wv[u], *reinterpret_cast<const uint4*>(act + k), acc);
+        acc = dot8_op<F16>(wv[u], *reinterpret_cast<const uint4*>(act + k), acc);
     }
     return acc;
 }
@@ -41,7 +42,7 @@ struct OutGemvArgs {
 // fc2 role of the co-scheduled decode launch (attention.hip, attn_decode_co_kernel): y2[n] = W1[n, :] a1 + b1[n] for the columns of
 // role-block `rb` of `nrb`, `nw` waves per block.  Same lane split, accumulation order and epilogue expression as
 // out_gemv2_kernel<C, 1> (decode.hip), so the result does not depend on which launch computed it.  sa: >= K1 bf16 of LDS.
-template <int C>
+template <int C, bool F16 = false>
 static __device__ __forceinline__ void fc2_columns_role(const OutGemvArgs& g, int rb, int nrb, int nw, bf16_t* sa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int stride = nrb * nw;
@@ -58,7 +59,7 @@ static __device__ __forceinline__ void fc2_columns_role(const OutGemvArgs& g, in
         float acc1 = 0.f;
 #pragma unroll
         for (int t = 0; t < C; ++t) {
-            acc1 = fma4(buf[t], sa, t * 2048 + lane * 8, g.K1, acc1);
+            acc1 = fma4<F16>(buf[t], sa, t * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) load4(g.W1 + (int64_t)nn * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
         }
         acc1 = wave_sum_swap(acc1);
@@ -132,7 +133,7 @@ static __device__ __forceinline__ float wave_sum_groups(const float (&acc)[NB]) 
 
 // acc[b] += sum over the 4 loaded 8-element groups of w * act[b], in fma4's order (u ascending, pairs ascending) per sequence.
 // act: this lane's 32 activation values per sequence as 16 packed bf16 pairs (registers).
-template <int NB>
+template <int NB, bool F16 = false>
 static __device__ __forceinline__ void fma4_regs(const uint4 (&wv)[4], const uint32_t (&act)[NB][16], int k0, int K, float (&acc)[NB]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -141,7 +142,7 @@ static __device__ __forceinline__ void fma4_regs(const uint4 (&wv)[4], const uin
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = dot2_bf16(w[p], act[b][u * 4 + p], acc[b]);
+            for (int b = 0; b < NB; ++b) acc[b] = Op16<F16>::dot2(w[p], act[b][u * 4 + p], acc[b]);
     }
 }
 // this lane's 16 pairs of one bf16 activation row (global or LDS), zero beyond K
@@ -156,14 +157,14 @@ static __device__ __forceinline__ void load_act_pairs(AP row, int k0, int K, uin
     }
 }
 // the same with the activations in LDS (sa: row b at sa + b * ld, bf16): one 16-byte read per 8 products per sequence
-template <int NB>
+template <int NB, bool F16 = false>
 static __device__ __forceinline__ void fma4_lds(const uint4 (&wv)[4], const bf16_t* sa, int ld, int k0, int K, float (&acc)[NB]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * 512;
         if (k >= K) break;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = dot8_bf16(wv[u], *reinterpret_cast<const uint4*>(sa + (size_t)b * ld + k), acc[b]);
+        for (int b = 0; b < NB; ++b) acc[b] = dot8_op<F16>(wv[u], *reinterpret_cast<const uint4*>(sa + (size_t)b * ld + k), acc[b]);
     }
 }
 
@@ -171,7 +172,7 @@ static __device__ __forceinline__ void fma4_lds(const uint4 (&wv)[4], const bf16
 // the columns of role-block rb of nrb, nw waves per block.  fc2_columns_role's lane split and accumulation order per sequence (chunks
 // t ascending into ONE accumulator chain, then the wave reduction): the bits of the batch-1 launch.  The NB activation rows live in
 // LDS as bf16 (NB * K1 * 2 bytes: 64 KiB at NB = 4).
-template <int C, int NB>
+template <int C, int NB, bool F16 = false>
 static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, int rb, int nrb, int nw, bf16_t* sa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int stride = nrb * nw;
@@ -192,7 +193,7 @@ static __device__ __forceinline__ void fc2_columns_roleB(const OutGemvBArgs& g, 
         for (int b = 0; b < NB; ++b) acc1[b] = 0.f;
 #pragma unroll
         for (int t = 0; t < C; ++t) {
-            fma4_lds<NB>(buf[t], sa, g.K1, t * 2048 + lane * 8, g.K1, acc1);
+            fma4_lds<NB, F16>(buf[t], sa, g.K1, t * 2048 + lane * 8, g.K1, acc1);
             if (nn < g.N) load4(g.W1 + (int64_t)nn * g.K1, t * 2048 + lane * 8, g.K1, buf[t]);
         }
         const float tot = wave_sum_groups<NB>(acc1);

@@ -37,13 +37,14 @@ int sample_topk_launch(const float* logits, int V, int top_k, float temperature,
 struct DecodePrefetch;
 bool decode_fused_shapes_ok(int H, int F);
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
-                    bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s);
+                    bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s,
+                    int op = 0);  // op: SHOWO_OP_BF16 | SHOWO_OP_F16 -- the element type of weights and 16-bit activations (all decode entry points)
 int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* b0, int K0, const bf16_t* W1, const bf16_t* a1,
-                     const float* b1, int K1, int N, hipStream_t s, int mode = 0, float* y2 = nullptr);
+                     const float* b1, int K1, int N, hipStream_t s, int mode = 0, float* y2 = nullptr, int op = 0);
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,
                       const float* sinT, bf16_t* K, bf16_t* Vt, const int32_t* iv, bf16_t* O, int nH, int rot, float eps, int pos,
                       int Lcap, int Lp, hipStream_t s, const bf16_t* W2 = nullptr, const bf16_t* ffn = nullptr, const float* b2 = nullptr,
-                      int F = 0, int Hout = 0, float* y2 = nullptr, int co_blocks = 0, const DecodePrefetch* pf = nullptr);
+                      int F = 0, int Hout = 0, float* y2 = nullptr, int co_blocks = 0, const DecodePrefetch* pf = nullptr, int op = 0);
 // Infinity-Cache prefetch role of the co-scheduled decode launches (decode_common.h): what layer li's attention launch reads ahead.
 // next_mb: MB of the next launches' weights ([Wqkv ; W1] of layer li + 1, the lm_head after the last layer), dense: this layer's Wd
 // first, blocks: prefetch blocks per launch (0: off).  Defaults from SHOWO_DECODE_PF_MB / _DENSE / _BLOCKS; showo_decode_set_prefetch.

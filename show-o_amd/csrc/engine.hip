@@ -715,8 +715,8 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
     TRY(collect_x(e, 0, T, s));
     const int Lk = pos0 + L;
     const int Lcap = kv.Lcap, Lp = kv.Lp;
-    // (the fused three-launch decode layer of decode.hip has bf16 instances only: precision 2 decodes on the general path below)
-    if (T == 1 && !op && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
+    // (the fused three-launch decode layer of decode.hip has instances for both operand types since round 6)
+    if (T == 1 && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
         // AR decode step (decode.hip): three launches per layer.  Forked layer (opt-in, SHOWO_DECODE_FORK=1; measured SLOWER: 705-711 vs
         // 843-846 tokens/s in one box, gpurun_out/bench_mmu_r2k_*: every fork / join edge of the per-token graph costs more than the
         // overlap buys, like the side-stream weight prefetch of round 1): fc1 and fc2 do not depend on the attention, so their 67 MB
@@ -754,34 +754,34 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
             if (co) {
                 TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
-                                           e->ffn, F, s));
+                                           e->ffn, F, s, op));
                 showo::DecodePrefetch pf;
                 showo::decode_prefetch_plan(e, li, &pf);
                 TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
-                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, l.w2, e->ffn, l.b2, F, H, e->y2, co_blocks, &pf));
-                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2));
+                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, l.w2, e->ffn, l.b2, F, H, e->y2, co_blocks, &pf, op));
+                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2, op));
                 continue;
             }
             if (!fork) {
                 TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
-                                           e->ffn, F, s));
+                                           e->ffn, F, s, op));
                 TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
-                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
-                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s));
+                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, op));
+                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 0, nullptr, op));
                 continue;
             }
             SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));  // x of this layer is final
             SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
             TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, nullptr, nullptr,
-                                       nullptr, 0, s));
+                                       nullptr, 0, s, op));
             TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, nullptr, nullptr, nullptr, nullptr, 0, l.w1, l.b1, e->ffn, F,
-                                       e->side));
-            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, e->side, 1, e->y2));
+                                       e->side, op));
+            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, e->side, 1, e->y2, op));
             SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
             TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
-                                         e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s));
+                                         e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, op));
             SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
-            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2));
+            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2, op));
         }
         return 0;
     }

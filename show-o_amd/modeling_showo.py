@@ -385,7 +385,7 @@ class Showo(PretrainedMixin, nn.Module):
         the same, operand rounding is 2^-12 instead of 2^-9 -- with the final LayerNorm + lm_head as the split-bf16 product of
         precision 1: logits within 1e-3 of the reference's fp32 inference (rel_rms ~8e-4 at model scale where bf16 operands give
         7e-3) at the speed of the default path.  Converts saturate at +-65504 (`range_check()` counts saturated activations);
-        the KV-cached decode steps take the general seven-launch layer, mmu_generate_batch falls back to n batch-1 calls, the
+        the KV-cached decode steps run the fp16 instances of the fused three-launch layer (csrc/decode.hip), mmu_generate_batch falls back to n batch-1 calls, the
         mm_projector runs in its fp32-class mode (it is one small MLP).  Switching to / from 2 re-uploads the weight images."""
         if int(precision) not in (0, 1, 2):
             raise ValueError("precision must be 0 (bf16 operands), 1 (split-bf16, fp32-class) or 2 (fp16 operands)")
