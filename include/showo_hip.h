@@ -289,10 +289,6 @@ int showo_mask_tokens(const int64_t* tokens, const float* noise, const int32_t* 
  * per 32 query rows, operands straight from L2), 2 = LDS-tiled form (4 waves share 64-key K / V^T tiles staged by
  * global_load_lds; 4 waves/SIMD), 3 = the same at 3 waves/SIMD (no register spill) */
 int showo_attn_set_impl(int impl);
-/* A/B switch of the LDS-tiled forward (tools/attn_bench.py): bit 0 = the query rows beyond the last full 128-row block (the two
- * stray rows of the 258-row t2i step) run as VALU single-row blocks in the same launch instead of an MFMA block of their own
- * (default on where it applies; 0 = every row on the MFMA tiles) */
-int showo_attn_set_variant(int variant);
 /* AR decode step (one new token against the KV cache): 0 = fused layer, three launches (LN + qkv/fc1 GEMV; prep +
  * single-query attention with the fc2 GEMV co-scheduled on the CUs the 32 attention blocks leave idle (F = 8192 only);
  * dense GEMV + both residual adds; default), 1 = the general seven-launch layer, 2 = the fused layer as a plain chain

@@ -1,5 +1,5 @@
 #!/bin/bash
-# attention forward at the t2i shape: micro-benchmark (tools/attn_bench.py) over variants / shapes + one SQ PMC pass.  usage: gpu_attn.sh <tag> [variants]
+# attention forward at the t2i shape: micro-benchmark (tools/attn_bench.py) over variants / shapes + one SQ PMC pass.  usage: gpu_attn.sh <tag> [impl list for showo_attn_set_impl, e.g. 0,3]
 TAG=${1:-attn}; VAR=${2:-0}
 R=$(pwd); mkdir -p gpurun_out; export TMPDIR=/tmp
 {

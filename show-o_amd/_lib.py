@@ -36,7 +36,6 @@ _PROTOS = {
     "showo_gemm_counters": [c_p, c_i],
     "showo_gemm_set_coop_polls": [c_i],
     "showo_attn_set_impl": [c_i],
-    "showo_attn_set_variant": [c_i],
     "showo_decode_set_impl": [c_i],
     "showo_decode_set_prefetch": [c_i, c_i, c_i],
     "showo_decode_set_tuning": [C.c_char_p, c_i],
@@ -232,6 +231,8 @@ def load():
                            "(show-o_amd has no CPU/eager fallback)")
     lib = C.CDLL(LIB_PATH)
     for name, args in _PROTOS.items():
+        if os.environ.get("SHOWO_LIB_PATH") and not hasattr(lib, name):
+            continue  # an older build loaded for a same-box A/B run lacks the newest entry points; the shipped library must have all
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = c_i

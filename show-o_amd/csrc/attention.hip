@@ -466,12 +466,7 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             }
             // interior sub-tile: every row of the wave sees all 32 keys -> no per-element mask work
             const bool inner = !dense && __all(((lo1 <= ks) & (ks + 32 <= hi1)) | ((lo2 <= ks) & (ks + 32 <= hi2)));
-            float sv[16];
-            float mx = -INFINITY;
-            if (inner) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sv[r] = s[r]; mx = fmaxf(mx, sv[r]); }
-            } else {
+            if (!inner) {  // masked in place (no second copy of the score tile)
                 const unsigned len1 = (unsigned)max(hi1 - lo1, 0), len2 = (unsigned)max(hi2 - lo2, 0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -479,11 +474,17 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
                     const bool vis = ((unsigned)(key - lo1) < len1) | ((unsigned)(key - lo2) < len2);
                     float x = s[r];
                     if (dense) x += (key < a.Lk) ? drow[key] : 0.f;
-                    sv[r] = vis ? x : -INFINITY;
-                    mx = fmaxf(mx, sv[r]);
+                    s[r] = vis ? x : -INFINITY;
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+            mx = fmaxf(mx, s[15]);
+            {   // the row's other 16 keys sit 32 lanes away: one VALU swap instead of a trip through the LDS crossbar
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             // deferred rescale: the running max is only advanced (and O, l rescaled) when some row's tile max exceeds
             // it by more than AT_DEFER; otherwise P = exp(S - m_old) <= e^AT_DEFER, still exact in the final ratio
             if (__any(mx > m_run + AT_DEFER)) {
@@ -496,13 +497,15 @@ __device__ __forceinline__ void attn_lds_body(const AttnArgs& a, bf16_t* sm, int
             }
             const float mb = ((m_run == -INFINITY) ? 0.f : m_run) * LOG2E;
             float p[16];
-            float ps = 0.f;
+            f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -mb));
-                ps += p[r];
+            for (int r = 0; r < 16; r += 2) {  // two scores per v_pk_fma_f32 / v_pk_add_f32 (same fp32 operations per element)
+                const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s[r], s[r + 1]}, (f32x2_t){LOG2E, LOG2E}, (f32x2_t){-mb, -mb});
+                p[r] = __builtin_amdgcn_exp2f(t[0]);
+                p[r + 1] = __builtin_amdgcn_exp2f(t[1]);
+                ps2 += (f32x2_t){p[r], p[r + 1]};
             }
-            l_run += ps;
+            l_run += ps2[0] + ps2[1];
             bf16x8 pb0, pb1;
             uint4 u0, u1;
             {
@@ -582,6 +585,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void attn_fwd_lds_split_kernel(AttnArg
 }
 
 
+// (Round 6 measured the two stray query rows of the 258-row t2i step (258 = 2 x 128 + 2) as VALU single-row blocks co-scheduled in the
+// same launch -- v_dot2 scores, block soft-max, P V from the key-contiguous V^T rows -- instead of an MFMA block with 30 rows of padding:
+// SLOWER, 33.4 vs 29.5 us (tools/attn_bench.py, profiles/r6_attention_ab.txt: the serial load -> score -> soft-max -> load chain of a
+// stray block outlasts the MFMA stub), and rows then get different bits depending on which path serves them, which breaks the
+// prefix-reuse == recompute property.  Not in the library.)
 // (Round 5 measured a RESIDENT form -- the whole key range of a head staged into LDS up front, one 576-thread block per (batch, head),
 // no barrier in the key loop; bit-identical to attn_lds_body -- and it was slower: 312 vs 346 TF/s at the t2i shape, 37.8 vs 38.4
 // images/s on one box (profiles/r5m_attention_resident_ab.txt): 112 KiB of LDS leave one block per CU and the up-front stage is bound by
@@ -890,12 +898,6 @@ static int g_attn_forced = -1;
 
 extern "C" int showo_attn_set_impl(int impl) {
     g_attn_forced = (impl >= 1 && impl <= 3) ? impl : 0;  // 1 gather, 2 LDS double-buffered, 3 the same with 3 blocks per CU
-    return 0;
-}
-
-static int g_attn_variant = 0;
-extern "C" int showo_attn_set_variant(int variant) {
-    g_attn_variant = variant;
     return 0;
 }
 

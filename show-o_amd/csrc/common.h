@@ -180,10 +180,31 @@ __device__ inline int wave_max_i(int v) {
     return v;
 }
 
+// gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + 2^(x (C1 + C3 x^2))),  u = sqrt(2/pi) (x + 0.044715 x^3),
+// C1 = -2 log2(e) sqrt(2/pi), C3 = 0.044715 C1: 3 multiplies + 1 fma + 1 add around v_exp_f32 / v_rcp_f32 (round 6; the literal
+// transcription of the formula cost 8 -- the fc1 half of the projection epilogue is VALU-bound on it: DESIGN.md).  The packed form
+// evaluates two values per v_pk_*_f32 instruction and gives the SAME bits per element (IEEE fp32 operations either way).
+constexpr float GELU_C1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+constexpr float GELU_C3 = GELU_C1 * 0.044715f;
 __device__ inline float gelu_new_fast(float x) {
-    // gelu_new(x) = 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
-    float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+    const float p = __builtin_fmaf(x * x, GELU_C3, GELU_C1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+}
+__device__ inline f32x2_t gelu_new_fast2(f32x2_t x) {
+    const f32x2_t p = __builtin_elementwise_fma(x * x, (f32x2_t){GELU_C3, GELU_C3}, (f32x2_t){GELU_C1, GELU_C1});
+    const f32x2_t t = x * p;
+    const f32x2_t e = (f32x2_t){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2_t){1.0f, 1.0f};
+    return x * (f32x2_t){__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
+__device__ __forceinline__ void gelu4(float (&v)[4]) {
+    const f32x2_t a = gelu_new_fast2((f32x2_t){v[0], v[1]}), c = gelu_new_fast2((f32x2_t){v[2], v[3]});
+    v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
+}
+// v[r] = gelu_new(v[r] + b[r]), r = 0..3, on the packed forms (the bias add included: v_pk_add_f32)
+__device__ __forceinline__ void gelu4_bias(float (&v)[4], const float (&b)[4]) {
+    const f32x2_t a = gelu_new_fast2((f32x2_t){v[0], v[1]} + (f32x2_t){b[0], b[1]});
+    const f32x2_t c = gelu_new_fast2((f32x2_t){v[2], v[3]} + (f32x2_t){b[2], b[3]});
+    v[0] = a[0]; v[1] = a[1]; v[2] = c[0]; v[3] = c[1];
 }
 
 // acc + w[0] a[0] + w[1] a[1] on packed bf16 pairs: v_dot2c_f32_bf16 (gfx950), no bf16 -> fp32 conversions (the converting FMA form

@@ -274,12 +274,13 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
         }                                                                                                         \
     } while (0)
     __shared__ int s_last;
+    __shared__ int s_ml[2];  // splitk_coop_finish's mode / last-arriver flags: shared by BOTH wave groups
     constexpr int NFS = 4 * (MF0 > MF1 ? MF0 : MF1);
     if (MF0 == MF1 || wm == 0) {
         Q2_RUN(MF0);
         if (wm == 0) bar_raw_fn();  // re-align the barrier counts of the two groups
         if constexpr (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT) {
-            if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF0, NFS, F16>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg); return; }
+            if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF0, NFS, F16>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg, s_ml); return; }
         }
         if (g.splits > 1 && !splitk_exchange<MF0, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
         if constexpr (EPI == EPI_QKV_SPLIT) epilogue_qkv_split<MF0>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm2p_kernel(GemmArgs g) {
     } else {
         Q2_RUN(MF1);
         if constexpr (EPI != EPI_QKV && EPI != EPI_QKV_SPLIT) {
-            if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF1, NFS, F16>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg); return; }
+            if (g.splits > 1 && g.coop) { splitk_coop_finish<EPI, MF1, NFS, F16>(g, acc, tm * tilesN + tn, split, n0, wn, m0 + gbase, fr, fg, s_ml); return; }
         }
         if (g.splits > 1 && !splitk_exchange<MF1, NFS>(g, acc, tm * tilesN + tn, split, &s_last)) return;
         if constexpr (EPI == EPI_QKV_SPLIT) epilogue_qkv_split<MF1>(g, acc, n0, wn, m0 + gbase, fr, fg, g_stage ? smem + wave * 8192 : nullptr);

@@ -83,8 +83,7 @@ static __device__ inline void store_frag(const GemmArgs& g, const f32x4& acc, in
     const bool full = (n + 3 < g.N) && g.vec_out;
     if (EPI == SHOWO_EPI_BF16 || EPI == SHOWO_EPI_GELU_BF16) {
         if (EPI == SHOWO_EPI_GELU_BF16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_new_fast(v[r]);
+            gelu4(v);
         }
         bf16_t* o = reinterpret_cast<bf16_t*>(g.out) + (int64_t)m * g.ldo + n;
         if (full) {
@@ -205,7 +204,7 @@ static __device__ __forceinline__ bool splitk_exchange(const GemmArgs& g, f32x4 
 // tick[2048 + tile] departures, tick[4096 + tile] holds the tile's mode; the last block to leave zeroes all three for the next launch.
 template <int EPI, int MF, int NFS, bool F16 = false>
 static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32x4 (&acc)[4][8], int tile, int split, int n0, int wn, int mrow0,
-                                                          int fr, int fg) {
+                                                          int fr, int fg, int* s_ml) {  // s_ml: two ints of LDS declared ONCE by the kernel
     const int tid = threadIdx.x;
     float4* base = g.ws + (size_t)tile * g.splits * NFS * 512;
     float4* mine = base + (size_t)split * NFS * 512 + tid;
@@ -236,7 +235,11 @@ static __device__ __forceinline__ void splitk_coop_finish(const GemmArgs& g, f32
     // g.coop_polls polls (~2 ms: they are not resident -- another process on the GPU, a CU mask the host did not know about) no longer
     // traps (round 5: __builtin_trap after ~100 s): it switches the TILE to the last-arriver form and leaves; the block whose arrival
     // completes the count then sums every partial alone.  Same split order per element in both forms: the same bits.
-    __shared__ int s_mode, s_last;
+    // (The two block-wide flags come from the KERNEL: a function-scope __shared__ here is one variable per template instance, and the
+    //  two wave groups of a tile with MF0 != MF1 call different instances -- group 1 then read flags nobody wrote.  Round 6, found by
+    //  the full-size [2,387] fixture once the tuner picked a 5 + 4 tile for a split launch.)
+    int& s_mode = s_ml[0];
+    int& s_last = s_ml[1];
     if (tid == 0) {
         if (g.coop != 2) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -346,8 +349,10 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     const int m = mrow0 + j * 16 + fr;
                     uint2 pk;
                     // (training: acc holds the rounded pre-activation and bn is 0 -> the bits of showo_gelu_bf16 on the saved tensor)
-                    pk.x = Op16<F16>::pack2(gelu_new_fast(acc[i][j][0] + bn[0]), gelu_new_fast(acc[i][j][1] + bn[1]));
-                    pk.y = Op16<F16>::pack2(gelu_new_fast(acc[i][j][2] + bn[2]), gelu_new_fast(acc[i][j][3] + bn[3]));
+                    float gv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    gelu4_bias(gv, bn);
+                    pk.x = Op16<F16>::pack2(gv[0], gv[1]);
+                    pk.y = Op16<F16>::pack2(gv[2], gv[3]);
                     if (staged) stage_frag_bf16(stg, j * 16 + fr, i, fg, pk);
                     else if (m < g.M && n < g.N) *reinterpret_cast<uint2*>(g.out2 + (int64_t)m * g.ldo2 + (n - g.Nq)) = pk;
                 }
@@ -537,9 +542,9 @@ static __device__ __forceinline__ void epilogue8p(const GemmArgs& g, f32x4 (&acc
                     for (int j = 0; j < MF; ++j) {
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v[r] = acc[i][j][r] + bn[r] + 0.f;  // same expression as store_frag (bias per row = 0)
-                            if (EPI == SHOWO_EPI_GELU_BF16) v[r] = gelu_new_fast(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bn[r] + 0.f;  // same expression as store_frag (bias per row = 0)
+                        if (EPI == SHOWO_EPI_GELU_BF16) {
+                            gelu4(v);
                         }
                         uint2 pk;
                         pk.x = Op16<F16>::pack2(v[0], v[1]);

@@ -773,7 +773,7 @@ def test_gemm_tn_fast_form_ignores_nan_padding_rows(M, N, T):
 SPLITK_OFF, SPLITK_ON = 64, 128  # showo_gemm_tune flag bits
 
 
-@pytest.mark.parametrize("variant", [0, 256, 208, 176, 144, 1192, 1160, 1128])
+@pytest.mark.parametrize("variant", [0, 256, 208, 176, 144, 1192, 1176, 1160, 1144, 1128])  # 1176 = 6 + 5, 1144 = 5 + 4: wave groups of different height
 @pytest.mark.parametrize("M,N,K", [(577, 1024, 4096), (631, 2048, 2048), (300, 700, 2048)])
 def test_gemm_splitk_epilogues(variant, M, N, K):
     """Launches with few tiles and a long K (the M = 631 prefill, the CLIP tower) split K over tiles x splits ~ 256 blocks; the last

@@ -2,8 +2,8 @@
 B = 16 CFG-doubled rows, 32 heads, 258 query rows <soi> + 256 image tokens + <eoi>, 387 keys; per-row visibility interval as
 synthetic.t2i_inputs builds it: conditional rows see their 2..37 text tokens + the image block, unconditional rows the image block).
 usage: python tools/attn_bench.py [--variants 0,1,2] [--reps 200] [--op 0|1] [--B 16 --Lq 258 --Lk 387]
-Prints us per launch and TF/s (4 B nH Lq Lk 64 flops) per variant (showo_attn_set_variant), and the max |difference| of every variant's
-output against variant 0 (the same inputs)."""
+Prints us per launch and TF/s (4 B nH Lq Lk 64 flops) per implementation (showo_attn_set_impl: 0 = by shape, 1 = gather form,
+2 = LDS-tiled, 3 = LDS-tiled at 3 waves / SIMD), and the max |difference| of every implementation's output against the first."""
 import argparse
 import os
 import sys
@@ -54,7 +54,7 @@ def main():
     flops = 4.0 * B * nH * Lq * Lk * 64
     ref = None
     for v in [int(x) for x in a.variants.split(",")]:
-        L.call("showo_attn_set_variant", v)
+        L.call("showo_attn_set_impl", v)
         O.zero_()
         launch()
         torch.cuda.synchronize()
@@ -77,7 +77,7 @@ def main():
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / a.reps * 1e3)
         print(f"variant {v}: {best:7.2f} us per launch = {flops / best / 1e6:6.1f} TF/s; max |o - o_variant0| = {diff:.3e} (|o| max {float(ref.abs().max()):.2f})")
-    L.call("showo_attn_set_variant", 0)
+    L.call("showo_attn_set_impl", 0)
 
 
 if __name__ == "__main__":
