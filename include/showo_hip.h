@@ -287,7 +287,7 @@ int showo_mask_tokens(const int64_t* tokens, const float* noise, const int32_t* 
  * iv == NULL and flag == NULL: causal (query r sees keys <= r + Lk - Lq). */
 /* kernel selection for tests/benchmarks: 0 = by shape (default: LDS-tiled for Lq >= 64), 1 = gather form (one wave
  * per 32 query rows, operands straight from L2), 2 = LDS-tiled form (4 waves share 64-key K / V^T tiles staged by
- * global_load_lds; 4 waves/SIMD), 3 = the same at 3 waves/SIMD (no register spill) */
+ * global_load_lds; 4 waves/SIMD, no register spill) */
 int showo_attn_set_impl(int impl);
 /* AR decode step (one new token against the KV cache): 0 = fused layer, three launches (LN + qkv/fc1 GEMV; prep +
  * single-query attention with the fc2 GEMV co-scheduled on the CUs the 32 attention blocks leave idle (F = 8192 only);

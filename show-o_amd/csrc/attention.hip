@@ -913,12 +913,9 @@ extern "C" int showo_mask_compress(const float* mask, int32_t* iv, int32_t* flag
 static int g_attn_forced = -1;
 
 extern "C" int showo_attn_set_impl(int impl) {
-    g_attn_forced = (impl >= 1 && impl <= 3) ? impl : 0;  // 1 gather, 2 LDS double-buffered, 3 the same with 3 blocks per CU
+    g_attn_forced = (impl >= 1 && impl <= 2) ? impl : 0;  // 1 gather, 2 LDS-tiled
     return 0;
 }
-
-static int g_attn_wpb5 = -1;  // SHOWO_ATTN_WPB5=1: five query tiles per block where that saves a block per (b, head).  Opt-in: measured
-                              // SLOWER in one box (attention 214-217 vs 286-294 TF/s, 32.0 vs 33.1 images/s): the fifth wave shares a SIMD
 
 // XCD-aware 1-D grid of the LDS-tiled form (SHOWO_ATTN_XCD=0: the natural 3-D grid)
 static dim3 grid_f16(AttnArgs& a, int nqb, int nH, int B) {
@@ -943,7 +940,6 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
     int qblocks = (Lq + 31) / 32;
     ProfScope prof(PROF_ATTN, 4.0 * B * nH * (double)Lq * Lk * 64, (hipStream_t)stream);  // dense QK^T + PV flops
     if (g_attn_forced < 0) { const char* e = getenv("SHOWO_ATTN_IMPL"); g_attn_forced = e ? atoi(e) : 0; }
-    if (g_attn_wpb5 < 0) { const char* e = getenv("SHOWO_ATTN_WPB5"); g_attn_wpb5 = e ? (atoi(e) != 0) : 0; }
     const int forced = g_attn_forced;  // 1 = gather form, 2 = LDS-tiled form, else by shape
     const bool tiled = lse != nullptr || forced >= 2 || (forced != 1 && Lq >= 64);  // only the tiled form writes lse  // decode steps (a few query rows) keep the gather form
     if (Lq == 1 && forced != 1 && !lse) {  // AR decode step
@@ -964,18 +960,10 @@ static int attn_fwd_impl(const uint16_t* Q, const uint16_t* K, const uint16_t* V
         return 0;
     }
     // SHOWO_ATTN_XCD (default 1): XCD-aware 1-D block order (attn_block_coords); 0 = the natural 3-D grid (A/B runs).
-    // SHOWO_ATTN_WPB9=1: all (up to 9) query tiles of a (batch, head) in ONE 576-thread block -- every K / V^T tile is staged once per
-    // (batch, head) -- for 129 <= Lq <= 288 (the 258 active rows of the t2i loop).
-    static int xcd = -1, wpb9 = -1;
+    static int xcd = -1;
     if (xcd < 0) { const char* e = getenv("SHOWO_ATTN_XCD"); xcd = e ? (atoi(e) != 0) : 1; }
-    if (wpb9 < 0) { const char* e = getenv("SHOWO_ATTN_WPB9"); wpb9 = e ? (atoi(e) != 0) : 0; }
     auto grid = [&](int nqb) { if (xcd) { a.nqb = nqb; return dim3((unsigned)nqb * nH * B); } a.nqb = 0; return dim3(nqb, nH, B); };
-    if (tiled && forced == 3) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<3><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
-    else if (tiled && wpb9 && qblocks > 4 && qblocks <= 9) { const dim3 g = grid(1); attn_fwd_lds_kernel<2, 9><<<g, dim3(576), 0, (hipStream_t)stream>>>(a); }
-    else if (tiled && (qblocks + 4) / 5 < (qblocks + 3) / 4 && g_attn_wpb5) {  // five query tiles per block save a block per (b, head)
-        const dim3 g = grid((qblocks + 4) / 5);
-        attn_fwd_lds_kernel<3, 5><<<g, dim3(320), 0, (hipStream_t)stream>>>(a);
-    } else if (tiled) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<4><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
+    if (tiled) { const dim3 g = grid((qblocks + 3) / 4); attn_fwd_lds_kernel<4><<<g, dim3(256), 0, (hipStream_t)stream>>>(a); }
     else attn_fwd_kernel<false><<<dim3((qblocks + 3) / 4, nH, B), dim3(256), 0, (hipStream_t)stream>>>(a);
     SHOWO_CHECK_HIP(hipGetLastError());
     return 0;

@@ -530,33 +530,6 @@ extern "C" int showo_copy_b128(const void* src, void* dst, int64_t nbytes, void*
     return 0;
 }
 
-// ---- Infinity-Cache warm-up of a weight image ---------------------------------------------------------------------------------
-// A few blocks read [p, p + nbytes) once with default-policy loads and drop the data: the lines land in the die-level Infinity Cache
-// (256 MiB, memory side, shared by the 8 XCDs), so a GEMM that starts later finds its weight tiles there instead of paying the
-// HBM latency on the first touch of every tile.  Runs on a side stream NEXT to a compute-bound kernel (engine.hip, SHOWO_MALL_PF).
-namespace {
-__global__ __launch_bounds__(256) void mall_warm_kernel(const uint4* __restrict__ p, int64_t n16, int* __restrict__ sink) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    uint32_t acc = 0;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc ^= a.x ^ b.y ^ c.z ^ d.w;
-    }
-    for (; i < n16; i += stride) acc ^= p[i].x;
-    if (acc == 0x9e3779b9u && sink) atomicAdd(sink, 1);  // never true in practice; keeps the loads alive
-}
-}  // namespace
-
-namespace showo {
-int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t s) {
-    if (nbytes < 16 || blocks <= 0) return 0;
-    mall_warm_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const uint4*)p, nbytes >> 4, sink);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_error_hip(e, "mall_warm launch", __FILE__, __LINE__);
-    return 0;
-}
-}  // namespace showo
 
 
 // ---- CU census (tests of showo_stream_create_cu_mask): where do the blocks of a launch on this stream run?

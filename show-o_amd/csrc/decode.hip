@@ -36,8 +36,7 @@ struct LnGemvArgs {
     int N1;
 };
 
-// R = weight rows in flight per wave (2 by default; R = 4 with a grid of Ntot / 16 blocks requests every row of a layer's 58.7 MB at
-// kernel start -- see decode_ln_gemv2 for the measurement); larger matrices (lm_head) loop and refill.
+// R = weight rows in flight per wave (2; see decode_ln_gemv2 for the measurement of 4); larger matrices (lm_head) loop and refill.
 template <int R, bool F16 = false>
 __global__ __launch_bounds__(256) void ln_gemv2_kernel(LnGemvArgs g) {  // H <= 2048: one 4-load group covers a weight row
     extern __shared__ bf16_t sh[];  // normalised row, bf16 like showo_layernorm_f32_bf16's output
@@ -184,14 +183,12 @@ bool decode_fused_shapes_ok(int H, int F) { return (H % 8) == 0 && (F % 8) == 0 
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
                     bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s, int op) {
     LnGemvArgs g{x, lnw, lnb, eps, H, W0, b0, out0, outf, N0, W1, b1, out1, N1};
-    // rows in flight per wave: 2 (default: 12 rows per block, a wave's third row is requested behind its first FMA) or 4
-    // (SHOWO_DECODE_LNR=4: the whole layer matrix requested at kernel start; measured SLOWER on cfg4, 0.983-0.992 vs 0.958-0.969 ms per
-    // token in one box, gpurun_out/bench_mmu_r2z_*: 123 VGPRs halve the resident waves and the single burst queues behind itself)
-    static int lnr = 0;
-    if (!lnr) { const char* e = getenv("SHOWO_DECODE_LNR"); lnr = (e && atoi(e) == 4) ? 4 : 2; }
-    if (op) ln_gemv2_kernel<2, true><<<dim3(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
-    else if (lnr == 2) ln_gemv2_kernel<2><<<dim3(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
-    else ln_gemv2_kernel<4><<<dim3(pick_blocks(N0 + N1, 16, 1024)), dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    // two weight rows in flight per wave (12 rows per block; a wave's third row is requested behind its first FMA).  Four rows -- the whole
+    // layer matrix requested at kernel start -- measured SLOWER on cfg4 (0.983-0.992 vs 0.958-0.969 ms per token, round 2: 123 VGPRs halve
+    // the resident waves and the single burst queues behind itself); that instance left the library in round 6.
+    const dim3 grid(pick_blocks(N0 + N1, 12, showo::decode_tuning().ln_blocks));
+    if (op) ln_gemv2_kernel<2, true><<<grid, dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
+    else ln_gemv2_kernel<2><<<grid, dim3(256), (size_t)H * sizeof(bf16_t), s>>>(g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error_hip(e, "ln_gemv2 launch", __FILE__, __LINE__);
     return 0;

@@ -61,7 +61,6 @@ struct DecodeTuning {
 DecodeTuning& decode_tuning();
 int greedy_token_seam(const float* logits, int n, int64_t* tok, int64_t* out_tokens, int* pos, int base, const float* table, float* x, int H,
                       int V, const int32_t* last_iv, int L0, int32_t* iv, hipStream_t s);
-int mall_warm(const void* p, int64_t nbytes, int blocks, int* sink, hipStream_t s);
 // accuracy-mode kernels (precise.hip)
 int precise_ln_split(const float* x, const float* w, const float* b, const int32_t* row_index, bf16_t* hi, bf16_t* lo, int rows, int H,
                      float eps, hipStream_t s);
@@ -123,8 +122,6 @@ struct showo_engine {
     int* pos_dev = nullptr;
     int32_t* last_iv_dev = nullptr;
     // second stream for the two independent branches of a Phi block (attention branch | fc1): see run_layers
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_fc1 = nullptr;
     float* y2 = nullptr;  // forked decode layer: fc2 + b2 of the current layer
     // hipGraph replay of the denoise step: instantiated graphs of one active-rows step are cached (small LRU), keyed by everything
     // BAKED into their launches: shapes, scalars, and every pointer that is neither engine-owned-and-fixed nor refreshed per call.

@@ -163,9 +163,6 @@ extern "C" void showo_engine_destroy(showo_engine* e) {
         if (ge.exec) hipGraphExecDestroy(ge.exec);
     if (e->ev_pfx) hipEventDestroy(e->ev_pfx);
     if (e->pfx_host) hipHostFree(e->pfx_host);
-    if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    if (e->ev_fc1) hipEventDestroy(e->ev_fc1);
-    if (e->side) hipStreamDestroy(e->side);
     showo::engine_batch_free(e);
     for (void* p : e->allocs) hipFree(p);
     delete e;
@@ -373,15 +370,6 @@ extern "C" int showo_decode_set_impl(int impl) {
 static KVDest kv_decode_cache(showo_engine* e) {
     return KVDest{e->kcache, e->vtcache, (int64_t)e->nH * e->cache_cap * 64, (int64_t)e->nH * 64 * e->cache_cap, e->cache_cap, e->cache_cap,
                   e->kcache_lo, e->vtcache_lo};
-}
-
-static bool layer_overlap_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* env = getenv("SHOWO_LAYER_OVERLAP");
-        v = env ? (atoi(env) != 0) : 0;
-    }
-    return v != 0;
 }
 
 // parity hook (showo_engine_set_collect): copy the fp32 residual stream after layer `slot - 1` (slot 0 = the embeddings)
@@ -717,37 +705,24 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
     const int Lcap = kv.Lcap, Lp = kv.Lp;
     // (the fused three-launch decode layer of decode.hip has instances for both operand types since round 6)
     if (T == 1 && showo::g_decode_impl == 0 && !dense && showo::decode_fused_shapes_ok(H, F) && (size_t)Lcap * 4 + 2048 <= 60000) {
-        // AR decode step (decode.hip): three launches per layer.  Forked layer (opt-in, SHOWO_DECODE_FORK=1; measured SLOWER: 705-711 vs
-        // 843-846 tokens/s in one box, gpurun_out/bench_mmu_r2k_*: every fork / join edge of the per-token graph costs more than the
-        // overlap buys, like the side-stream weight prefetch of round 1): fc1 and fc2 do not depend on the attention, so their 67 MB
-        // of weights can stream on a second stream while the latency-bound single-query attention (32 blocks on 256 CUs) runs:
-        //   s:    LN + qkv GEMV ------> attention (prep + cache append + softmax) ----join--> dense GEMV + both residual adds
-        //   side:                  \--> LN + fc1 GEMV + GELU --> fc2 GEMV (-> y2) --------/
-        // Same arithmetic and parenthesisation as the chain (x = (x + (dense + bd)) + (fc2 + b2)): bit-identical results.
-        // Co-scheduled layer (SHOWO_DECODE_FORK=2): the same overlap WITHOUT graph edges -- the attention launch carries extra blocks
-        // that stream the fc2 weights into y2 (attention.hip, attn_decode_co_kernel), the third launch adds dense(attn) and y2:
+        // AR decode step (decode.hip): three launches per layer.  Co-scheduled layer (default): the attention launch carries extra
+        // blocks that stream the fc2 weights into y2 (attention.hip, attn_decode_co_kernel) -- fc2 does not depend on the attention
+        // (Phi's block is parallel-residual) -- and the third launch adds dense(attn) and y2:
         //   LN + qkv GEMV + fc1 GEMV  ->  [ attention (32 blocks) || fc2 GEMV -> y2 (co_blocks) ]  ->  dense GEMV + both residual adds
-        // Measured (gpurun_out/bench_mmu_r2p_*, one box, cfg4): chain 857-861 tokens/s; co-scheduled 922-928 with 224 fc2 blocks,
-        // 965 with 128, 969 with 96 (fewer, fuller blocks leave the attention blocks' CUs alone) -> default, SHOWO_DECODE_FORK=0 is the chain.
-        static int fork_on = -1;
-        if (fork_on < 0) {
+        // Same arithmetic and parenthesisation as the plain chain (x = (x + (dense + bd)) + (fc2 + b2)): bit-identical results.
+        // Measured (gpurun_out/bench_mmu_r2p_*, one box, cfg4): chain 857-861 tokens/s; co-scheduled 922-928 with 224 fc2 blocks, 965
+        // with 128, 969 with 96.  (A stream fork / join of the same overlap was SLOWER than the chain, 705-711 vs 843-846 tokens/s --
+        // every fork / join edge of the per-token graph costs more than the overlap buys -- and left the library in round 6; so did
+        // folding the third launch into the second behind an in-launch hand-off, profiles/r6_decode_merge_ab.txt.)
+        // SHOWO_DECODE_FORK=0 / showo_decode_set_impl(2): the plain chain.
+        static int co_on = -1;
+        if (co_on < 0) {
             const char* env = getenv("SHOWO_DECODE_FORK");
-            fork_on = env ? atoi(env) : 2;
+            co_on = env ? (atoi(env) != 0) : 1;
         }
         const int co_blocks = showo::decode_tuning().co_blocks;
-        bool fork = fork_on == 1;
-        const bool co = fork_on == 2 && F == 8192 && !g_decode_chain;
+        const bool co = co_on && F == 8192 && !g_decode_chain;
         if (co && !e->y2) TRY(e->alloc(&e->y2, H));
-        if (fork && !e->side) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            hipStreamIsCapturing(s, &cs);
-            if (cs != hipStreamCaptureStatusNone) fork = false;  // never create the stream inside a capture
-            else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_fc1, hipEventDisableTiming) != hipSuccess)
-                return set_error_msg(7, "engine: cannot create the side stream");
-        }
-        if (fork && !e->y2) TRY(e->alloc(&e->y2, H));
         for (int li = 0; li < e->nL; ++li) {
             showo::Layer& l = e->layers[li];
             bf16_t* Kd = kv.k + li * kv.k_lstride;
@@ -762,70 +737,30 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
                 TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2, op));
                 continue;
             }
-            if (!fork) {
-                TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
-                                           e->ffn, F, s, op));
-                TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
-                                             e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, op));
-                TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 0, nullptr, op));
-                continue;
-            }
-            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));  // x of this layer is final
-            SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, nullptr, nullptr,
-                                       nullptr, 0, s, op));
-            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, nullptr, nullptr, nullptr, nullptr, 0, l.w1, l.b1, e->ffn, F,
-                                       e->side, op));
-            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, e->side, 1, e->y2, op));
-            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
+            TRY(showo::decode_ln_gemv2(e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, l.w1, l.b1,
+                                       e->ffn, F, s, op));
             TRY(showo::attn_decode_fused(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, Kd, Vd, iv, e->attn, nH,
                                          e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp, s, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, op));
-            SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
-            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 2, e->y2, op));
+            TRY(showo::decode_out_gemv2(e->x, l.wd, e->attn, l.bd, H, l.w2, e->ffn, l.b2, F, H, s, 0, nullptr, op));
         }
         return 0;
     }
     // Prefill / t2i layers: TWO GEMM launches.  Phi's block is parallel-residual (phi.py:774-790): q/k/v_proj and fc1 read the
     // same LayerNorm output -> one [Wqkv ; W1] projection with a column-split epilogue; dense and fc2 add into the same residual
     // row -> one K-concatenated GEMM over [attn | ffn] with a single read-modify-write of x.
-    const bool fused = T >= 256 && e->cfg.rotary_dim == 32 && fused_layer_enabled() && !layer_overlap_enabled() && (3 * H) % 256 == 0 &&
+    const bool fused = T >= 256 && e->cfg.rotary_dim == 32 && fused_layer_enabled() && (3 * H) % 256 == 0 &&
                        (int64_t)T * F * 2 < ((int64_t)1 << 32);
     if (fused) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         hipStreamIsCapturing(s, &cs);
         if (!e->fused_valid && cs != hipStreamCaptureStatusNone) return set_error_msg(7, "engine: fused weight images must be built before a stream capture");
         TRY(fused_sync(e, s));
-        // Infinity-Cache warm-up of the NEXT GEMM's weight image on a side stream (SHOWO_MALL_PF bit 0: [Wd | W2] of this layer next
-        // to the projection GEMM; bit 1: [Wqkv ; W1] of the next layer next to the K-concatenated GEMM).  24 layers x 100 MB of
-        // weights cycle through a 256 MiB cache, so every weight tile is otherwise an HBM first touch (basic.hip, mall_warm).
-        static int mall_pf = -1, mall_blocks = 64;
-        if (mall_pf < 0) {
-            const char* env = getenv("SHOWO_MALL_PF");
-            mall_pf = env ? atoi(env) : 0;
-            const char* eb = getenv("SHOWO_MALL_PF_BLOCKS");
-            if (eb && atoi(eb) > 0) mall_blocks = atoi(eb);
-        }
-        int pf = mall_pf;
-        if (pf && !e->side) {
-            if (cs != hipStreamCaptureStatusNone) pf = 0;  // never create the stream inside a capture
-            else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&e->ev_fc1, hipEventDisableTiming) != hipSuccess)
-                return set_error_msg(7, "engine: cannot create the side stream");
-        }
-        const int64_t wq1_bytes = (int64_t)(3 * H + F) * H * 2, wd2_bytes = (int64_t)H * (H + F) * 2;
         for (int li = 0; li < e->nL; ++li) {
             showo::Layer& l = e->layers[li];
             bf16_t* Kd = kv.k + li * kv.k_lstride;
             bf16_t* Vd = kv.vt + li * kv.v_lstride;
             TRY(showo_layernorm_f32_op16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, op, s));
             TRY(range_check(e, e->h, (int64_t)T * H, s));
-            if (pf & 1) {
-                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
-                SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-                TRY(showo::mall_warm(l.wd2, wd2_bytes, mall_blocks, nullptr, e->side));
-                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
-            }
             TRY(showo_gemm_qkv_fc1_op16(e->h, H, e->fused_tiled ? l.wq1t : l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT,
                                         e->sinT, e->Q, Kd, Vd, e->ffn, F, F, B, L, nH, e->cfg.rotary_dim, e->cfg.ln_eps, pos0, Lcap, Lp,
                                         e->fused_tiled ? 1 : 0, op, s));
@@ -833,31 +768,11 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
             TRY(range_check(e, e->ffn, (int64_t)T * F, s));
             TRY(showo_attn_fwd_op16(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, op, s));
             TRY(range_check(e, e->attn, (int64_t)T * H, s));
-            if (pf & 1) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
-            const bool pf2 = (pf & 2) && li + 1 < e->nL;
-            if (pf2) {
-                showo::Layer& nx = e->layers[li + 1];
-                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
-                SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-                TRY(showo::mall_warm(e->fused_tiled ? nx.wq1t : nx.wqkv, wq1_bytes, mall_blocks, nullptr, e->side));
-                SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
-            }
             TRY(showo_gemm_kcat_op16(e->attn, H, H, e->ffn, F, F, l.wd2, H + F, l.bd2, e->x, H, e->x, H, T, H, SHOWO_EPI_RESID_F32,
                                      e->fused_tiled ? 1 : 0, op, s));
-            if (pf2) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
             TRY(collect_x(e, li + 1, T, s));
         }
         return 0;
-    }
-    bool overlap = T >= 1024 && layer_overlap_enabled();
-    if (overlap && !e->side) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        hipStreamIsCapturing(s, &cs);
-        if (cs != hipStreamCaptureStatusNone) overlap = false;  // never create the stream inside a capture
-        else if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-                 hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                 hipEventCreateWithFlags(&e->ev_fc1, hipEventDisableTiming) != hipSuccess)
-            return set_error_msg(7, "engine: cannot create the side stream");
     }
     for (int li = 0; li < e->nL; ++li) {
         showo::Layer& l = e->layers[li];
@@ -865,17 +780,6 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         bf16_t* Vd = kv.vt + li * kv.v_lstride;
         TRY(showo_layernorm_f32_op16(e->x, l.ln_w, l.ln_b, e->h, nullptr, T, H, e->cfg.ln_eps, op, s));
         TRY(range_check(e, e->h, (int64_t)T * H, s));
-        // Phi's block is parallel (phi.py:774-790): the attention branch (qkv -> attention -> dense) and fc1 both read the
-        // same LayerNorm output.  fc1 goes to a second stream so that its tiles fill the CUs the other branch leaves idle
-        // (partial last rounds of the GEMMs, the latency-bound attention kernel); fc2 follows on the main stream once both
-        // dense (x += ...) and fc1 are done.  Layer 0 stays sequential: GEMM shapes are auto-tuned on first use, undisturbed.
-        const bool fork = overlap && li > 0;
-        if (fork) {
-            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fork, s));
-            SHOWO_CHECK_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-            TRY(showo_gemm_op16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, op, e->side));
-            SHOWO_CHECK_HIP(hipEventRecord(e->ev_fc1, e->side));
-        }
         if (T >= 256 && e->cfg.rotary_dim == 32) {
             // prefill / t2i: one kernel (the projection's epilogue normalises, rotates and relayouts the fp32 accumulators)
             TRY(showo_gemm_qkv_fc1_op16(e->h, H, l.wqkv, H, l.bqkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, e->Q, Kd, Vd,
@@ -889,8 +793,7 @@ static int run_layers(showo_engine* e, int B, int L, int pos0, const KVDest& kv,
         TRY(showo_attn_fwd_op16(e->Q, Kd, Vd, iv, flag, dense, e->attn, B, nH, L, Lk, Lcap, Lp, H, op, s));
         TRY(range_check(e, e->attn, (int64_t)T * H, s));
         TRY(showo_gemm_op16(e->attn, H, l.wd, H, l.bd, 0, e->x, H, e->x, H, T, H, H, SHOWO_EPI_RESID_F32, op, s));
-        if (fork) SHOWO_CHECK_HIP(hipStreamWaitEvent(s, e->ev_fc1, 0));
-        else TRY(showo_gemm_op16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, op, s));
+        TRY(showo_gemm_op16(e->h, H, l.w1, H, l.b1, 0, e->ffn, F, nullptr, 0, T, F, H, SHOWO_EPI_GELU_BF16, op, s));
         TRY(range_check(e, e->ffn, (int64_t)T * F, s));
         TRY(showo_gemm_op16(e->ffn, F, l.w2, F, l.b2, 0, e->x, H, e->x, H, T, H, F, SHOWO_EPI_RESID_F32, op, s));
         TRY(collect_x(e, li + 1, T, s));

@@ -86,9 +86,9 @@ int splitk_coop_mode() {  // SHOWO_GEMM_COOP: 2 (default) = write-through (sc1) 
 // cooperative launches on different streams could each be partly resident and wait for each other until the trap, so ONE
 // stream at a time owns the cooperative form: the first stream that asks; another stream takes over only when the owner's last
 // cooperative launch has completed (event), and a stream that CAPTURED cooperative launches into a hipGraph keeps the ownership (the
-// graph may replay at any time).  Everybody else gets the last-arriver reduction: the same bits, no waiting.  Disabled altogether while
-// the opt-in side-stream experiments (SHOWO_LAYER_OVERLAP / SHOWO_MALL_PF) are on.  Work of ANOTHER PROCESS on the same GPU is outside
-// this gate: SHOWO_GEMM_COOP=0 there.
+// graph may replay at any time).  Everybody else gets the last-arriver reduction: the same bits, no waiting.  Work of ANOTHER PROCESS
+// on the same GPU is outside this gate, but no longer a hazard: a block whose siblings do not show up falls back to the last-arriver
+// form after coop_polls polls (gemm_common.h splitk_coop_finish).
 namespace {
 struct CoopOwner { hipStream_t s = nullptr; hipEvent_t ev = nullptr; bool sticky = false, used = false; };
 CoopOwner g_coop_owner;
@@ -98,9 +98,6 @@ bool splitk_coop_ok(int blocks, hipStream_t s) {  // caller holds g_gemm_mu
     if (on < 0) {
         const char* e = getenv("SHOWO_GEMM_COOP");
         on = e ? atoi(e) : 1;
-        const char* o1 = getenv("SHOWO_LAYER_OVERLAP");
-        const char* o2 = getenv("SHOWO_MALL_PF");
-        if (!e && ((o1 && atoi(o1)) || (o2 && atoi(o2)))) on = 0;
     }
     if (!on || (blocks + 7) / 8 > showo_cu_usable((void*)s) / 8) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
