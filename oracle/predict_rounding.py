@@ -5,7 +5,7 @@ Runs the rounding-point oracle (showo_oracle.Bf16Points: the fp32 restatement wi
 committed fp32 REFERENCE fixtures (tests/golden/showo_full_*.npz, written by the real reference through oracle/make_golden.py):
 
     python oracle/predict_rounding.py                 # fp16 + bf16 on the [2,387] fixture, then one site at a time (fp16)
-    python oracle/predict_rounding.py --cfg3 --cfg4   # the [8,1155] rows 1 / 5 and the 631-embedding prefill as well
+    python oracle/predict_rounding.py --cfg3          # rows 1 / 5 of the [8,1155] batch as well
     python oracle/predict_rounding.py --exempt w_lm,hf   # fp16 everywhere except the named sites (those stay fp32 = a (hi, lo) pair)
 
 "site" = one of Bf16Points.SITES: w (GEMM weights of the 24 blocks), w_lm, h (LayerNorm output), q, k, v, p (soft-max numerator),
@@ -66,29 +66,9 @@ def case_cfg3():
     return "cfg3 rows 1,5 of [8,1155]", run
 
 
-def case_cfg4():
-    g = np.load(os.path.join(GOLD, "showo_full_cfg4.npz"))
-    d = Wt.ShowoDims(w_clip_vit=True)
-    sd = O.to_torch(Wt.make_showo_state(d, seed=int(g["seed"])))
-    feats = torch.from_numpy(np.random.RandomState(int(g["feat_seed"])).standard_normal((1, 576, 1024)).astype(np.float32))
-    ids_llava = torch.from_numpy(g["ids_llava"].astype(np.int64))
-    txt = sd["showo.model.embed_tokens.weight"][ids_llava]
-    img = O.mm_projector({k[len("mm_projector."):]: v for k, v in sd.items() if k.startswith("mm_projector.")}, feats)
-    emb = torch.cat([txt[:, :30], img, txt[:, 30:]], dim=1)
-    mask = O.mask_mmu_vit(1, 631, system_prompt_len=28)
-    rows, cols = torch.from_numpy(g["rows"]), torch.from_numpy(g["cols"])
-    ref = torch.from_numpy(g["prefill_logits"])
-
-    def run(pts):
-        lg = O.showo_logits(sd, d, None, input_embeddings=emb, attention_mask=mask, pts=pts)
-        return relerr(lg[0][rows][:, cols], ref)
-    return "cfg4 prefill [1,631]", run
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg3", action="store_true")
-    ap.add_argument("--cfg4", action="store_true")
     ap.add_argument("--no-387", action="store_true", help="skip the [2,387] fixture")
     ap.add_argument("--no-sites", action="store_true", help="skip the one-site-at-a-time table")
     ap.add_argument("--only", default="", help="comma list: round ONLY these sites (fp16)")
@@ -96,7 +76,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
-    cases = ([] if a.no_387 else [case_387]) + ([case_cfg3] if a.cfg3 else []) + ([case_cfg4] if a.cfg4 else [])
+    cases = ([] if a.no_387 else [case_387]) + ([case_cfg3] if a.cfg3 else [])
     for mk in cases:
         t0 = time.time()
         name, run = mk()
