@@ -384,8 +384,11 @@ int main(int argc, char** argv) {
                 // round 3: what do the two halves of the fused epilogue cost?  Same variant, same rotating weights, microseconds per launch:
                 //   q = QKV projection with the LayerNorm / RoPE / relayout epilogue, qp = the same GEMM with the plain bf16 epilogue,
                 //   f = fc1 with bias + GELU, fp = fc1 plain bf16
-                auto t_us = [&](auto&& fn) { for (int i = 0; i < 2; ++i) fn(i); CK(hipEventRecord(e0, st)); for (int i = 0; i < iters; ++i) fn(i);
-                                             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float m_; CK(hipEventElapsedTime(&m_, e0, e1)); return m_ * 1000.f / iters; };
+                // best of 3 x 40 launches (10 were too few: +-10 us between repeats of the same build)
+                auto t_us = [&](auto&& fn) { float best = 1e30f; for (int i = 0; i < 4; ++i) fn(i);
+                                             for (int rep = 0; rep < 3; ++rep) { CK(hipEventRecord(e0, st)); for (int i = 0; i < 40; ++i) fn(i);
+                                                 CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float m_; CK(hipEventElapsedTime(&m_, e0, e1)); best = std::min(best, m_ * 1000.f / 40); }
+                                             return best; };
                 const float tq = t_us([&](int i) { RC(showo_gemm_qkv_bf16(h, H, Wq1 + (size_t)(i % RW) * qstride, H, bq1, lnp, lnp + 64, lnp + 128, lnp + 192, cosT, sinT, Q1, K1, V1, B, L, nH, 32, 1e-5f, 0, L, Lp, st)); });
                 const float tqp = t_us([&](int i) { RC(showo_gemm_bf16(h, H, Wq1 + (size_t)(i % RW) * qstride, H, bq1, 0, f1, Nq, nullptr, 0, Mx, Nq, H, 0, st)); });
                 const float tf = t_us([&](int i) { RC(showo_gemm_bf16(h, H, Wq1 + (size_t)(i % RW) * qstride + (size_t)Nq * H, H, bq1 + Nq, 0, f1, F, nullptr, 0, Mx, F, H, 1, st)); });
