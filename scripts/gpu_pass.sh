@@ -1,6 +1,6 @@
 #!/bin/bash
 # One parameterised GPU pass (round 6; replaces the one-shot scripts of round 5).  usage: scripts/gpurun_built.sh <timeout> 'bash scripts/gpu_pass.sh <tag> <step> [<step> ...]'
-# steps:  tests[:<pytest -k expr>|:<file>]  smoke  bench  bench:<extra args>  train  mmu  vq  t2i512  batch1  prof-t2i  prof-train  prof-mmu  pmc
+# steps:  tests[:<pytest -k expr>|:<file>]  smoke  bench  bench:<extra args>  train  mmu  vq  t2i512  batch1  prof-t2i  prof-train  prof-mmu  pmc  pmc-mfma
 # Every step writes gpurun_out/<tag>_<step>.*; copy what is cited into profiles/.
 TAG=$1; shift
 mkdir -p gpurun_out
@@ -27,7 +27,13 @@ for step in "$@"; do
       unset SHOWO_GEMM_TUNE
       find gpurun_out/${TAG}_prof_$wl -type f ! -name "*stats*" -size +2M -delete
       f=$(find gpurun_out/${TAG}_prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_${wl}_kernel_stats.csv && head -12 "$f" ;;
-    pmc) bash scripts/gpu_pmc3.sh ${TAG} ;;
+    pmc) bash scripts/gpu_pmc3.sh ${TAG}
+         python tools/pmc_agg.py gpurun_out/${TAG}_pmc_traffic_all_kernels.json /tmp/pmc_1 /tmp/pmc_2 | head -8 ;;
+    pmc-mfma)  # MFMA busy cycles per kernel (GEMM launches, attention, conv3t of the VQ decode): one SQ / GRBM pass over the bench command
+      rm -rf /tmp/pmc_mfma
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d /tmp/pmc_mfma -o pmc -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-leg --no-accuracy-leg --no-config-legs --roofline-steps 0 --no-events > $OLDPWD/gpurun_out/${TAG}_pmc_mfma.log 2>&1)
+      python tools/pmc_agg.py gpurun_out/${TAG}_pmc_mfma_agg.json /tmp/pmc_mfma > /dev/null
+      python tools/pmc_mfma.py ${TAG} gpurun_out/${TAG}_pmc_mfma_agg.json gpurun_out/${TAG}_bench_mfma_util.json ;;
     *) bash -c "$step" > gpurun_out/${TAG}_cmd.log 2>&1; tail -30 gpurun_out/${TAG}_cmd.log ;;
   esac
 done
