@@ -15,7 +15,7 @@ def main():
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("showo::", ""))
+                name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("showo::", "").replace("g2p::", "").replace("g3w::", ""))
                 name = re.sub(r"\((?!.*<).*$", "", name)
                 a = acc[name][r["Counter_Name"]]
                 a[0] += 1

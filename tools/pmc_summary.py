@@ -20,7 +20,7 @@ def load(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("showo::", ""))
+            name = re.sub(r"^void ", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("showo::", "").replace("g2p::", "").replace("g3w::", ""))
             name = re.sub(r"\(.*", "", name)
             a = acc[name]
             a[0] += 1
