@@ -454,13 +454,16 @@ extern "C" int showo_engine_batch_begin(showo_engine* e, int nb, int cap_tokens)
         TRY(e->alloc(&d->k, need));
         TRY(e->alloc(&d->vt, need));
         d->elems = need;
+        // zeroed ONCE, when the caches are (re)allocated (the two memsets -- 600 MB at cfg4 -- ran on every call): columns of
+        // V^T beyond a sequence's live length only ever meet probabilities that are exactly 0, so they must be FINITE, not zero, and
+        // whatever an earlier batch left there is (a cache row is written by prefill / decode steps of finite activations)
+        SHOWO_CHECK_HIP(hipMemset(d->k, 0, (size_t)need * sizeof(bf16_t)));
+        SHOWO_CHECK_HIP(hipMemset(d->vt, 0, (size_t)need * sizeof(bf16_t)));
     }
     if (!d->pos_dev) {
         TRY(e->alloc(&d->pos_dev, MAXB)); TRY(e->alloc(&d->L0_dev, MAXB)); TRY(e->alloc(&d->base_dev, MAXB));
         TRY(e->alloc(&d->last_iv_dev, 4 * MAXB)); TRY(e->alloc(&d->iv_dev, 4 * MAXB));
     }
-    SHOWO_CHECK_HIP(hipMemset(d->k, 0, (size_t)need * sizeof(bf16_t)));
-    SHOWO_CHECK_HIP(hipMemset(d->vt, 0, (size_t)need * sizeof(bf16_t)));
     d->nb = nb; d->cap = cap;
     for (int b = 0; b < MAXB; ++b) { d->prompt_len[b] = 0; d->cache_len[b] = 0; }
     return 0;

@@ -734,7 +734,14 @@ def mmu_generate_batch(self, idx=None, input_embeddings=None, attention_mask=Non
     eng = self.engine()
     dev = seqs[0].device
     lens = [int(t.shape[1]) for t in seqs]
-    _lib.call("showo_engine_batch_begin", eng, n, max(lens) + max_new_tokens + 1)
+    try:
+        _lib.call("showo_engine_batch_begin", eng, n, max(lens) + max_new_tokens + 1)
+    except RuntimeError:
+        # the batch's common capacity (longest prompt + max_new_tokens) does not fit the engine (max_position_embeddings, the single-block
+        # decode attention): n sequential calls fail only if a sequence actually reaches the limit before <eot>
+        return [self.mmu_generate(idx=None if idx is None else idx[b], input_embeddings=None if input_embeddings is None else input_embeddings[b],
+                                  attention_mask=masks[b], max_new_tokens=max_new_tokens, temperature=temperature, top_k=top_k,
+                                  eot_token=eot_token) for b in range(n)]
     logits = torch.empty((n, self.vocab_size), dtype=torch.float32, device=dev)
     tok = torch.empty((n,), dtype=torch.int64, device=dev)
     for b in range(n):
