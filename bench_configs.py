@@ -46,6 +46,8 @@ def t2i512(a):
     Lseq = 129 + 1 + N + 1
     torch.manual_seed(0)
     model = synthetic.random_init_showo(max_batch=2 * B, max_seq=Lseq, ln_jitter=True, num_vq_tokens=N).eval()
+    if a.precision:
+        model.set_precision(a.precision)
     vq = showo_amd.MAGVITv2(max_batch=B, max_res=512).cuda().eval()
     uni = synthetic.prompting(max_text_len=128)
     sp = uni.sptids_dict
@@ -115,6 +117,8 @@ def mmu(a):
     from showo_amd.prompting_utils import create_attention_mask_for_mmu_vit
     torch.manual_seed(0)
     model = synthetic.random_init_showo(max_batch=1, max_seq=768, w_clip_vit=True).eval()
+    if a.precision:
+        model.set_precision(a.precision)  # (2: the batched entry point then serves the 4 sequences one by one)
     g = torch.Generator().manual_seed(22)
     sd = {}
     for k, shape in vision_state_spec(CLIP_VIT_L_14_336).items():  # random-init weights of the true ViT-L/14-336 architecture
@@ -340,11 +344,15 @@ def main(argv):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="Showo.set_precision: 0 bf16 operands (default), 1 accuracy mode, 2 fp16 operands")
     a, _ = ap.parse_known_args(argv)
     if a.gpus != 1:
         raise SystemExit("bench: the t2i512 / mmu / vq workloads are single-GPU lines (replicas scale like the headline)")
     torch.cuda.set_device(0)
     out = {"t2i512": t2i512, "mmu": mmu, "vq": vq}[a.workload](a)
+    if a.precision and isinstance(out.get("config"), dict):
+        out["config"]["precision"] = {1: "accuracy mode (split-bf16)", 2: "fp16 operands, split-bf16 lm_head"}.get(a.precision, str(a.precision))
+        out["dtype"] = {1: "bf16x3", 2: "f16"}.get(a.precision, out.get("dtype"))
     print(json.dumps(out))
 
 

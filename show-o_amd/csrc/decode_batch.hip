@@ -54,6 +54,7 @@ struct LnGemvBArgs {
     const float* b1;
     bf16_t* out1;
     int N1, ld1;
+    const bf16_t* W0lo = nullptr;  // HEAD3 instances (precision 2's lm_head): low halves of W0's rows, same layout
 };
 
 // REG (NB <= 4): after the LayerNorm every lane keeps ITS 32 activation values of each sequence in registers as 16 packed bf16 pairs
@@ -61,19 +62,28 @@ struct LnGemvBArgs {
 // conversion and no LDS read -- with the activations re-read from LDS per row (the batch-1 form, !REG) four sequences made the step
 // VALU / LDS-bound.  Fewer, longer-lived waves (2 blocks per CU) amortise the register fill (grid caps 256 / 1024 and 4 rows in flight
 // measured slower: profiles/r5_decode_batch_sweep.txt).  Same products and the same accumulation order per sequence either way.
-template <int NB, bool REG>
+// F16: weights and 16-bit activations are IEEE half (precision 2; common.h Op16).  HEAD3 (precision 2's lm_head, fp32 logits only): the
+// normalised row is kept as a (hi, lo) bf16 pair and the weights come as (hi, lo) bf16 rows (W0, W0lo): acc = hi.hi + lo.hi + hi.lo in
+// ONE chain per sequence -- the split-bf16 product of engine.hip head_rows_precise_fast without its 3 H image (2 x 240 MB instead of
+// 719 MB per token step) and without a separate LayerNorm launch.
+template <int NB, bool REG, bool F16 = false, bool HEAD3 = false>
 __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H <= 2048; 2 weight rows in flight per wave (4: measured slower)
+    static_assert(!(HEAD3 && (REG || F16)), "the split head keeps its activations in LDS and multiplies bf16 halves");
     constexpr int R = 2;
-    extern __shared__ bf16_t sh[];  // [NB][H] normalised rows (bf16, like showo_layernorm_f32_bf16's output)
+    extern __shared__ bf16_t sh[];  // [NB][H] normalised rows (16-bit, like showo_layernorm_f32_op16's output); HEAD3: [NB][2 H] = hi | lo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
     const int H = g.H, Ntot = g.N0 + g.N1;
     const int stride = gridDim.x * 4;
     int n = blockIdx.x * 4 + wave;
     auto rowp = [&](int c) { return c < g.N0 ? g.W0 + (int64_t)c * H : g.W1 + (int64_t)(c - g.N0) * H; };
-    uint4 br[R][4];
+    uint4 br[R][4], bl[HEAD3 ? R : 1][4];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (n + r * stride < Ntot) load4(rowp(n + r * stride), lane * 8, H, br[r]);
+        if (n + r * stride < Ntot) {
+            load4(rowp(n + r * stride), lane * 8, H, br[r]);
+            if constexpr (HEAD3) load4(g.W0lo + (int64_t)(n + r * stride) * H, lane * 8, H, bl[r]);
+        }
+    constexpr int LDH = HEAD3 ? 2 : 1;  // activation row stride in LDS, in units of H
     // LayerNorm: wave w normalises rows w, w + 4, ... with ln_gemv2_kernel's lane split and expressions (same bits per row)
     for (int b = wave; b < NB; b += 4) {
         const float* xr = g.x + (int64_t)b * H;
@@ -103,10 +113,18 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
                 const float4 v = xv[j];
                 const float4 w = *reinterpret_cast<const float4*>(g.lnw + i);
                 const float4 bb = *reinterpret_cast<const float4*>(g.lnb + i);
+                const float y0 = (v.x - mean) * rstd * w.x + bb.x, y1 = (v.y - mean) * rstd * w.y + bb.y;
+                const float y2 = (v.z - mean) * rstd * w.z + bb.z, y3 = (v.w - mean) * rstd * w.w + bb.w;
                 uint2 o;
-                o.x = pack_bf2((v.x - mean) * rstd * w.x + bb.x, (v.y - mean) * rstd * w.y + bb.y);
-                o.y = pack_bf2((v.z - mean) * rstd * w.z + bb.z, (v.w - mean) * rstd * w.w + bb.w);
-                *reinterpret_cast<uint2*>(sh + b * H + i) = o;
+                o.x = Op16<F16>::pack2(y0, y1);
+                o.y = Op16<F16>::pack2(y2, y3);
+                *reinterpret_cast<uint2*>(sh + b * LDH * H + i) = o;
+                if constexpr (HEAD3) {  // low halves: y - bf16(y), rounded to bf16 (precise.hip ln_split3_kernel's expressions)
+                    uint2 lo;
+                    lo.x = pack_bf2(y0 - bf2f((bf16_t)(o.x & 0xffffu)), y1 - bf2f((bf16_t)(o.x >> 16)));
+                    lo.y = pack_bf2(y2 - bf2f((bf16_t)(o.y & 0xffffu)), y3 - bf2f((bf16_t)(o.y >> 16)));
+                    *reinterpret_cast<uint2*>(sh + b * LDH * H + H + i) = lo;
+                }
             }
         }
     }
@@ -125,12 +143,22 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
                 if constexpr (REG) {
 #pragma unroll
                     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-                    fma4_regs<NB>(br[r], act, lane * 8, H, acc);
+                    fma4_regs<NB, F16>(br[r], act, lane * 8, H, acc);
+                } else if constexpr (HEAD3) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {  // K' = [hi.hi | lo.hi | hi.lo], one chain (the order of the 3 H GEMV it replaces)
+                        float t = fma4(br[r], sh + b * 2 * H, lane * 8, H, 0.f);
+                        t = fma4(br[r], sh + b * 2 * H + H, lane * 8, H, t);
+                        acc[b] = fma4(bl[r], sh + b * 2 * H, lane * 8, H, t);
+                    }
                 } else {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] = fma4(br[r], sh + b * H, lane * 8, H, 0.f);
+                    for (int b = 0; b < NB; ++b) acc[b] = fma4<F16>(br[r], sh + b * H, lane * 8, H, 0.f);
                 }
-                if (c + R * stride < Ntot) load4(rowp(c + R * stride), lane * 8, H, br[r]);
+                if (c + R * stride < Ntot) {
+                    load4(rowp(c + R * stride), lane * 8, H, br[r]);
+                    if constexpr (HEAD3) load4(g.W0lo + (int64_t)(c + R * stride) * H, lane * 8, H, bl[r]);
+                }
                 if constexpr (NB <= 4) {  // lane 16 b finishes sequence b (wave_sum's order of additions per sequence: decode_common.h)
                     const float tot = wave_sum_groups<NB>(acc);
                     const int b = lane >> 4;
@@ -138,9 +166,9 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
                         if (c < g.N0) {
                             const float v = tot + g.b0[c];
                             if (g.outf) g.outf[(int64_t)b * g.ld0 + c] = v;
-                            else g.out0[(int64_t)b * g.ld0 + c] = f2bf(v);
+                            else g.out0[(int64_t)b * g.ld0 + c] = Op16<F16>::cvt(v);
                         } else {
-                            g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = f2bf(gelu_new_fast(tot + g.b1[c - g.N0]));
+                            g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = Op16<F16>::cvt(gelu_new_fast(tot + g.b1[c - g.N0]));
                         }
                     }
                 } else {
@@ -153,12 +181,12 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
                             for (int b = 0; b < NB; ++b) {
                                 const float v = acc[b] + bias;
                                 if (g.outf) g.outf[(int64_t)b * g.ld0 + c] = v;
-                                else g.out0[(int64_t)b * g.ld0 + c] = f2bf(v);
+                                else g.out0[(int64_t)b * g.ld0 + c] = Op16<F16>::cvt(v);
                             }
                         } else {
                             const float bias = g.b1[c - g.N0];
 #pragma unroll
-                            for (int b = 0; b < NB; ++b) g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = f2bf(gelu_new_fast(acc[b] + bias));
+                            for (int b = 0; b < NB; ++b) g.out1[(int64_t)b * g.ld1 + (c - g.N0)] = Op16<F16>::cvt(gelu_new_fast(acc[b] + bias));
                         }
                     }
                 }
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemvB_kernel(LnGemvBArgs g) {  // H
 }
 
 // C = 2048-element chunks per output column (dense chunks first, then fc2 chunks), all in flight per wave (out_gemv2_kernel<C, 0>)
-template <int C, int NB>
+template <int C, int NB, bool F16 = false>
 __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
     extern __shared__ bf16_t sa[];  // [NB][K0 + K1]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
@@ -200,8 +228,8 @@ __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
         for (int t = 0; t < C; ++t) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                if (t < c0) acc0[b] = fma4(buf[t], sa + b * KK, t * 2048 + lane * 8, g.K0, acc0[b]);
-                else acc1[b] = fma4(buf[t], sa + b * KK + g.K0, (t - c0) * 2048 + lane * 8, g.K1, acc1[b]);
+                if (t < c0) acc0[b] = fma4<F16>(buf[t], sa + b * KK, t * 2048 + lane * 8, g.K0, acc0[b]);
+                else acc1[b] = fma4<F16>(buf[t], sa + b * KK + g.K0, (t - c0) * 2048 + lane * 8, g.K1, acc1[b]);
             }
             if (nn < g.N) issue(nn, t, buf[t]);
         }
@@ -237,7 +265,7 @@ __global__ __launch_bounds__(512) void out_gemvB_kernel(OutGemvBArgs g) {
 // Third launch of the co-scheduled batched layer: x[b][n] = (x[b][n] + (dense(attn[b]) + bd)) + y2[b][n]  (out_gemv2_kernel<1, 2>'s
 // expression; y2 = fc2 + b2 from the fc2 role of the attention launch).  K0 <= 2048: the lane's 32 attention values per sequence stay
 // in registers.
-template <int NB>
+template <int NB, bool F16 = false>
 __global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row bases live in SGPRs
     const int stride = gridDim.x * 8;
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(512) void out_dense_y2B_kernel(OutGemvBArgs g) {
         float acc0[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc0[b] = 0.f;
-        fma4_regs<NB>(buf, act, lane * 8, g.K0, acc0);
+        fma4_regs<NB, F16>(buf, act, lane * 8, g.K0, acc0);
         if (nn < g.N) load4(g.W0 + (int64_t)nn * g.K0, lane * 8, g.K0, buf);
         const float tot = wave_sum_groups<NB>(acc0);
         if (writer) {
@@ -333,39 +361,46 @@ __global__ __launch_bounds__(1024) void greedy_seam_rows_kernel(const float* __r
 }
 
 template <int NB>
-int launch_ln_gemvB(const LnGemvBArgs& g, hipStream_t s) {
+int launch_ln_gemvB(const LnGemvBArgs& g, hipStream_t s, int op, bool head3) {
     const int Ntot = g.N0 + g.N1;
-    if (NB <= 4) {  // register-resident activations (16 NB packed registers per lane): up to 4 blocks per CU resident
+    if (head3) {  // precision 2's lm_head: (hi, lo) activations in LDS, (hi, lo) bf16 weight rows
+        if (!g.W0lo || !g.outf || g.N1) return set_error_msg(1, "ln_gemvB: the split head writes fp32 logits from (hi, lo) weight rows");
+        int blocks = (Ntot + 11) / 12;
+        if (blocks > 1280) blocks = 1280;
+        ln_gemvB_kernel<NB, false, false, true><<<dim3(blocks), dim3(256), (size_t)NB * 2 * g.H * sizeof(bf16_t), s>>>(g);
+    } else if (NB <= 4) {  // register-resident activations (16 NB packed registers per lane): up to 4 blocks per CU resident
         int blocks = (Ntot + 7) / 8;
         const int cap = showo::decode_tuning().batch_ln_blocks;
         if (blocks > cap) blocks = cap;
-        ln_gemvB_kernel<NB, (NB <= 4)><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+        if (op) ln_gemvB_kernel<NB, (NB <= 4), true><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+        else ln_gemvB_kernel<NB, (NB <= 4)><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
     } else {
         int blocks = (Ntot + 11) / 12;
         if (blocks > 1280) blocks = 1280;
-        ln_gemvB_kernel<NB, false><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+        if (op) ln_gemvB_kernel<NB, false, true><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
+        else ln_gemvB_kernel<NB, false><<<dim3(blocks), dim3(256), (size_t)NB * g.H * sizeof(bf16_t), s>>>(g);
     }
     return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "ln_gemvB launch failed");
 }
-int ln_gemvB(int nb, const LnGemvBArgs& g, hipStream_t s) {
+int ln_gemvB(int nb, const LnGemvBArgs& g, hipStream_t s, int op = 0, bool head3 = false) {
     switch (nb) {
-        case 1: return launch_ln_gemvB<1>(g, s);
-        case 2: return launch_ln_gemvB<2>(g, s);
-        case 3: return launch_ln_gemvB<3>(g, s);
-        case 4: return launch_ln_gemvB<4>(g, s);
-        case 5: return launch_ln_gemvB<5>(g, s);
-        case 6: return launch_ln_gemvB<6>(g, s);
-        case 7: return launch_ln_gemvB<7>(g, s);
-        case 8: return launch_ln_gemvB<8>(g, s);
+        case 1: return launch_ln_gemvB<1>(g, s, op, head3);
+        case 2: return launch_ln_gemvB<2>(g, s, op, head3);
+        case 3: return launch_ln_gemvB<3>(g, s, op, head3);
+        case 4: return launch_ln_gemvB<4>(g, s, op, head3);
+        case 5: return launch_ln_gemvB<5>(g, s, op, head3);
+        case 6: return launch_ln_gemvB<6>(g, s, op, head3);
+        case 7: return launch_ln_gemvB<7>(g, s, op, head3);
+        case 8: return launch_ln_gemvB<8>(g, s, op, head3);
     }
     return set_error_msg(1, "batched decode: 1..8 sequences");
 }
 
-template <int C, int NB>
+template <int C, int NB, bool F16>
 int launch_out_gemvB(const OutGemvBArgs& g, hipStream_t s) {
     static bool attr_set = false;
     const size_t smem = (size_t)NB * (g.K0 + g.K1) * sizeof(bf16_t);
-    auto kfn = out_gemvB_kernel<C, NB>;
+    auto kfn = out_gemvB_kernel<C, NB, F16>;
     if (!attr_set && smem > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error_hip(e, "hipFuncSetAttribute(out_gemvB)", __FILE__, __LINE__);
@@ -378,42 +413,56 @@ int launch_out_gemvB(const OutGemvBArgs& g, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "out_gemvB launch failed");
 }
 template <int NB>
-int out_gemvB_c(const OutGemvBArgs& g, hipStream_t s) {
+int out_gemvB_c(const OutGemvBArgs& g, hipStream_t s, int op) {
     const int C = (g.K0 + 2047) / 2048 + (g.K1 + 2047) / 2048;
     switch (C) {
-        case 2: return launch_out_gemvB<2, NB>(g, s);
-        case 3: return launch_out_gemvB<3, NB>(g, s);
-        case 4: return launch_out_gemvB<4, NB>(g, s);
-        case 5: return launch_out_gemvB<5, NB>(g, s);
+        case 2: return op ? launch_out_gemvB<2, NB, true>(g, s) : launch_out_gemvB<2, NB, false>(g, s);
+        case 3: return op ? launch_out_gemvB<3, NB, true>(g, s) : launch_out_gemvB<3, NB, false>(g, s);
+        case 4: return op ? launch_out_gemvB<4, NB, true>(g, s) : launch_out_gemvB<4, NB, false>(g, s);
+        case 5: return op ? launch_out_gemvB<5, NB, true>(g, s) : launch_out_gemvB<5, NB, false>(g, s);
     }
     return set_error_msg(1, "batched decode: unsupported K0 / K1 (decode_fused_shapes_ok)");
 }
-int out_dense_y2B(int nb, const OutGemvBArgs& g, hipStream_t s) {
+int out_dense_y2B(int nb, const OutGemvBArgs& g, hipStream_t s, int op) {
     int blocks = (g.N + 7) / 8;
     if (blocks > showo::decode_tuning().out_blocks) blocks = showo::decode_tuning().out_blocks;
-    switch (nb) {
-        case 2: out_dense_y2B_kernel<2><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
-        case 3: out_dense_y2B_kernel<3><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
-        case 4: out_dense_y2B_kernel<4><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+    switch (nb * 2 + (op ? 1 : 0)) {
+        case 4: out_dense_y2B_kernel<2><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 6: out_dense_y2B_kernel<3><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 8: out_dense_y2B_kernel<4><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 5: out_dense_y2B_kernel<2, true><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 7: out_dense_y2B_kernel<3, true><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
+        case 9: out_dense_y2B_kernel<4, true><<<dim3(blocks), dim3(512), 0, s>>>(g); break;
         default: return set_error_msg(1, "batched decode: the co-scheduled layer serves 2..4 sequences");
     }
     return hipGetLastError() == hipSuccess ? 0 : set_error_msg(7, "out_dense_y2B launch failed");
 }
-int out_gemvB(int nb, const OutGemvBArgs& g, hipStream_t s) {
+int out_gemvB(int nb, const OutGemvBArgs& g, hipStream_t s, int op) {
     switch (nb) {
-        case 1: return out_gemvB_c<1>(g, s);
-        case 2: return out_gemvB_c<2>(g, s);
-        case 3: return out_gemvB_c<3>(g, s);
-        case 4: return out_gemvB_c<4>(g, s);
-        case 5: return out_gemvB_c<5>(g, s);
-        case 6: return out_gemvB_c<6>(g, s);
-        case 7: return out_gemvB_c<7>(g, s);
-        case 8: return out_gemvB_c<8>(g, s);
+        case 1: return out_gemvB_c<1>(g, s, op);
+        case 2: return out_gemvB_c<2>(g, s, op);
+        case 3: return out_gemvB_c<3>(g, s, op);
+        case 4: return out_gemvB_c<4>(g, s, op);
+        case 5: return out_gemvB_c<5>(g, s, op);
+        case 6: return out_gemvB_c<6>(g, s, op);
+        case 7: return out_gemvB_c<7>(g, s, op);
+        case 8: return out_gemvB_c<8>(g, s, op);
     }
     return set_error_msg(1, "batched decode: 1..8 sequences");
 }
 
 }  // namespace
+
+namespace showo {
+// LayerNorm + lm_head of `nb` residual rows as the split-bf16 product (precision 2's head on a decode step): logits[b][n] = fp32,
+// row stride ld.  One launch, 2 x [N, H] bf16 of weights (ln_gemvB_kernel<.., HEAD3>); the batched loop and the batch-1 step share it.
+int decode_split_head(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* Whi, const bf16_t* Wlo,
+                      const float* bias, float* logits, int N, int ld, int nb, hipStream_t s) {
+    LnGemvBArgs h{x, lnw, lnb, eps, H, Whi, bias, nullptr, logits, N, ld, nullptr, nullptr, nullptr, 0, 0};
+    h.W0lo = Wlo;
+    return ln_gemvB(nb, h, s, 0, true);
+}
+}  // namespace showo
 
 // ---- engine entry points ------------------------------------------------------------------------------------------------------
 // State of a decode batch: per-layer caches [nb][heads][cap][64] (K) / [nb][heads][64][cap] (V^T), per-sequence prompt length,
@@ -427,6 +476,7 @@ struct showo_engine::BatchDecode {
     int *pos_dev = nullptr, *L0_dev = nullptr, *base_dev = nullptr;
     int32_t *last_iv_dev = nullptr, *iv_dev = nullptr;
     float* y2 = nullptr;  // [nb, H] fc2 + b2 of the current layer (co-scheduled form)
+    int precision = 0;    // the precision the caches were prefilled under (element type of K / V^T)
 };
 
 namespace showo {
@@ -483,12 +533,13 @@ extern "C" int showo_engine_batch_prefill(showo_engine* e, int b, const int64_t*
     if (L + 1 > d->cap) return set_error_msg(5, "batch_prefill: prompt exceeds the batch's cache capacity");
     if (showo_engine_missing(e) != 0) return set_error_msg(4, "engine: weights missing (showo_engine_missing() != 0)");
     if (L < 1 || L > e->maxT || L > e->cfg.max_seq || L > e->cfg.max_pos) return set_error_msg(5, "engine: sequence exceeds the configured workspace");
-    if (e->precision != 0) return set_error_msg(1, "batch_prefill: the batched decode runs with bf16 operands (showo_engine_set_precision(e, 0))");
+    if (e->precision == 1) return set_error_msg(1, "batch_prefill: the batched decode runs at precision 0 (bf16 operands) or 2 (fp16 operands)");
     const int64_t per_seq = (int64_t)e->nH * d->cap * 64, lstride = (int64_t)d->nb * per_seq;
     TRY(showo::engine_prefill_into(e, ids, embeds, mask, L, d->k + b * per_seq, d->vt + b * per_seq, lstride, lstride, d->cap, d->last_iv[b],
                                    logits_last, (hipStream_t)stream, nullptr, nullptr));
     d->prompt_len[b] = L;
     d->cache_len[b] = L;
+    d->precision = e->precision;
     return 0;
 }
 
@@ -502,7 +553,11 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
     auto* d = e->bd;
     const int nb = d->nb, H = e->H, F = e->F, nH = e->nH, V = e->V;
     if (!tok || !out_tokens || !logits_ws || n_steps < 1) return set_error_msg(1, "batch_decode_greedy: bad arguments");
-    if (e->precision != 0) return set_error_msg(1, "batch_decode_greedy: bf16 operands only");
+    if (e->precision == 1) return set_error_msg(1, "batch_decode_greedy: precision 0 (bf16 operands) or 2 (fp16 operands)");
+    const int op = e->precision == 2 ? SHOWO_OP_F16 : SHOWO_OP_BF16;
+    if ((op == SHOWO_OP_F16) != e->img_f16) return set_error_msg(4, "batch_decode_greedy: the weight images hold the other 16-bit type: upload the weights again");
+    if (d->precision != e->precision) return set_error_msg(1, "batch_decode_greedy: the caches were prefilled under another precision: prefill again");
+    if (op && (!e->wlm_lo || !e->lo_loaded.count("showo.lm_head.weight"))) return set_error_msg(4, "batch_decode_greedy (precision 2): the lm_head's low half is missing: upload the weights again");
     int lk_max = 0;
     int P0[MAXB];
     for (int b = 0; b < nb; ++b) {
@@ -537,7 +592,7 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
         for (int li = 0; li < e->nL; ++li) {
             showo::Layer& l = e->layers[li];
             LnGemvBArgs a{e->x, l.ln_w, l.ln_b, e->cfg.ln_eps, H, l.wqkv, l.bqkv, e->qkv, nullptr, 3 * H, 3 * H, l.w1, l.b1, e->ffn, F, F};
-            TRY(ln_gemvB(nb, a, s));
+            TRY(ln_gemvB(nb, a, s, op));
             OutGemvBArgs o{e->x, l.wd, e->attn, l.bd, H, H, l.w2, e->ffn, l.b2, F, F, H, d->y2};
             if (co) {
                 // [ attention of the nb x heads (sequence, head) pairs || fc2 of all nb sequences -> y2 ] -> dense + both residual adds
@@ -547,17 +602,21 @@ extern "C" int showo_engine_batch_decode_greedy(showo_engine* e, int64_t* tok, i
                 showo::decode_prefetch_plan(e, li, &pf);
                 TRY(showo::attn_decode_co_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,
                                                 d->vt + li * lstride, d->iv_dev, e->attn, nb, nH, e->cfg.rotary_dim, e->cfg.ln_eps,
-                                                d->pos_dev, lk_max, d->cap, d->cap, o, co_blocks, s, &pf));
-                TRY(out_dense_y2B(nb, o, s));
+                                                d->pos_dev, lk_max, d->cap, d->cap, o, co_blocks, s, &pf, op));
+                TRY(out_dense_y2B(nb, o, s, op));
             } else {
                 TRY(showo::attn_decode_fused_batch(e->qkv, l.qln_w, l.qln_b, l.kln_w, l.kln_b, e->cosT, e->sinT, d->k + li * lstride,
                                                    d->vt + li * lstride, d->iv_dev, e->attn, nb, nH, e->cfg.rotary_dim, e->cfg.ln_eps,
-                                                   d->pos_dev, lk_max, d->cap, d->cap, s));
-                TRY(out_gemvB(nb, o, s));
+                                                   d->pos_dev, lk_max, d->cap, d->cap, s, op));
+                TRY(out_gemvB(nb, o, s, op));
             }
         }
-        LnGemvBArgs h{e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, H, e->wlm, e->blm, nullptr, logits_ws, V, V, nullptr, nullptr, nullptr, 0, 0};
-        TRY(ln_gemvB(nb, h, s));
+        if (op) {  // precision 2: the lm_head is the split-bf16 product (its images stay bf16 (hi, lo) at that precision)
+            TRY(showo::decode_split_head(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, H, e->wlm, e->wlm_lo, e->blm, logits_ws, V, V, nb, s));
+        } else {
+            LnGemvBArgs h{e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, H, e->wlm, e->blm, nullptr, logits_ws, V, V, nullptr, nullptr, nullptr, 0, 0};
+            TRY(ln_gemvB(nb, h, s));
+        }
         greedy_seam_rows_kernel<<<dim3(nb), dim3(1024), 0, s>>>(logits_ws, V, tok, out_tokens, n_steps, d->pos_dev, d->base_dev, e->embed, e->x,
                                                                H, d->last_iv_dev, d->L0_dev, d->iv_dev);
         SHOWO_CHECK_HIP(hipGetLastError());

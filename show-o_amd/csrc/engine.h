@@ -39,6 +39,8 @@ bool decode_fused_shapes_ok(int H, int F);
 int decode_ln_gemv2(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* W0, const float* b0,
                     bf16_t* out0, float* outf, int N0, const bf16_t* W1, const float* b1, bf16_t* out1, int N1, hipStream_t s,
                     int op = 0);  // op: SHOWO_OP_BF16 | SHOWO_OP_F16 -- the element type of weights and 16-bit activations (all decode entry points)
+int decode_split_head(const float* x, const float* lnw, const float* lnb, float eps, int H, const bf16_t* Whi, const bf16_t* Wlo,
+                      const float* bias, float* logits, int N, int ld, int nb, hipStream_t s);  // decode_batch.hip: precision 2's head on a decode step
 int decode_out_gemv2(float* x, const bf16_t* W0, const bf16_t* a0, const float* b0, int K0, const bf16_t* W1, const bf16_t* a1,
                      const float* b1, int K1, int N, hipStream_t s, int mode = 0, float* y2 = nullptr, int op = 0);
 int attn_decode_fused(const bf16_t* qkv, const float* qw, const float* qb, const float* kw, const float* kb, const float* cosT,

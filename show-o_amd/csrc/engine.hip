@@ -833,7 +833,15 @@ static int head_rows(showo_engine* e, const int32_t* rows, int nrows, int col0, 
     if (col0 < 0 || ncols <= 0 || col0 + ncols > e->V) return set_error_msg(1, "engine: bad vocabulary slice");
     if (e->precision == 1) return precise_fast_ok(e) ? head_rows_precise_fast(e, rows, nrows, col0, ncols, logits, s)
                                                        : head_rows_precise(e, rows, nrows, col0, ncols, logits, s);
-    if (e->precision == 2) return head_rows_precise_fast(e, rows, nrows, col0, ncols, logits, s);  // the split-bf16 head (any shape)
+    if (e->precision == 2) {
+        // the split-bf16 head; a decode step (one row) takes the fused LayerNorm + (hi, lo) GEMV: 2 x 240 MB of weights in one launch
+        // instead of the LayerNorm launch + a GEMV over the 719 MB [hi | hi | lo] image
+        if (nrows == 1 && !rows && showo::g_decode_impl == 0 && showo::decode_fused_shapes_ok(e->H, e->F) && e->wlm_lo &&
+            e->lo_loaded.count("showo.lm_head.weight"))
+            return showo::decode_split_head(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, e->H, e->wlm + (int64_t)col0 * e->H,
+                                            e->wlm_lo + (int64_t)col0 * e->H, e->blm + col0, logits, ncols, ncols, 1, s);
+        return head_rows_precise_fast(e, rows, nrows, col0, ncols, logits, s);  // (any shape)
+    }
     if (nrows == 1 && !rows && showo::g_decode_impl == 0 && showo::decode_fused_shapes_ok(e->H, e->F))  // decode step: LN + lm_head in one launch
         return showo::decode_ln_gemv2(e->x, e->fln_w, e->fln_b, e->cfg.ln_eps, e->H, e->wlm + (int64_t)col0 * e->H, e->blm + col0,
                                       nullptr, logits, ncols, nullptr, nullptr, nullptr, 0, s);

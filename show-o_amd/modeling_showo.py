@@ -385,7 +385,7 @@ class Showo(PretrainedMixin, nn.Module):
         the same, operand rounding is 2^-12 instead of 2^-9 -- with the final LayerNorm + lm_head as the split-bf16 product of
         precision 1: logits within 1e-3 of the reference's fp32 inference (rel_rms ~8e-4 at model scale where bf16 operands give
         7e-3) at the speed of the default path.  Converts saturate at +-65504 (`range_check()` counts saturated activations);
-        the KV-cached decode steps run the fp16 instances of the fused three-launch layer (csrc/decode.hip), mmu_generate_batch falls back to n batch-1 calls, the
+        the KV-cached decode steps run the fp16 instances of the fused three-launch layer and of the batched layer (csrc/decode.hip, decode_batch.hip; the lm_head of a decode step is one fused LayerNorm + (hi, lo) GEMV launch), the
         mm_projector runs in its fp32-class mode (it is one small MLP).  Switching to / from 2 re-uploads the weight images."""
         if int(precision) not in (0, 1, 2):
             raise ValueError("precision must be 0 (bf16 operands), 1 (split-bf16, fp32-class) or 2 (fp16 operands)")
@@ -721,12 +721,12 @@ def mmu_generate_batch(self, idx=None, input_embeddings=None, attention_mask=Non
     inference_mmu.py:87-177 walks the images one by one).  `idx` / `input_embeddings` / `attention_mask` are LISTS (one entry per
     sequence, each what a single `mmu_generate` call takes: [1, L_b] ids or [1, L_b, H] embeddings, its own mask or IntervalMask);
     returns a list of n token lists -- exactly what n separate calls return.  Greedy (`top_k=1`, the reference caller's setting,
-    inference_mmu.py:81) with bf16 operands runs on the batched engine path (csrc/decode_batch.hip: n KV caches, ONE weight stream per
+    inference_mmu.py:81) at precision 0 or 2 runs on the batched engine path (csrc/decode_batch.hip: n KV caches, ONE weight stream per
     token step, every sequence bit-identical to its batch-1 run); anything else falls back to n sequential calls."""
     seqs = idx if idx is not None else input_embeddings
     n = len(seqs)
     masks = attention_mask if isinstance(attention_mask, (list, tuple)) else [attention_mask] * n
-    if top_k != 1 or int(getattr(self, "_precision", 0)) != 0 or n > 8 or n < 2:
+    if top_k != 1 or int(getattr(self, "_precision", 0)) == 1 or n > 8 or n < 2:
         return [self.mmu_generate(idx=None if idx is None else idx[b], input_embeddings=None if input_embeddings is None else input_embeddings[b],
                                   attention_mask=masks[b], max_new_tokens=max_new_tokens, temperature=temperature, top_k=top_k,
                                   eot_token=eot_token) for b in range(n)]

@@ -26,11 +26,13 @@ def _prompts(d, g, n):
     return out
 
 
+@pytest.mark.parametrize("precision", [0, 2])  # 2 (round 6): fp16 instances of the batched kernels + the fused split-bf16 head
 @pytest.mark.parametrize("n", [2, 3, 4, 8])
-def test_tiny_mmu_generate_batch_equals_n_single_calls(n):
+def test_tiny_mmu_generate_batch_equals_n_single_calls(n, precision):
     g = util.golden("showo_tiny_mmu.npz")
     d, sd = util.tiny_state()
     m = util.build_showo(d, sd)
+    m.set_precision(precision)
     ids = _prompts(d, g, n)
     assert len({t.shape[1] for t in ids}) > 1  # ragged: every sequence has its own length, position and mask row
     masks = [O.mask_mmu(t, d.eoi_id).cuda() for t in ids]
@@ -58,12 +60,14 @@ def test_tiny_mmu_generate_batch_equals_n_single_calls(n):
     assert [[int(t) for t in r] for r in gp] == [[int(t) for t in m.mmu_generate(ids[b], attention_mask=masks[b], max_new_tokens=6, top_k=1)] for b in range(2)]
 
 
-def test_batch_decode_logits_are_the_bits_of_the_batch1_run():
+@pytest.mark.parametrize("precision", [0, 2])
+def test_batch_decode_logits_are_the_bits_of_the_batch1_run(precision):
     """C ABI: showo_engine_batch_prefill / _batch_decode_greedy against showo_engine_prefill / _decode_greedy, logits workspace compared
     bit for bit after the same number of steps; capacity / order errors are refused"""
     g = util.golden("showo_tiny_mmu.npz")
     d, sd = util.tiny_state()
     m = util.build_showo(d, sd)
+    m.set_precision(precision)
     L = util.lib()
     eng = m.engine()
     n, steps = 3, 5

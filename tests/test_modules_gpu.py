@@ -676,7 +676,7 @@ def test_full_size_cfg4_mmu_vit_prefill_and_greedy_decode_vs_reference():
         if j + 1 < len(toks_ref):
             tok = torch.tensor([t], dtype=torch.int64, device="cuda")
             L.call("showo_engine_decode_step", eng, L.ptr(tok), None, L.ptr(logits), L.stream())
-    # the batched entry point serves precision 2 as n batch-1 calls (its kernels have bf16 instances only): same tokens
+    # the batched entry point at precision 2 (fp16 instances of the batched kernels + the fused split head since round 6): same tokens
     got2 = [[int(t) for t in r] for r in m.mmu_generate_batch(input_embeddings=[embh, embh[:, :620].contiguous()],
                                                               attention_mask=[am[0], P.create_attention_mask_for_mmu_vit(embh[:, :620], system_prompt_len=28)[0]],
                                                               max_new_tokens=8, top_k=1)]
